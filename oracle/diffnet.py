@@ -1,0 +1,64 @@
+"""DiffNet (WaveNet-style noise predictor) — CPU oracle.
+
+Follows /root/reference/train_bisinger/usr/diff/net.py:
+  SinusoidalPosEmb :32-44, ResidualBlock :58-78, DiffNet.forward :107-130,
+  Mish = x*tanh(softplus(x)) (usr/diff/diffusion.py:68-70).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def mish(x):
+    return x * torch.tanh(F.softplus(x))
+
+
+def sinusoidal_pos_emb(t, dim):
+    """net.py:37-44 — evaluated in float32 from the int64 step, cat(sin, cos), divisor half-1."""
+    half = dim // 2
+    e = math.log(10000) / (half - 1)
+    e = torch.exp(torch.arange(half) * -e)            # float32, as in the reference
+    e = t[:, None] * e[None, :]                        # int64 * float32 -> float32
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def step_embedding(sd, t, C, prefix='', dtype=torch.float32):
+    """net.py:119-120 — SinusoidalPosEmb -> Linear -> Mish -> Linear.  Returns [B, C]."""
+    g = lambda k: sd[prefix + k].to(dtype)
+    e = sinusoidal_pos_emb(t, C).to(dtype)
+    h = mish(F.linear(e, g('mlp.0.weight'), g('mlp.0.bias')))
+    return F.linear(h, g('mlp.2.weight'), g('mlp.2.bias'))
+
+
+def residual_block(sd, p, x, cond, d, dilation, dtype=torch.float32):
+    """net.py:66-78.  gate = first C channels -> sigmoid, filter = last C -> tanh;
+    residual = first C of the output projection, skip = last C."""
+    g = lambda k: sd[p + k].to(dtype)
+    dp = F.linear(d, g('diffusion_projection.weight'), g('diffusion_projection.bias')).unsqueeze(-1)
+    c = F.conv1d(cond, g('conditioner_projection.weight'), g('conditioner_projection.bias'))
+    y = F.conv1d(x + dp, g('dilated_conv.weight'), g('dilated_conv.bias'),
+                 padding=dilation, dilation=dilation) + c
+    gate, filt = torch.chunk(y, 2, dim=1)
+    y = torch.sigmoid(gate) * torch.tanh(filt)
+    y = F.conv1d(y, g('output_projection.weight'), g('output_projection.bias'))
+    res, skip = torch.chunk(y, 2, dim=1)
+    return (x + res) / math.sqrt(2.0), skip
+
+
+def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=torch.float32):
+    """spec [B,1,M,T], t [B] int64, cond [B,H,T] -> eps [B,1,M,T]   (net.py:107-130)."""
+    g = lambda k: sd[prefix + k].to(dtype)
+    spec = spec.to(dtype)
+    cond = cond.to(dtype)
+    x = spec[:, 0]
+    x = F.relu(F.conv1d(x, g('input_projection.weight'), g('input_projection.bias')))
+    d = step_embedding(sd, t, x.shape[1], prefix, dtype)
+    skips = []
+    for i in range(n_layers):
+        x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype)
+        skips.append(s)
+    x = torch.sum(torch.stack(skips), dim=0) / math.sqrt(n_layers)
+    x = F.relu(F.conv1d(x, g('skip_projection.weight'), g('skip_projection.bias')))
+    x = F.conv1d(x, g('output_projection.weight'), g('output_projection.bias'))
+    return x[:, None, :, :]
