@@ -1,0 +1,90 @@
+"""ctypes binding of libbisinger_hip.so (include/bisinger_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, the product path raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
+ABI_VERSION = 1
+
+
+class BsgError(RuntimeError):
+    pass
+
+
+class DiffnetCfg(Structure):
+    _fields_ = [('in_dims', c_int32), ('residual_channels', c_int32), ('encoder_hidden', c_int32),
+                ('residual_layers', c_int32), ('dilation_cycle_length', c_int32), ('max_steps', c_int32)]
+
+
+class Schedule(Structure):
+    _fields_ = [('num_timesteps', c_int32),
+                ('sqrt_recip_alphas_cumprod', POINTER(c_float)), ('sqrt_recipm1_alphas_cumprod', POINTER(c_float)),
+                ('posterior_mean_coef1', POINTER(c_float)), ('posterior_mean_coef2', POINTER(c_float)),
+                ('sigma', POINTER(c_float)), ('alphas_cumprod', POINTER(c_float))]
+
+
+_SIGS = {
+    'bsg_abi_version': (c_int32, []),
+    'bsg_last_error': (c_char_p, []),
+    'bsg_device_arch': (c_char_p, []),
+    'bsg_diffnet_create': (c_int32, [POINTER(c_void_p), POINTER(DiffnetCfg), POINTER(c_void_p), c_int32, c_void_p, c_void_p]),
+    'bsg_diffnet_destroy': (None, [c_void_p]),
+    'bsg_diffnet_prepare': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_diffnet_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_diffnet_residual_layer': (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_ddpm_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_void_p, c_uint64, c_int32, c_int32, c_int32,
+                                  c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_plms_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_philox_normal': (c_int32, [c_void_p, c_int64, c_uint64, c_uint32, c_uint64, c_void_p]),
+    'bsg_gemm_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                               c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises BsgError when it is absent: build it with
+    `python -m bisinger_amd.build` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BsgError(f'{LIB_PATH} not found: the HIP extension is not built. '
+                       f'Run `python -m bisinger_amd.build`. There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bsg_abi_version() != ABI_VERSION:
+        raise BsgError(f'ABI mismatch: library {lib.bsg_abi_version()} vs binding {ABI_VERSION}; rebuild')
+    _lib = lib
+    return lib
+
+
+def declared_symbols():
+    return list(_SIGS)
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().bsg_last_error()
+        raise BsgError(f'{what} failed (code {rc}): {msg.decode() if msg else ""}')
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(=HIP) tensor, or NULL for None."""
+    if t is None:
+        return c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), 'expected a contiguous device tensor'
+    return c_void_p(t.data_ptr())

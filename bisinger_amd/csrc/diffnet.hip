@@ -1,0 +1,708 @@
+// DiffNet (WaveNet noise predictor) on gfx950 — the >97 %-of-FLOPs hot loop of BiSinger's mel generation.
+//
+// Reference semantics: /root/reference/train_bisinger/usr/diff/net.py
+//   ResidualBlock.forward :66-78, DiffNet.forward :107-130, SinusoidalPosEmb :32-44.
+//
+// One launch of residual_layer_kernel computes a whole ResidualBlock for a tile of N_TILE frames of one
+// utterance, with every intermediate ([2C,T] pre-activation, gated z, [2C,T] output projection) kept on
+// chip:
+//
+//   stage  xs = x[:, t0-8 : t0+N_TILE+8] + diffusion_projection(step)   (zero outside [0,T): the conv's
+//          zero padding pads x + d, net.py:69-71)                                       -> LDS  [C][N_TILE+16]
+//   GEMM1  y = W_dil[2C x 3C] * im2col(xs)  (3 dilated taps = 3 shifted reads of the same LDS image),
+//          accumulators initialised with the step-invariant conditioner term (hoisted to prepare()),
+//          v_mfma_f32_32x32x2_f32, A fragments streamed from L2 in pre-packed fragment order (one
+//          global_load_dwordx4 per lane = 4 k-steps), B fragments = conflict-free ds_read_b32 rows.
+//   gate   z = sigmoid(y[:C]) * tanh(y[C:])  in registers (a wave owns gate rows c and filter rows C+c)
+//          -> LDS [C][N_TILE] (aliases xs)
+//   GEMM2  o = W_out[2C x C] * z ; residual half: x_out = (x + o)/sqrt(2) ; skip half: skip += o
+//
+// 8 waves per workgroup = NB column blocks (32 frames each) x MS = 8/NB row slices.  Algorithmic work:
+// 2*(2C*3C + 2C*C) = 1,048,576 FLOP per frame per layer (C = 256); algorithmic HBM bytes per frame per
+// layer = 6*C*4 = 6 KB (x in, x out, conditioner term 2C, skip read+write)  -> AI = 171 FLOP/B: bound by
+// the fp32 MFMA roof (157.3 TFLOP/s), not HBM.
+#include <math.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "bsg_common.h"
+
+namespace bsg {
+
+namespace {
+
+constexpr int C = 256;     // residual channels == encoder hidden (checked at create)
+constexpr int HALO = 8;    // max dilation 2^3
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: out[((mt*(K/8) + q)*64 + lane)*4 + j] = W(m = 32*mt + (lane&31), k = 8*q + 2*j + (lane>>5))
+// with W(m,k) at src[m*sm + (k % Kc)*sc + (k / Kc)*st]  (dilated conv: k = tap*C + ci, src [2C][C][3]).
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_a_frag_kernel(const float* __restrict__ src, float* __restrict__ out, int M, int K, int Kc,
+                                   long long sm, long long sc, long long st) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)M * K;
+  if (i >= total) return;
+  const int j = (int)(i & 3);
+  const int lane = (int)((i >> 2) & 63);
+  const long long rest = i >> 8;
+  const int Kq = K / 8;
+  const int q = (int)(rest % Kq);
+  const int mt = (int)(rest / Kq);
+  const int m = 32 * mt + (lane & 31);
+  const int k = 8 * q + 2 * j + (lane >> 5);
+  out[i] = src[(long long)m * sm + (long long)(k % Kc) * sc + (long long)(k / Kc) * st];
+}
+
+__global__ void vec_add_kernel(const float* a, const float* b, float* o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused residual block
+// ------------------------------------------------------------------------------------------------
+struct ResArgs {
+  const float* x_in;     // [B][C][T]
+  float* x_out;          // [B][C][T]
+  float* skip;           // [B][C][T]
+  const float* condterm; // this layer's [B][2C][T]: conditioner_projection(cond) + b_cond + b_dil
+  const float* dproj;    // [S][L][C] table: diffusion_projection_l(mlp(emb(step)))
+  const long long* t_dev;  // [B] or null
+  int t_uniform;
+  const float* apack1;   // dilated conv, packed  [16][96][64][4]
+  const float* apack2;   // output projection     [16][32][64][4]
+  const float* bias_out; // [2C]
+  int B, T, L, layer, dil, tiles_per_row;
+  int first;             // layer 0: skip is stored, not accumulated
+  float skip_div;        // last layer: skip_sum / sqrt(L) (net.py:126); 1 otherwise
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int NB>
+__global__ __launch_bounds__(512, (NB == 4 ? 2 : 4)) void residual_layer_kernel(ResArgs a) {
+  constexpr int NT = 32 * NB;          // frames per workgroup
+  constexpr int LDX = NT + 2 * HALO;   // xs row stride
+  constexpr int LDZ = NT;              // zs row stride
+  constexpr int CPW = NB;              // 32-channel chunks (gate+filter tile pairs) per wave = 8 / MS
+  constexpr int G = CPW >= 2 ? 2 : 1;  // chunks multiplied together (share the B fragment)
+  constexpr int P1 = CPW / G;          // GEMM1 passes
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;
+  float* zs = lds;  // aliases xs after the barrier that ends GEMM1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nb = wave % NB, ms = wave / NB;
+  const int b = blockIdx.x / a.tiles_per_row;
+  const int t0 = (blockIdx.x - b * a.tiles_per_row) * NT;
+  const int T = a.T;
+  const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
+  const int col = t0 + 32 * nb + l31;       // this lane's frame in every accumulator tile
+  const bool col_ok = col < T;
+
+  // ---- stage xs = x + d (zero padded) ----------------------------------------------------------
+  {
+    const float* __restrict__ xb = a.x_in + (long long)b * C * T;
+    const float* __restrict__ dp = a.dproj + ((long long)tb * a.L + a.layer) * C;
+#pragma unroll 8
+    for (int idx = tid; idx < C * LDX; idx += 512) {
+      const int c = idx / LDX, j = idx - c * LDX;
+      const int t = t0 - HALO + j;
+      float v = 0.f;
+      if (t >= 0 && t < T) v = xb[(long long)c * T + t] + dp[c];
+      xs[idx] = v;
+    }
+  }
+
+  // ---- GEMM1 accumulators start from the conditioner term --------------------------------------
+  float z[CPW][16];
+  const float* __restrict__ ct = a.condterm + (long long)b * 2 * C * T;
+  __syncthreads();
+
+#pragma unroll
+  for (int p = 0; p < P1; ++p) {
+    f32x16 acc[2 * G];
+    int mt[2 * G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int chunk = ms * CPW + p * G + g;
+      mt[2 * g] = chunk;          // gate rows   [32*chunk, +32)
+      mt[2 * g + 1] = 8 + chunk;  // filter rows [C + 32*chunk, +32)
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * G; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[i][r] = col_ok ? ct[(long long)(32 * mt[i] + acc_row(r, lh)) * T + col] : 0.f;
+
+    const f32x4* __restrict__ ap[2 * G];
+#pragma unroll
+    for (int i = 0; i < 2 * G; ++i) ap[i] = reinterpret_cast<const f32x4*>(a.apack1) + ((long long)mt[i] * 96) * 64 + lane;
+
+    f32x4 cur[2 * G], nxt[2 * G];
+#pragma unroll
+    for (int i = 0; i < 2 * G; ++i) cur[i] = ap[i][0];
+    for (int q = 0; q < 96; ++q) {
+      const int qn = q + 1 < 96 ? q + 1 : q;
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) nxt[i] = ap[i][(long long)qn * 64];
+      const int tap = q >> 5, cg = q & 31;
+      const float* bp = xs + (8 * cg + lh) * LDX + (HALO + (tap - 1) * a.dil + 32 * nb + l31);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = bp[2 * j * LDX];
+#pragma unroll
+        for (int i = 0; i < 2 * G; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i][j], bv, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * G; ++i) cur[i] = nxt[i];
+    }
+    // gate: z = sigmoid(gate) * tanh(filter)   (net.py:73-74)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[p * G + g][r] = sigmoid_f(acc[2 * g][r]) * tanhf(acc[2 * g + 1][r]);
+  }
+
+  __syncthreads();  // every wave is done reading xs
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int chunk = ms * CPW + c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zs[(32 * chunk + acc_row(r, lh)) * LDZ + 32 * nb + l31] = z[c][r];
+  }
+  __syncthreads();
+
+  // ---- GEMM2: pass 0 = residual rows, pass 1 = skip rows ----------------------------------------
+  const float* __restrict__ xb = a.x_in + (long long)b * C * T;
+  float* __restrict__ xo = a.x_out + (long long)b * C * T;
+  float* __restrict__ sk = a.skip + (long long)b * C * T;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    f32x16 acc[NB];
+    float prev[NB][16];
+    int mt[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      mt[i] = pass * 8 + ms * NB + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = 32 * (ms * NB + i) + acc_row(r, lh);
+        acc[i][r] = a.bias_out[pass * C + ch];
+        if (pass == 0)
+          prev[i][r] = col_ok ? xb[(long long)ch * T + col] : 0.f;
+        else
+          prev[i][r] = (col_ok && !a.first) ? sk[(long long)ch * T + col] : 0.f;
+      }
+    }
+    const f32x4* __restrict__ ap[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) ap[i] = reinterpret_cast<const f32x4*>(a.apack2) + ((long long)mt[i] * 32) * 64 + lane;
+    f32x4 cur[NB], nxt[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) cur[i] = ap[i][0];
+    for (int q = 0; q < 32; ++q) {
+      const int qn = q + 1 < 32 ? q + 1 : q;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) nxt[i] = ap[i][(long long)qn * 64];
+      const float* bp = zs + (8 * q + lh) * LDZ + 32 * nb + l31;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = bp[2 * j * LDZ];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i][j], bv, acc[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) cur[i] = nxt[i];
+    }
+    if (col_ok) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = 32 * (ms * NB + i) + acc_row(r, lh);
+          if (pass == 0) {
+            xo[(long long)ch * T + col] = (prev[i][r] + acc[i][r]) / 1.41421356237309504880f;  // net.py:78
+          } else {
+            sk[(long long)ch * T + col] = (prev[i][r] + acc[i][r]) / a.skip_div;
+          }
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler: one ancestral step, elementwise over [B][M][T]   (shallow_diffusion_tts.py:134-166)
+// ------------------------------------------------------------------------------------------------
+struct Philox {
+  unsigned c[4];
+};
+__device__ __forceinline__ Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
+    const unsigned long long p1 = (unsigned long long)c2 * 0xCD9E8D57ull;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox{{c0, c1, c2, c3}};
+}
+// element i of stream `stream` = lane i%4 of counter (i/4, stream, 0, 0); Box-Muller on (0,1),(2,3)
+// — the layout bisinger_amd/synth.py:philox_normal reproduces on the host.
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned stream, unsigned long long quad) {
+  const Philox r = philox4x32_10((unsigned)quad, stream, 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32));
+  float u[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = fminf(((float)r.c[i] + 1.0f) * 2.3283064365386963e-10f, 1.0f);
+  const float r0 = sqrtf(-2.0f * logf(u[0])), r1 = sqrtf(-2.0f * logf(u[2]));
+  const float a0 = 6.283185307179586f * u[1], a1 = 6.283185307179586f * u[3];
+  return f32x4{r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
+}
+
+struct StepCoef {
+  float recip, recipm1, pc1, pc2, sigma;
+};
+
+__global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                 StepCoef k, long long n4, unsigned long long seed, unsigned stream,
+                                 unsigned long long quad0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+  const f32x4 ev = reinterpret_cast<const f32x4*>(eps)[i];
+  f32x4 nv;
+  if (noise) nv = reinterpret_cast<const f32x4*>(noise)[i];
+  else if (k.sigma != 0.f) nv = philox_normal4(seed, stream, quad0 + (unsigned long long)i);
+  else nv = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    // every product/sum rounded separately, like the reference's elementwise ATen ops (no FMA contraction)
+    float x0 = __fsub_rn(__fmul_rn(k.recip, xv[e]), __fmul_rn(k.recipm1, ev[e]));   // :134-138
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                                              // :154
+    const float mean = __fadd_rn(__fmul_rn(k.pc1, x0), __fmul_rn(k.pc2, xv[e]));    // :141-144
+    o[e] = __fadd_rn(mean, __fmul_rn(k.sigma, nv[e]));                               // :166
+  }
+  reinterpret_cast<f32x4*>(x)[i] = o;
+}
+
+__global__ void philox_fill_kernel(float* __restrict__ x, long long n4, unsigned long long seed, unsigned stream,
+                                   unsigned long long quad0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  reinterpret_cast<f32x4*>(x)[i] = philox_normal4(seed, stream, quad0 + (unsigned long long)i);
+}
+
+// PLMS transfer x_pred = x + x_delta  (shallow_diffusion_tts.py:174-182); eps' = blend of eps history (:191-198)
+struct PlmsCoef {
+  float a_t, a_prev;
+  float w0, w1, w2, w3, inv;  // eps' = (w0*e0 + w1*e1 + w2*e2 + w3*e3) / inv
+};
+__global__ void plms_step_kernel(const float* __restrict__ x, float* __restrict__ xo, const float* __restrict__ e0,
+                                 const float* __restrict__ e1, const float* __restrict__ e2,
+                                 const float* __restrict__ e3, PlmsCoef k, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float ep = e0[i];
+  if (e1) {   // multistep blends, evaluated left to right like the reference expressions
+    if (e3) ep = __fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0[i]), __fmul_rn(-k.w1, e1[i])), __fmul_rn(k.w2, e2[i])), __fmul_rn(-k.w3, e3[i]));
+    else if (e2) ep = __fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0[i]), __fmul_rn(-k.w1, e1[i])), __fmul_rn(k.w2, e2[i]));
+    else if (k.w0 == 1.0f) ep = __fadd_rn(e0[i], e1[i]);                       // (eps + eps_prev) / 2
+    else ep = __fsub_rn(__fmul_rn(k.w0, e0[i]), e1[i]);                        // (3*eps - h[-1]) / 2
+    ep = ep / k.inv;
+  }
+  const float a_t = k.a_t, a_prev = k.a_prev;
+  const float a_t_sq = sqrtf(a_t), a_prev_sq = sqrtf(a_prev);
+  const float cx = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(a_t_sq, a_prev_sq));
+  const float ce = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(sqrtf(__fmul_rn(__fsub_rn(1.0f, a_prev), a_t)),
+                                                       sqrtf(__fmul_rn(__fsub_rn(1.0f, a_t), a_prev))));
+  const float xd = __fmul_rn(__fsub_rn(a_prev, a_t), __fsub_rn(__fmul_rn(cx, x[i]), __fmul_rn(ce, ep)));
+  xo[i] = __fadd_rn(x[i], xd);
+}
+
+}  // namespace
+
+}  // namespace bsg
+
+// ================================================================================================
+// host side
+// ================================================================================================
+using namespace bsg;
+
+struct bsg_diffnet {
+  bsg_diffnet_cfg cfg;
+  int M, L;
+  // packed / derived weights (library-owned)
+  float* w_in = nullptr;    // [C][M]
+  float* b_in = nullptr;    // [C]
+  float* apack1 = nullptr;  // [L][2C*3C]
+  float* apack2 = nullptr;  // [L][2C*C]
+  float* w_cond = nullptr;  // [L][2C][H]
+  float* b_cond = nullptr;  // [L][2C]  (b_cond + b_dil)
+  float* b_out = nullptr;   // [L][2C]
+  float* w_skip = nullptr;  // [C][C]
+  float* b_skip = nullptr;
+  float* w_fin = nullptr;   // [M][C]
+  float* b_fin = nullptr;
+  float* dproj = nullptr;   // [S][L][C]
+  // workspaces for the bound (B,T)
+  int B = 0, T = 0;
+  size_t cap_bt = 0;
+  float* condterm = nullptr;  // [L][B][2C][T]
+  float* xa = nullptr;        // [B][C][T]
+  float* xb = nullptr;
+  float* skip = nullptr;
+  float* hid = nullptr;
+  float* eps = nullptr;       // [B][M][T]
+  float* eps_hist[4] = {nullptr, nullptr, nullptr, nullptr};  // PLMS history + x_pred scratch
+  float* xpred = nullptr;
+};
+
+static int dev_alloc(float** p, size_t n) {
+  BSG_HIP(hipMalloc((void**)p, n * sizeof(float)));
+  return BSG_OK;
+}
+static void dev_free(float*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
+  if (!h) return;
+  float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
+                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
+                   &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
+  for (float** p : all) dev_free(*p);
+  delete h;
+}
+
+static int copy_dev(float* dst, const void* src, size_t n, hipStream_t st) {
+  BSG_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return BSG_OK;
+}
+
+#define TRY(expr)              \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != BSG_OK) return _rc; \
+  } while (0)
+
+static int gemm_nt(const float* A, const float* W, float* Cc, const float* bias_n, int M, int N, int K, int lda, int ldc,
+                   int act, hipStream_t st) {
+  GemmArgs g{};
+  g.A = A; g.B = W; g.C = Cc; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = ldc; g.trans_b = 1;
+  g.taps = 1; g.bias_n = bias_n; g.alpha = 1.f; g.act = act; g.batch = 1;
+  return launch_gemm(g, st);
+}
+
+// conv1x1 over [B][K][T] -> [B][M][T]
+static int conv1x1(const float* W, const float* bias, const float* X, float* Y, int M, int K, int B, int T, int act,
+                   hipStream_t st) {
+  GemmArgs g{};
+  g.A = W; g.B = X; g.C = Y; g.M = M; g.N = T; g.K = K; g.lda = K; g.ldb = T; g.ldc = T; g.trans_b = 0;
+  g.sA = 0; g.sB = (long long)K * T; g.sC = (long long)M * T; g.taps = 1; g.bias_m = bias; g.alpha = 1.f; g.act = act;
+  g.batch = B;
+  return launch_gemm(g, st);
+}
+
+static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_table, hipStream_t st) {
+  const int M = h->M, L = h->L, S = h->cfg.max_steps;
+  TRY(dev_alloc(&h->w_in, (size_t)C * M));
+  TRY(dev_alloc(&h->b_in, C));
+  TRY(dev_alloc(&h->apack1, (size_t)L * 2 * C * 3 * C));
+  TRY(dev_alloc(&h->apack2, (size_t)L * 2 * C * C));
+  TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
+  TRY(dev_alloc(&h->b_cond, (size_t)L * 2 * C));
+  TRY(dev_alloc(&h->b_out, (size_t)L * 2 * C));
+  TRY(dev_alloc(&h->w_skip, (size_t)C * C));
+  TRY(dev_alloc(&h->b_skip, C));
+  TRY(dev_alloc(&h->w_fin, (size_t)M * C));
+  TRY(dev_alloc(&h->b_fin, M));
+  TRY(dev_alloc(&h->dproj, (size_t)S * L * C));
+  TRY(copy_dev(h->w_in, w[0], (size_t)C * M, st));
+  TRY(copy_dev(h->b_in, w[1], C, st));
+  // step-embedding MLP over the whole table: D = W2 * mish(W1 * e + b1) + b2        (net.py:92-96,120)
+  float *hid = nullptr, *dtab = nullptr;
+  TRY(dev_alloc(&hid, (size_t)S * 4 * C));
+  TRY(dev_alloc(&dtab, (size_t)S * C));
+  int rc = gemm_nt(step_table, (const float*)w[2], hid, (const float*)w[3], S, 4 * C, C, C, 4 * C, ACT_MISH, st);
+  if (rc == BSG_OK) rc = gemm_nt(hid, (const float*)w[4], dtab, (const float*)w[5], S, C, 4 * C, 4 * C, C, ACT_NONE, st);
+  for (int l = 0; l < L && rc == BSG_OK; ++l) {
+    const void* const* lw = w + 6 + 8 * l;
+    // dilated conv [2C][C][3] -> fragment order with k = tap*C + ci
+    {
+      const long long total = (long long)2 * C * 3 * C;
+      hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)lw[0],
+                         h->apack1 + (size_t)l * total, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL);
+    }
+    {
+      const long long total = (long long)2 * C * C;
+      hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)lw[6],
+                         h->apack2 + (size_t)l * total, 2 * C, C, C, (long long)C, 1LL, 0LL);
+    }
+    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, (const float*)lw[5], (const float*)lw[1],
+                       h->b_cond + (size_t)l * 2 * C, 2 * C);
+    if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: pack kernels failed"); rc = BSG_EHIP; break; }
+    rc = copy_dev(h->w_cond + (size_t)l * 2 * C * C, lw[4], (size_t)2 * C * C, st);
+    if (rc == BSG_OK) rc = copy_dev(h->b_out + (size_t)l * 2 * C, lw[7], 2 * C, st);
+    // diffusion_projection of the tabulated step embedding -> dproj[s][l][:]            (net.py:67)
+    if (rc == BSG_OK) rc = gemm_nt(dtab, (const float*)lw[2], h->dproj + (size_t)l * C, (const float*)lw[3], S, C, C, C, L * C, ACT_NONE, st);
+  }
+  const void* const* tw = w + 6 + 8 * L;
+  if (rc == BSG_OK) rc = copy_dev(h->w_skip, tw[0], (size_t)C * C, st);
+  if (rc == BSG_OK) rc = copy_dev(h->b_skip, tw[1], C, st);
+  if (rc == BSG_OK) rc = copy_dev(h->w_fin, tw[2], (size_t)M * C, st);
+  if (rc == BSG_OK) rc = copy_dev(h->b_fin, tw[3], M, st);
+  hipError_t e = hipStreamSynchronize(st);
+  dev_free(hid);
+  dev_free(dtab);
+  if (rc != BSG_OK) return rc;
+  BSG_HIP(e);
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_create(bsg_diffnet** out, const bsg_diffnet_cfg* cfg, const void* const* dev_weights,
+                                  int32_t n_weights, const float* step_table, void* stream) {
+  BSG_REQUIRE(out && cfg && dev_weights && step_table, "diffnet_create: null argument");
+  BSG_REQUIRE(cfg->residual_channels == C && cfg->encoder_hidden == C,
+              "diffnet_create: residual_channels=%d hidden=%d; kernels are built for 256/256", cfg->residual_channels,
+              cfg->encoder_hidden);
+  BSG_REQUIRE(cfg->in_dims > 0 && cfg->in_dims % 4 == 0 && cfg->in_dims <= 128, "diffnet_create: in_dims=%d unsupported", cfg->in_dims);
+  BSG_REQUIRE(cfg->residual_layers > 0 && cfg->residual_layers <= 64, "diffnet_create: residual_layers=%d", cfg->residual_layers);
+  BSG_REQUIRE(cfg->dilation_cycle_length >= 1 && cfg->dilation_cycle_length <= 4,
+              "diffnet_create: dilation_cycle_length=%d (max dilation 8 supported)", cfg->dilation_cycle_length);
+  BSG_REQUIRE(cfg->max_steps > 0, "diffnet_create: max_steps=%d", cfg->max_steps);
+  BSG_REQUIRE(n_weights == 10 + 8 * cfg->residual_layers, "diffnet_create: expected %d weight tensors, got %d",
+              10 + 8 * cfg->residual_layers, n_weights);
+  for (int i = 0; i < n_weights; ++i) BSG_REQUIRE(dev_weights[i] != nullptr, "diffnet_create: weight %d is null", i);
+  bsg_diffnet* h = new bsg_diffnet();
+  h->cfg = *cfg;
+  h->M = cfg->in_dims;
+  h->L = cfg->residual_layers;
+  int rc = create_impl(h, dev_weights, step_table, (hipStream_t)stream);
+  if (rc != BSG_OK) {
+    bsg_diffnet_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B, int32_t T, void* stream) {
+  BSG_REQUIRE(h && cond, "diffnet_prepare: null argument");
+  BSG_REQUIRE(B > 0 && T > 0, "diffnet_prepare: B=%d T=%d", B, T);
+  BSG_REQUIRE((long long)B * T < (1LL << 31) / (2 * C), "diffnet_prepare: B*T=%lld too large", (long long)B * T);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bt = (size_t)B * T;
+  if (bt > h->cap_bt) {
+    BSG_HIP(hipStreamSynchronize(st));
+    float** bufs[] = {&h->condterm, &h->xa, &h->xb, &h->skip, &h->hid, &h->eps, &h->eps_hist[0], &h->eps_hist[1],
+                      &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
+    for (float** p : bufs) dev_free(*p);
+    h->cap_bt = 0;
+    TRY(dev_alloc(&h->condterm, (size_t)h->L * 2 * C * bt));
+    TRY(dev_alloc(&h->xa, C * bt));
+    TRY(dev_alloc(&h->xb, C * bt));
+    TRY(dev_alloc(&h->skip, C * bt));
+    TRY(dev_alloc(&h->hid, C * bt));
+    TRY(dev_alloc(&h->eps, (size_t)h->M * bt));
+    h->cap_bt = bt;
+  }
+  h->B = B;
+  h->T = T;
+  for (int l = 0; l < h->L; ++l)
+    TRY(conv1x1(h->w_cond + (size_t)l * 2 * C * C, h->b_cond + (size_t)l * 2 * C, cond,
+                h->condterm + (size_t)l * 2 * C * bt, 2 * C, C, B, T, ACT_NONE, st));
+  return BSG_OK;
+}
+
+static int pick_nb(int B, int T) {
+  // fill the 256 CUs: prefer the widest tile that still yields >= 256 workgroups
+  for (int nb : {4, 2}) {
+    const long long wgs = (long long)B * cdiv(T, 32 * nb);
+    if (wgs >= 256) return nb;
+  }
+  return 1;
+}
+
+static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long long* t_dev, int t_uniform, float* x_out,
+                        float* skip, int B, int T, hipStream_t st, int force_nb = 0) {
+  ResArgs a{};
+  a.x_in = x_in; a.x_out = x_out; a.skip = skip;
+  a.condterm = h->condterm + (size_t)layer * 2 * C * (size_t)B * T;
+  a.dproj = h->dproj; a.t_dev = t_dev; a.t_uniform = t_uniform;
+  a.apack1 = h->apack1 + (size_t)layer * 2 * C * 3 * C;
+  a.apack2 = h->apack2 + (size_t)layer * 2 * C * C;
+  a.bias_out = h->b_out + (size_t)layer * 2 * C;
+  a.B = B; a.T = T; a.L = h->L; a.layer = layer;
+  a.dil = 1 << (layer % h->cfg.dilation_cycle_length);
+  a.first = layer == 0;
+  a.skip_div = layer == h->L - 1 ? sqrtf((float)h->L) : 1.0f;
+  const int nb = force_nb ? force_nb : pick_nb(B, T);
+  const int NT = 32 * nb;
+  a.tiles_per_row = cdiv(T, NT);
+  const dim3 grid(B * a.tiles_per_row), block(512);
+  const size_t lds = (size_t)C * (NT + 2 * HALO) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, C * (128 + 2 * HALO) * 4));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C * (64 + 2 * HALO) * 4));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C * (32 + 2 * HALO) * 4));
+    attr_set = true;
+  }
+  if (nb == 4) hipLaunchKernelGGL(residual_layer_kernel<4>, grid, block, lds, st, a);
+  else if (nb == 2) hipLaunchKernelGGL(residual_layer_kernel<2>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(residual_layer_kernel<1>, grid, block, lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+static int check_bound(bsg_diffnet* h, int B, int T, const char* who) {
+  if (!h) { set_error("%s: null handle", who); return BSG_EINVAL; }
+  if (h->cap_bt == 0 || h->B != B || h->T != T) {
+    set_error("%s: (B=%d,T=%d) does not match the condition bound by bsg_diffnet_prepare (B=%d,T=%d)", who, B, T, h->B, h->T);
+    return BSG_ESTATE;
+  }
+  return BSG_OK;
+}
+
+// eps = DiffNet(x, t); t either per-row on the device or uniform
+static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, int t_uniform, float* eps, int B, int T,
+                        hipStream_t st) {
+  TRY(conv1x1(h->w_in, h->b_in, x, h->xa, C, h->M, B, T, ACT_RELU, st));  // net.py:116-118
+  float* cur = h->xa;
+  float* nxt = h->xb;
+  for (int l = 0; l < h->L; ++l) {
+    TRY(launch_layer(h, l, cur, t_dev, t_uniform, nxt, h->skip, B, T, st));
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  TRY(conv1x1(h->w_skip, h->b_skip, h->skip, h->hid, C, C, B, T, ACT_RELU, st));   // net.py:127-128
+  TRY(conv1x1(h->w_fin, h->b_fin, h->hid, eps, h->M, C, B, T, ACT_NONE, st));      // net.py:129
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_forward(bsg_diffnet* h, const float* x, const int64_t* t, float* eps, int32_t B, int32_t T,
+                                   void* stream) {
+  TRY(check_bound(h, B, T, "diffnet_forward"));
+  BSG_REQUIRE(x && t && eps, "diffnet_forward: null argument");
+  return forward_impl(h, x, (const long long*)t, 0, eps, B, T, (hipStream_t)stream);
+}
+
+extern "C" int bsg_diffnet_residual_layer(bsg_diffnet* h, int32_t layer, const float* x_in, const int64_t* t, float* x_out,
+                                          float* skip, int32_t B, int32_t T, void* stream) {
+  TRY(check_bound(h, B, T, "diffnet_residual_layer"));
+  BSG_REQUIRE(x_in && t && x_out && skip && x_in != x_out, "diffnet_residual_layer: null or aliased argument");
+  BSG_REQUIRE(layer >= 0 && layer < h->L, "diffnet_residual_layer: layer %d out of range", layer);
+  // test hook: BSG_FORCE_NB in {1,2,4} overrides the tile width chosen by pick_nb()
+  int force_nb = 0;
+  if (const char* e = getenv("BSG_FORCE_NB")) force_nb = atoi(e);
+  BSG_REQUIRE(force_nb == 0 || force_nb == 1 || force_nb == 2 || force_nb == 4, "BSG_FORCE_NB=%d", force_nb);
+  return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream, force_nb);
+}
+
+static int check_schedule(const bsg_schedule* s, const char* who, bool plms) {
+  if (!s || s->num_timesteps <= 0) { set_error("%s: bad schedule", who); return BSG_EINVAL; }
+  if (plms ? !s->alphas_cumprod
+           : !(s->sqrt_recip_alphas_cumprod && s->sqrt_recipm1_alphas_cumprod && s->posterior_mean_coef1 &&
+               s->posterior_mean_coef2 && s->sigma)) {
+    set_error("%s: schedule array missing", who);
+    return BSG_EINVAL;
+  }
+  return BSG_OK;
+}
+
+extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float* noise, uint64_t seed,
+                               int32_t t_start, int32_t n_steps, int32_t B, int32_t T, int32_t row0, int32_t B_total,
+                               void* stream) {
+  TRY(check_bound(h, B, T, "ddpm_sample"));
+  TRY(check_schedule(s, "ddpm_sample", false));
+  BSG_REQUIRE(x, "ddpm_sample: null x");
+  BSG_REQUIRE(t_start < s->num_timesteps && t_start < h->cfg.max_steps && n_steps >= 0 && t_start - n_steps + 1 >= 0,
+              "ddpm_sample: steps [%d..%d] outside the schedule (%d) / step table (%d)", t_start - n_steps + 1, t_start,
+              s->num_timesteps, h->cfg.max_steps);
+  BSG_REQUIRE(row0 >= 0 && row0 + B <= B_total, "ddpm_sample: rows [%d,%d) outside the global batch %d", row0, row0 + B, B_total);
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * h->M * T;
+  BSG_REQUIRE(n % 4 == 0, "ddpm_sample: B*M*T must be a multiple of 4");
+  const long long n4 = n / 4;
+  const unsigned long long quad0 = (unsigned long long)row0 * h->M * T / 4;
+  for (int k = 0; k < n_steps; ++k) {
+    const int i = t_start - k;
+    TRY(forward_impl(h, x, nullptr, i, h->eps, B, T, st));
+    StepCoef c{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
+               s->posterior_mean_coef2[i], s->sigma[i]};
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, x, (const float*)h->eps,
+                       noise ? noise + (long long)k * n : nullptr, c, n4, (unsigned long long)seed, (unsigned)(i + 1), quad0);
+    BSG_LAUNCH_CHECK();
+  }
+  return BSG_OK;
+}
+
+extern "C" int bsg_philox_normal(float* x, int64_t n, uint64_t seed, uint32_t stream_id, uint64_t offset, void* stream) {
+  BSG_REQUIRE(x && n > 0 && n % 4 == 0 && offset % 4 == 0, "philox_normal: n=%lld offset=%llu must be multiples of 4", (long long)n, (unsigned long long)offset);
+  hipLaunchKernelGGL(philox_fill_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)(n / 4),
+                     (unsigned long long)seed, (unsigned)stream_id, (unsigned long long)(offset / 4));
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, int32_t K_step, int32_t interval, int32_t B,
+                               int32_t T, void* stream) {
+  TRY(check_bound(h, B, T, "plms_sample"));
+  TRY(check_schedule(s, "plms_sample", true));
+  BSG_REQUIRE(x && interval > 0 && K_step > 0 && K_step <= s->num_timesteps && K_step <= h->cfg.max_steps,
+              "plms_sample: K_step=%d interval=%d schedule=%d", K_step, interval, s->num_timesteps);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)B * h->M * T;
+  if (!h->xpred) {
+    BSG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; ++i) TRY(dev_alloc(&h->eps_hist[i], (size_t)h->M * h->cap_bt));
+    TRY(dev_alloc(&h->xpred, (size_t)h->M * h->cap_bt));
+  }
+  const dim3 grid(cdiv((long long)n, 256)), block(256);
+  // history ring: hist[0] = newest
+  float* hist[4] = {h->eps_hist[0], h->eps_hist[1], h->eps_hist[2], h->eps_hist[3]};
+  int n_hist = 0;
+  const int last = ((K_step - 1) / interval) * interval;
+  for (int i = last; i >= 0; i -= interval) {
+    const int ip = i - interval > 0 ? i - interval : 0;
+    PlmsCoef c{};
+    c.a_t = s->alphas_cumprod[i];
+    c.a_prev = s->alphas_cumprod[ip];
+    float* e_new = hist[3];  // slot about to be recycled
+    TRY(forward_impl(h, x, nullptr, i, e_new, B, T, st));
+    if (n_hist == 0) {
+      c.inv = 1.f;
+      hipLaunchKernelGGL(plms_step_kernel, grid, block, 0, st, (const float*)x, h->xpred, (const float*)e_new,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, c, (long long)n);
+      TRY(forward_impl(h, h->xpred, nullptr, ip, h->eps, B, T, st));
+      c.w0 = 1.f; c.inv = 2.f;
+      hipLaunchKernelGGL(plms_step_kernel, grid, block, 0, st, (const float*)x, x, (const float*)e_new, (const float*)h->eps,
+                         (const float*)nullptr, (const float*)nullptr, c, (long long)n);
+    } else if (n_hist == 1) {
+      c.w0 = 3.f; c.inv = 2.f;
+      hipLaunchKernelGGL(plms_step_kernel, grid, block, 0, st, (const float*)x, x, (const float*)e_new, (const float*)hist[0],
+                         (const float*)nullptr, (const float*)nullptr, c, (long long)n);
+    } else if (n_hist == 2) {
+      c.w0 = 23.f; c.w1 = -16.f; c.w2 = 5.f; c.inv = 12.f;
+      hipLaunchKernelGGL(plms_step_kernel, grid, block, 0, st, (const float*)x, x, (const float*)e_new, (const float*)hist[0],
+                         (const float*)hist[1], (const float*)nullptr, c, (long long)n);
+    } else {
+      c.w0 = 55.f; c.w1 = -59.f; c.w2 = 37.f; c.w3 = -9.f; c.inv = 24.f;
+      hipLaunchKernelGGL(plms_step_kernel, grid, block, 0, st, (const float*)x, x, (const float*)e_new, (const float*)hist[0],
+                         (const float*)hist[1], (const float*)hist[2], c, (long long)n);
+    }
+    BSG_LAUNCH_CHECK();
+    hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = e_new;
+    if (n_hist < 3) ++n_hist;
+  }
+  return BSG_OK;
+}

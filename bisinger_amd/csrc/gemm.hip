@@ -1,0 +1,222 @@
+// Generic batched fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-for-bit a k-ordered fmaf chain; 256 FLOP/clk/CU = the fp32 roofline of the chip).
+//
+// Used for every dense contraction of the path that is not the fused DiffNet residual block:
+// 1x1 convolutions in [B,C,T] layout (B operand [K,N], N contiguous), Linear layers and attention
+// products in [tokens,C] layout (B operand [N,K], K contiguous), and the k=9 / k=3 Conv1d of the
+// FFN / duration predictor as K-segmented GEMMs over shifted A rows ("taps").
+//
+// Tile: 128x128x32 per 256-thread workgroup; wave (wm, wn) owns a 64x64 sub-tile = 2x2 MFMA tiles
+// (64 accumulator VGPRs).  Operands are staged through LDS ([row][33] padded images: the 32 lanes of
+// an MFMA operand read 32 different rows at one k -> 33-float stride = conflict-free ds_read_b32),
+// next tile prefetched into registers while the current one is multiplied.
+#include "bsg_common.h"
+
+namespace bsg {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDP = BK + 1;
+
+template <bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ float As[BM * LDP];
+  __shared__ float Bs[TRANS_B ? BN * LDP : BK * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * BN, bz = blockIdx.z;
+
+  const float* __restrict__ A = g.A + (long long)bz * g.sA;
+  const float* __restrict__ Bp = g.B + (long long)bz * g.sB;
+
+  const bool vecA = ((g.lda | g.K) & 3) == 0 && ((((uintptr_t)A) & 15) == 0);
+  const bool vecB = TRANS_B ? (((g.ldb | g.K) & 3) == 0 && ((((uintptr_t)Bp) & 15) == 0) && ((g.sTapB & 3) == 0))
+                            : (((g.ldb | g.N) & 3) == 0 && ((((uintptr_t)Bp) & 15) == 0) && ((g.sTapB & 3) == 0));
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kTiles = (g.K + BK - 1) / BK;
+  const int nIter = kTiles * g.taps;
+
+  f32x4 ra[4], rb[4];
+
+  auto load_tiles = [&](int it) {
+    const int tap = it / kTiles, k0 = (it - tap * kTiles) * BK;
+    const int shift = g.tap_shift0 + tap;
+    // A tile: 128 rows x 32 k
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx >> 3, c4 = (idx & 7) << 2;
+      const int gr = bm + row + shift, gk = k0 + c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr >= 0 && gr < g.M && (bm + row) < g.M) {
+        const float* p = A + (long long)gr * g.lda + gk;
+        if (vecA && gk + 3 < g.K) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gk + e < g.K) v[e] = p[e];
+        }
+      }
+      ra[j] = v;
+    }
+    const float* Bt = Bp + (long long)tap * g.sTapB;
+    if (TRANS_B) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 3, c4 = (idx & 7) << 2;
+        const int gn = bn + row, gk = k0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gn < g.N) {
+          const float* p = Bt + (long long)gn * g.ldb + gk;
+          if (vecB && gk + 3 < g.K) {
+            v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gk + e < g.K) v[e] = p[e];
+          }
+        }
+        rb[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 5, c4 = (idx & 31) << 2;
+        const int gk = k0 + row, gn = bn + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < g.K) {
+          const float* p = Bt + (long long)gk * g.ldb + gn;
+          if (vecB && gn + 3 < g.N) {
+            v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gn + e < g.N) v[e] = p[e];
+          }
+        }
+        rb[j] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx >> 3, c4 = (idx & 7) << 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[row * LDP + c4 + e] = ra[j][e];
+    }
+    if (TRANS_B) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 3, c4 = (idx & 7) << 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[row * LDP + c4 + e] = rb[j][e];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 5, c4 = (idx & 31) << 2;
+        *reinterpret_cast<f32x4*>(&Bs[row * BN + c4]) = rb[j];
+      }
+    }
+  };
+
+  load_tiles(0);
+  for (int it = 0; it < nIter; ++it) {
+    __syncthreads();   // previous tile fully consumed
+    store_tiles();
+    __syncthreads();
+    if (it + 1 < nIter) load_tiles(it + 1);   // in flight while the MFMAs below run
+    const float* a0p = &As[(wm * 64 + l31) * LDP + lh];
+    const float* a1p = a0p + 32 * LDP;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const float a0 = a0p[2 * s], a1 = a1p[2 * s];
+      float b0, b1;
+      if (TRANS_B) {
+        b0 = Bs[(wn * 64 + l31) * LDP + 2 * s + lh];
+        b1 = Bs[(wn * 64 + 32 + l31) * LDP + 2 * s + lh];
+      } else {
+        b0 = Bs[(2 * s + lh) * BN + wn * 64 + l31];
+        b1 = Bs[(2 * s + lh) * BN + wn * 64 + 32 + l31];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lanes 0..31 of a register hold 32 consecutive columns of one row -> 128-B stores
+  float* __restrict__ C = g.C + (long long)bz * g.sC;
+  const float* __restrict__ R = g.R ? g.R + (long long)bz * g.sR : nullptr;
+  const float* __restrict__ RS = g.rowscale ? g.rowscale + (long long)bz * g.sRS : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = bn + wn * 64 + ni * 32 + l31;
+      const float bn_v = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm * 64 + mi * 32 + acc_row(r, lh);
+        if (row < g.M && col < g.N) {
+          float v = acc[mi][ni][r] + bn_v;
+          if (g.bias_m) v += g.bias_m[row];
+          v *= g.alpha;
+          if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+          else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          if (R) v += R[(long long)row * g.ldr + col];
+          if (RS) v *= RS[row];
+          C[(long long)row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  BSG_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.taps > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
+  BSG_REQUIRE(g.batch <= 65535, "gemm: batch %d > 65535", g.batch);
+  dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch);
+  if (g.trans_b)
+    hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, g);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+}  // namespace bsg
+
+extern "C" int bsg_gemm_f32(const float* A, const float* Bm, float* C, const float* bias_m, const float* bias_n,
+                            int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t trans_b,
+                            int32_t batch, int64_t strideA, int64_t strideB, int64_t strideC, int32_t relu,
+                            void* stream) {
+  bsg::GemmArgs g{};
+  g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.sA = strideA; g.sB = strideB; g.sC = strideC; g.trans_b = trans_b; g.taps = 1; g.tap_shift0 = 0; g.sTapB = 0;
+  g.bias_m = bias_m; g.bias_n = bias_n; g.alpha = 1.f; g.act = relu ? bsg::ACT_RELU : bsg::ACT_NONE;
+  g.batch = batch;
+  return bsg::launch_gemm(g, (hipStream_t)stream);
+}

@@ -1,0 +1,167 @@
+"""``DiffNet`` — drop-in for the reference's WaveNet denoiser, running on hand-written HIP kernels.
+
+Reference: /root/reference/train_bisinger/usr/diff/net.py:58-130 (ResidualBlock, DiffNet) and the
+``DIFF_DECODERS`` registry usr/diffsinger_task.py:24-29.  Same constructor, same hparams keys, same
+``state_dict`` names/shapes, same call contract ``denoise_fn(spec[B,1,M,T], t[B] int64, cond[B,H,T])``.
+The modules below only *hold* parameters; all arithmetic happens in libbisinger_hip
+(csrc/diffnet.hip) through the C ABI of include/bisinger_hip.h.  No CPU/eager fallback exists.
+"""
+import math
+from ctypes import POINTER, byref, c_void_p, cast
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .hparams import hparams
+
+
+class Mish(nn.Module):
+    """Parameter-free placeholder keeping ``mlp.1`` in place (usr/diff/diffusion.py:68-70)."""
+
+    def forward(self, x):  # pragma: no cover - never called, the kernels implement it
+        raise _lib.BsgError('Mish is evaluated inside libbisinger_hip')
+
+
+class SinusoidalPosEmb(nn.Module):
+    """net.py:32-44.  Used on the host only to tabulate the step embedding for the library."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def table(self, n):
+        half = self.dim // 2
+        e = math.log(10000) / (half - 1)
+        e = torch.exp(torch.arange(half) * -e)
+        e = torch.arange(n)[:, None] * e[None, :]          # int64 * float32 -> float32, as the reference
+        return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def _conv1d(*args, **kw):
+    layer = nn.Conv1d(*args, **kw)
+    nn.init.kaiming_normal_(layer.weight)
+    return layer
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, encoder_hidden, residual_channels, dilation):
+        super().__init__()
+        self.dilation = dilation
+        self.dilated_conv = _conv1d(residual_channels, 2 * residual_channels, 3, padding=dilation, dilation=dilation)
+        self.diffusion_projection = nn.Linear(residual_channels, residual_channels)
+        self.conditioner_projection = _conv1d(encoder_hidden, 2 * residual_channels, 1)
+        self.output_projection = _conv1d(residual_channels, 2 * residual_channels, 1)
+
+
+class DiffNet(nn.Module):
+    def __init__(self, in_dims=80):
+        super().__init__()
+        self.in_dims = in_dims
+        self.encoder_hidden = hparams['hidden_size']
+        self.n_layers = hparams['residual_layers']
+        self.residual_channels = C = hparams['residual_channels']
+        self.dilation_cycle_length = hparams['dilation_cycle_length']
+        self.max_steps = max(int(hparams.get('timesteps', 1000)), 1000)
+        self.input_projection = _conv1d(in_dims, C, 1)
+        self.diffusion_embedding = SinusoidalPosEmb(C)
+        self.mlp = nn.Sequential(nn.Linear(C, C * 4), Mish(), nn.Linear(C * 4, C))
+        self.residual_layers = nn.ModuleList([
+            ResidualBlock(self.encoder_hidden, C, 2 ** (i % self.dilation_cycle_length)) for i in range(self.n_layers)])
+        self.skip_projection = _conv1d(C, C, 1)
+        self.output_projection = _conv1d(C, in_dims, 1)
+        nn.init.zeros_(self.output_projection.weight)
+        self._h = None
+        self._h_key = None
+        self._bound = None
+
+    # ------------------------------------------------------------------ handle management
+    def _weights(self):
+        return list(self.state_dict(keep_vars=True).values())
+
+    def _key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
+
+    def handle(self):
+        """(Re)create the library handle when the parameters moved or changed (load_ckpt, .to())."""
+        key = self._key()
+        if self._h is not None and key == self._h_key:
+            return self._h
+        self.release()
+        ws = [p.detach() for p in self._weights()]
+        for p in ws:
+            if not p.is_cuda:
+                raise _lib.BsgError('DiffNet parameters must live on the GPU (model.cuda()); there is no CPU path')
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.BsgError('DiffNet parameters must be contiguous float32')
+        lib = _lib.load()
+        cfg = _lib.DiffnetCfg(self.in_dims, self.residual_channels, self.encoder_hidden, self.n_layers,
+                              self.dilation_cycle_length, self.max_steps)
+        arr = (c_void_p * len(ws))(*[p.data_ptr() for p in ws])
+        table = self.diffusion_embedding.table(self.max_steps).to(ws[0].device).contiguous()
+        h = c_void_p()
+        with torch.cuda.device(ws[0].device):
+            _lib.check(lib.bsg_diffnet_create(byref(h), byref(cfg), cast(arr, POINTER(c_void_p)), len(ws),
+                                              _lib.ptr(table), _lib.stream_ptr()), 'bsg_diffnet_create')
+        self._h, self._h_key, self._bound = h, key, None
+        return h
+
+    def release(self):
+        if self._h is not None:
+            _lib.load().bsg_diffnet_destroy(self._h)
+        self._h = self._h_key = self._bound = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def prepare(self, cond):
+        """Bind ``cond`` [B,H,T]: hoists every layer's conditioner projection out of the step loop."""
+        h = self.handle()
+        cond = cond.contiguous().float()
+        B, H, T = cond.shape
+        assert H == self.encoder_hidden
+        with torch.cuda.device(cond.device):
+            _lib.check(_lib.load().bsg_diffnet_prepare(h, _lib.ptr(cond), B, T, _lib.stream_ptr()), 'bsg_diffnet_prepare')
+        self._bound = (cond.data_ptr(), cond._version, B, T)
+        return B, T
+
+    def _ensure_bound(self, cond):
+        key = (cond.data_ptr(), cond._version, cond.shape[0], cond.shape[2])
+        if self._h is None or self._key() != self._h_key or self._bound != key or not cond.is_contiguous():
+            self.prepare(cond)
+            if cond.is_contiguous() and cond.dtype == torch.float32:
+                self._bound = key
+
+    # ------------------------------------------------------------------ reference call contract
+    @torch.no_grad()
+    def forward(self, spec, diffusion_step, cond):
+        """spec [B,1,M,T], diffusion_step [B] int64, cond [B,H,T] -> [B,1,M,T]   (net.py:107-130)."""
+        B, _, M, T = spec.shape
+        self._ensure_bound(cond)
+        x = spec[:, 0].contiguous().float()
+        t = diffusion_step.to(device=x.device, dtype=torch.long).contiguous()
+        eps = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().bsg_diffnet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(eps), B, T,
+                                                       _lib.stream_ptr()), 'bsg_diffnet_forward')
+        return eps[:, None, :, :]
+
+    @torch.no_grad()
+    def residual_layer(self, layer, x, t, skip):
+        """One fused ResidualBlock (net.py:66-78) — unit-test / micro-benchmark hook."""
+        B, C, T = x.shape
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().bsg_diffnet_residual_layer(self._h, layer, _lib.ptr(x), _lib.ptr(t), _lib.ptr(out),
+                                                              _lib.ptr(skip), B, T, _lib.stream_ptr()),
+                       'bsg_diffnet_residual_layer')
+        return out
+
+
+# usr/diffsinger_task.py:24-29.  ('fft' = SURVEY.md §8 row f4, not built.)
+DIFF_DECODERS = {
+    'wavenet': lambda hp: DiffNet(hp['audio_num_mel_bins']),
+}

@@ -1,0 +1,193 @@
+"""``GaussianDiffusion`` — drop-in for usr/diff/shallow_diffusion_tts.py:71-285 (inference direction).
+
+Same constructor, sub-module names (``fs2``, ``denoise_fn``), 14 registered buffers (computed in
+float64 numpy and cast, :90-126, so they are bit-identical and a checkpoint's buffers override them)
+and ``forward(..., infer=True)`` result keys.  The step loop itself (p_sample :159-166 /
+p_sample_plms :168-201 over DiffNet) runs inside libbisinger_hip (``bsg_ddpm_sample`` /
+``bsg_plms_sample``): one C call enqueues all ``K_step`` iterations on the current stream.
+
+Noise: the reference draws ``torch.randn`` per step.  Here either the caller supplies the draws
+(``noise=[K_step+1,B,M,T]``: parity mode, see bisinger_amd/synth.py) or they come from the on-device
+Philox4x32-10 stream keyed by ``seed`` and the *global* batch row (so utterance shards reproduce the
+unsharded run).
+"""
+from ctypes import POINTER, byref, c_float, cast
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .hparams import hparams
+
+
+def linear_beta_schedule(timesteps, max_beta=None):
+    """:44-49.  The reference captures hparams['max_beta'] at import time; here it is read at call time."""
+    if max_beta is None:
+        max_beta = hparams.get('max_beta', 0.01)
+    return np.linspace(1e-4, max_beta, timesteps)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    """:52-62."""
+    steps = timesteps + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999)
+
+
+beta_schedule = {'cosine': cosine_beta_schedule, 'linear': linear_beta_schedule}
+
+_SCHED_KEYS = ('sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod', 'posterior_mean_coef1',
+               'posterior_mean_coef2', 'alphas_cumprod')
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, phone_encoder, out_dims, denoise_fn, timesteps=1000, K_step=1000, loss_type=None,
+                 betas=None, spec_min=None, spec_max=None):
+        super().__init__()
+        self.denoise_fn = denoise_fn
+        if hparams.get('use_midi'):
+            from .fs2 import FastSpeech2MIDI
+            self.fs2 = FastSpeech2MIDI(phone_encoder, out_dims)
+        else:
+            raise NotImplementedError('only the MIDI front (use_midi: true) is on the BiSinger path (SURVEY.md §8)')
+        self.mel_bins = out_dims
+        if betas is not None:
+            betas = betas.detach().cpu().numpy() if isinstance(betas, torch.Tensor) else betas
+        elif 'schedule_type' in hparams:
+            betas = beta_schedule[hparams['schedule_type']](timesteps)
+        else:
+            betas = cosine_beta_schedule(timesteps)
+        alphas = 1. - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1., ac[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.K_step = K_step
+        self.loss_type = loss_type if loss_type is not None else hparams.get('diff_loss_type', 'l1')
+        f = lambda a: torch.tensor(a, dtype=torch.float32)
+        self.register_buffer('betas', f(betas))
+        self.register_buffer('alphas_cumprod', f(ac))
+        self.register_buffer('alphas_cumprod_prev', f(ac_prev))
+        self.register_buffer('sqrt_alphas_cumprod', f(np.sqrt(ac)))
+        self.register_buffer('sqrt_one_minus_alphas_cumprod', f(np.sqrt(1. - ac)))
+        self.register_buffer('log_one_minus_alphas_cumprod', f(np.log(1. - ac)))
+        self.register_buffer('sqrt_recip_alphas_cumprod', f(np.sqrt(1. / ac)))
+        self.register_buffer('sqrt_recipm1_alphas_cumprod', f(np.sqrt(1. / ac - 1)))
+        pv = betas * (1. - ac_prev) / (1. - ac)
+        self.register_buffer('posterior_variance', f(pv))
+        self.register_buffer('posterior_log_variance_clipped', f(np.log(np.maximum(pv, 1e-20))))
+        self.register_buffer('posterior_mean_coef1', f(betas * np.sqrt(ac_prev) / (1. - ac)))
+        self.register_buffer('posterior_mean_coef2', f((1. - ac_prev) * np.sqrt(alphas) / (1. - ac)))
+        self.register_buffer('spec_min', torch.FloatTensor(spec_min)[None, None, :hparams['keep_bins']])
+        self.register_buffer('spec_max', torch.FloatTensor(spec_max)[None, None, :hparams['keep_bins']])
+        self._sched_cache = None
+
+    # ------------------------------------------------------------------ schedule -> C struct
+    def _schedule(self):
+        """Host copies of the (possibly checkpoint-loaded) buffers for bsg_schedule."""
+        key = tuple((getattr(self, k).data_ptr(), getattr(self, k)._version) for k in _SCHED_KEYS) + \
+            (self.posterior_log_variance_clipped._version,)
+        if self._sched_cache is not None and self._sched_cache[0] == key:
+            return self._sched_cache[1]
+        host = {k: getattr(self, k).detach().float().cpu().contiguous() for k in _SCHED_KEYS}
+        sigma = (0.5 * self.posterior_log_variance_clipped.detach().float().cpu()).exp()   # :166
+        sigma[0] = 0.0                                                                      # nonzero_mask (:165)
+        host['sigma'] = sigma.contiguous()
+        s = _lib.Schedule()
+        s.num_timesteps = self.num_timesteps
+        for k, v in host.items():
+            setattr(s, k, cast(v.data_ptr(), POINTER(c_float)))
+        self._sched_cache = (key, (s, host))   # keep the host tensors alive with the struct
+        return s, host
+
+    # ------------------------------------------------------------------ samplers
+    @torch.no_grad()
+    def sample(self, cond, x, noise=None, seed=0, row0=0, B_total=None, n_steps=None):
+        """Run the inference loop (:258-267) from ``x`` ([B,1,M,T], modified in place) under ``cond`` [B,H,T]."""
+        lib = _lib.load()
+        B, _, M, T = x.shape
+        assert x.is_contiguous() and x.dtype == torch.float32
+        self.denoise_fn.prepare(cond)
+        s, _keep = self._schedule()
+        h = self.denoise_fn._h
+        t = self.K_step
+        with torch.cuda.device(x.device):
+            if hparams.get('pndm_speedup'):
+                _lib.check(lib.bsg_plms_sample(h, byref(s), _lib.ptr(x), t, int(hparams['pndm_speedup']), B, T,
+                                               _lib.stream_ptr()), 'bsg_plms_sample')
+            else:
+                n = t if n_steps is None else n_steps
+                if noise is not None:
+                    noise = noise.contiguous()
+                    assert tuple(noise.shape) == (n, B, M, T), noise.shape
+                _lib.check(lib.bsg_ddpm_sample(h, byref(s), _lib.ptr(x), _lib.ptr(noise), seed, t - 1, n, B, T, row0,
+                                               B if B_total is None else B_total, _lib.stream_ptr()), 'bsg_ddpm_sample')
+        return x
+
+    @torch.no_grad()
+    def p_sample(self, x, t, cond, clip_denoised=True, repeat_noise=False, noise=None, seed=0):
+        """One ancestral step with the reference signature (:159-166); all rows must share ``t``."""
+        assert clip_denoised and not repeat_noise
+        ti = int(t[0])
+        assert bool((t == ti).all()), 'p_sample: the HIP sampler takes one timestep per call'
+        lib = _lib.load()
+        B, _, M, T = x.shape
+        x = x.contiguous().clone()
+        self.denoise_fn._ensure_bound(cond)
+        s, _keep = self._schedule()
+        nz = None if noise is None else noise.reshape(1, B, M, T).contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bsg_ddpm_sample(self.denoise_fn._h, byref(s), _lib.ptr(x), _lib.ptr(nz), seed, ti, 1, B, T, 0, B,
+                                           _lib.stream_ptr()), 'bsg_ddpm_sample')
+        return x
+
+    def philox_normal(self, shape, device, seed, stream_id, offset=0):
+        x = torch.empty(shape, device=device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().bsg_philox_normal(_lib.ptr(x), x.numel(), seed, stream_id, offset, _lib.stream_ptr()),
+                       'bsg_philox_normal')
+        return x
+
+    # ------------------------------------------------------------------ reference forward (:230-273)
+    @torch.no_grad()
+    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
+                infer=False, noise=None, seed=None, row0=0, B_total=None, **kwargs):
+        if not infer:
+            raise NotImplementedError('training (p_losses) is outside the accelerated hot path (SURVEY.md §8)')
+        ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=False, infer=True, **kwargs)
+        cond = ret['decoder_inp'].transpose(1, 2).contiguous()
+        ret['fs2_mel'] = ret['mel_out']
+        B, H, T = cond.shape
+        t = self.K_step
+        seed = int(hparams.get('seed', 1234)) if seed is None else int(seed)
+        M = self.mel_bins
+        if noise is not None:
+            noise = noise.to(cond.device, torch.float32)
+            draw0, steps = noise[0][:, None].contiguous(), noise[1:]
+        else:
+            off = row0 * M * T
+            draw0 = self.philox_normal((B, 1, M, T), cond.device, seed, 0, off)
+            steps = None
+        if hparams.get('gaussian_start'):
+            x = draw0
+        else:
+            fm = self.norm_spec(ret['mel_out']).transpose(1, 2)[:, None]
+            x = (self.sqrt_alphas_cumprod[t - 1] * fm + self.sqrt_one_minus_alphas_cumprod[t - 1] * draw0).contiguous()
+        x = self.sample(cond, x, noise=steps, seed=seed, row0=row0, B_total=B_total)
+        x = x[:, 0].transpose(1, 2)
+        out = self.denorm_spec(x)
+        if mel2ph is not None:
+            out = out * (mel2ph > 0).float()[:, :, None]
+        ret['mel_out'] = out
+        return ret
+
+    def norm_spec(self, x):
+        return (x - self.spec_min) / (self.spec_max - self.spec_min) * 2 - 1
+
+    def denorm_spec(self, x):
+        return (x + 1) / 2 * (self.spec_max - self.spec_min) + self.spec_min
+
+    def out2mel(self, x):
+        return x

@@ -1,0 +1,217 @@
+"""``FastSpeech2MIDI`` — drop-in for modules/diffsinger_midi/fs2.py:80-197 (+ the base
+modules/fastspeech/fs2.py:24-89 constructor), inference direction, on HIP kernels.
+
+The sub-modules below reproduce the reference's module tree so that ``state_dict()`` has exactly the
+reference's 143 ``fs2.*`` entries (names, shapes, order — including the two aliased sub-trees
+``encoder.esm``/``esm`` and ``encoder.embed_tokens``/``encoder_embed_tokens`` and the
+``decoder.embed_positions._float_tensor`` buffer).  They only hold parameters: the arithmetic is
+``bsg_fs2midi_*`` in libbisinger_hip (csrc/fs2.hip).
+"""
+import math
+from ctypes import POINTER, byref, c_void_p, cast
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .hparams import hparams
+
+DEFAULT_MAX_TARGET_POSITIONS = 2000
+
+
+def Embedding(num_embeddings, embedding_dim, padding_idx=None):
+    m = nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx)
+    nn.init.normal_(m.weight, mean=0, std=embedding_dim ** -0.5)
+    if padding_idx is not None:
+        nn.init.constant_(m.weight[padding_idx], 0)
+    return m
+
+
+def Linear(in_features, out_features, bias=True):
+    m = nn.Linear(in_features, out_features, bias)
+    nn.init.xavier_uniform_(m.weight)
+    if bias:
+        nn.init.constant_(m.bias, 0.0)
+    return m
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise _lib.BsgError(f'{type(self).__name__} only holds parameters; it runs inside libbisinger_hip')
+
+
+class MultiheadAttention(_Holder):
+    """common_layers.py:199-280 with bias=False: in_proj_weight [3C,C], out_proj.weight [C,C]."""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=False)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.xavier_uniform_(self.out_proj.weight)
+
+
+class TransformerFFNLayer(_Holder):
+    """common_layers.py:598-644 (padding SAME, gelu)."""
+
+    def __init__(self, hidden_size, filter_size, kernel_size):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.ffn_1 = nn.Conv1d(hidden_size, filter_size, kernel_size, padding=kernel_size // 2)
+        self.ffn_2 = Linear(filter_size, hidden_size)
+
+
+class EncSALayer(_Holder):
+    """common_layers.py:664-704."""
+
+    def __init__(self, c, num_heads, kernel_size):
+        super().__init__()
+        self.layer_norm1 = nn.LayerNorm(c)
+        self.self_attn = MultiheadAttention(c, num_heads)
+        self.layer_norm2 = nn.LayerNorm(c)
+        self.ffn = TransformerFFNLayer(c, 4 * c, kernel_size)
+
+
+class TransformerEncoderLayer(_Holder):
+    def __init__(self, hidden_size, kernel_size, num_heads):
+        super().__init__()
+        self.op = EncSALayer(hidden_size, num_heads, kernel_size)
+
+
+class SinusoidalPositionalEmbedding(_Holder):
+    """common_layers.py:106-179.  ``table`` builds the lookup the decoder kernels index by position."""
+
+    def __init__(self, embedding_dim, padding_idx, init_size=1024):
+        super().__init__()
+        self.embedding_dim, self.padding_idx, self.init_size = embedding_dim, padding_idx, init_size
+        self.register_buffer('_float_tensor', torch.zeros(1))
+
+    def table(self, num):
+        half = self.embedding_dim // 2
+        e = math.log(10000) / (half - 1)
+        e = torch.exp(torch.arange(half, dtype=torch.float) * -e)
+        e = torch.arange(num, dtype=torch.float).unsqueeze(1) * e.unsqueeze(0)
+        e = torch.cat([torch.sin(e), torch.cos(e)], dim=1).view(num, -1)
+        if self.padding_idx is not None:
+            e[self.padding_idx, :] = 0
+        return e
+
+
+class RelPositionalEncoding(_Holder):
+    """espnet_positional_embedding.py:90-114 (reverse=True table of :25-46); no parameters."""
+
+    def __init__(self, d_model, max_len=5000):
+        super().__init__()
+        self.d_model, self.max_len = d_model, max_len
+
+    def table(self, length):
+        pe = torch.zeros(length, self.d_model)
+        pos = torch.arange(length - 1, -1, -1.0, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / self.d_model))
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        return pe
+
+
+class FFTBlocks(_Holder):
+    """tts_modules.py:253-282."""
+
+    def __init__(self, hidden_size, num_layers, ffn_kernel_size=9, num_heads=2, use_pos_embed=True):
+        super().__init__()
+        self.num_layers, self.hidden_size, self.use_pos_embed = num_layers, hidden_size, use_pos_embed
+        if use_pos_embed:
+            self.padding_idx = 0
+            self.pos_embed_alpha = nn.Parameter(torch.Tensor([1]))
+            self.embed_positions = SinusoidalPositionalEmbedding(hidden_size, 0, init_size=DEFAULT_MAX_TARGET_POSITIONS)
+        self.layers = nn.ModuleList([TransformerEncoderLayer(hidden_size, ffn_kernel_size, num_heads)
+                                     for _ in range(num_layers)])
+        self.layer_norm = nn.LayerNorm(hidden_size)
+
+
+class FastspeechDecoder(FFTBlocks):
+    def __init__(self):
+        super().__init__(hparams['hidden_size'], hparams['dec_layers'], hparams['dec_ffn_kernel_size'], hparams['num_heads'])
+
+
+class ESM(_Holder):
+    """common_layers.py:832-846."""
+
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.mh = nn.MultiheadAttention(d_model, nhead)
+        self.ffn = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
+        self.ln1 = nn.LayerNorm(d_model)
+        self.ln2 = nn.LayerNorm(d_model)
+
+
+class FastspeechMIDIEncoder(FFTBlocks):
+    """diffsinger_midi/fs2.py:14-17 on tts_modules.py:312-328."""
+
+    def __init__(self, esm, embed_tokens):
+        super().__init__(hparams['hidden_size'], hparams['enc_layers'], hparams['enc_ffn_kernel_size'],
+                         hparams['num_heads'], use_pos_embed=False)
+        self.embed_tokens = embed_tokens
+        self.embed_scale = math.sqrt(hparams['hidden_size'])
+        self.padding_idx = 0
+        self.embed_positions = RelPositionalEncoding(hparams['hidden_size'])
+        self.esm = esm
+
+
+class PredictorLayerNorm(nn.LayerNorm):
+    """tts_modules.py:39-58: LayerNorm over the channel axis of [B,C,T], eps = 1e-12."""
+
+    def __init__(self, nout):
+        super().__init__(nout, eps=1e-12)
+
+
+class DurationPredictor(_Holder):
+    """tts_modules.py:61-106 (dur_loss = mse)."""
+
+    def __init__(self, idim, n_layers, n_chans, kernel_size):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv = nn.ModuleList()
+        for i in range(n_layers):
+            self.conv.append(nn.Sequential(
+                nn.ConstantPad1d(((kernel_size - 1) // 2, (kernel_size - 1) // 2), 0),
+                nn.Conv1d(idim if i == 0 else n_chans, n_chans, kernel_size, stride=1, padding=0),
+                nn.ReLU(), PredictorLayerNorm(n_chans), nn.Dropout(hparams['predictor_dropout'])))
+        assert hparams['dur_loss'] == 'mse', 'only dur_loss: mse is on the BiSinger path'
+        self.linear = nn.Linear(n_chans, 1)
+
+
+class FastSpeech2MIDI(nn.Module):
+    def __init__(self, dictionary, out_dims=None):
+        super().__init__()
+        hp = hparams
+        assert hp['encoder_type'] == 'fft' and hp['decoder_type'] == 'fft'
+        assert hp['use_spk_id'] and not hp['use_spk_embed'] and not hp.get('use_split_spk_id'), \
+            'BiSinger path: use_spk_id speaker table (SURVEY.md §8)'
+        assert not hp['use_pitch_embed'] and not hp['use_energy_embed'], \
+            'pitch/energy predictors are not executed by any BiSinger config (SURVEY.md §2 row 5)'
+        assert hp['ffn_act'] == 'gelu' and hp['ffn_padding'] == 'SAME' and hp['use_pos_embed'] and hp.get('rel_pos')
+        self.dictionary = dictionary
+        self.padding_idx = dictionary.pad()
+        self.enc_layers, self.dec_layers = hp['enc_layers'], hp['dec_layers']
+        self.hidden_size = H = hp['hidden_size']
+        self.encoder_embed_tokens = Embedding(len(dictionary), H, self.padding_idx)
+        self.decoder = FastspeechDecoder()
+        self.out_dims = out_dims if out_dims is not None else hp['audio_num_mel_bins']
+        self.mel_out = Linear(H, self.out_dims, bias=True)
+        self.spk_embed_proj = Embedding(hp['num_spk'] + 1, H)
+        ph = hp['predictor_hidden'] if hp['predictor_hidden'] > 0 else H
+        self.dur_predictor = DurationPredictor(H, hp['dur_predictor_layers'], ph, hp['dur_predictor_kernel'])
+        self.esm = ESM(d_model=H, nhead=8)
+        self.encoder = FastspeechMIDIEncoder(self.esm, self.encoder_embed_tokens)
+        self.midi_embed = Embedding(300, H, self.padding_idx)
+        self.midi_dur_layer = Linear(1, H)
+        self.is_slur_embed = Embedding(2, H)
+        self.lang_embed = Embedding(2, H)
+        self.style_embed = Embedding(3, H)
+        self._h = None
+        self._h_key = None
+
+    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
+                skip_decoder=False, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
+        raise _lib.BsgError('bsg_fs2midi_* kernels not linked yet')

@@ -1,0 +1,135 @@
+/* bisinger_hip.h — C ABI of libbisinger_hip.so: the MI355X (gfx950) mel-generation hot path of BiSinger.
+ *
+ * The reference (BiSinger-SVS/BiSinger) is pure Python on PyTorch and has no FFI of its own; its
+ * plug points for this path are Python callables/registries.  Each entry point below
+ * names the reference interface it stands behind (paths relative to /root/reference/train_bisinger).
+ * The Python drop-ins in bisinger_amd/ (same class names, constructor arguments, state_dict keys) bind
+ * these with ctypes: see INTEGRATION.md.
+ *
+ * Conventions
+ *   - return 0 on success, a negative BSG_E* code on failure; never throws; bsg_last_error() gives
+ *     the thread-local message of the last failure on the calling thread.
+ *   - every tensor argument is a caller-owned, contiguous DEVICE pointer unless it says "host";
+ *     float = IEEE fp32, indices = int64 (torch.long), exactly the reference's dtypes.
+ *   - the library owns packed copies of the weights and its workspaces (sized at create /
+ *     prepare time; nothing is allocated by *_forward / *_sample, which only enqueue on `stream`
+ *     and never synchronise the host, so they can be captured into a hipGraph).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - a handle is single-stream and not re-entrant; distinct handles are independent.
+ */
+#ifndef BISINGER_HIP_H
+#define BISINGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSG_ABI_VERSION 1
+
+#define BSG_OK 0
+#define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
+#define BSG_ENOMEM (-12)  /* hipMalloc failed                                            */
+#define BSG_EHIP (-5)     /* a HIP runtime call failed (message has hipGetErrorString)   */
+#define BSG_ESTATE (-1)   /* call order violated (e.g. forward before prepare)           */
+
+int bsg_abi_version(void);
+const char* bsg_last_error(void);
+/* Name of device 0's architecture ("gfx950"...), or NULL when no HIP device is usable. */
+const char* bsg_device_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * DiffNet — the WaveNet noise predictor.
+ * Stands behind: DIFF_DECODERS['wavenet'] = lambda hp: DiffNet(hp['audio_num_mel_bins'])
+ *   (usr/diffsinger_task.py:24-29) with contract
+ *   denoise_fn(spec [B,1,M,T] f32, t [B] i64, cond [B,H,T] f32) -> [B,1,M,T]  (usr/diff/net.py:107-130).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bsg_diffnet bsg_diffnet;
+
+typedef struct {
+  int32_t in_dims;               /* M: mel bins, DiffNet(in_dims)                 net.py:82     */
+  int32_t residual_channels;     /* C: hparams['residual_channels'] (must be 256) net.py:88     */
+  int32_t encoder_hidden;        /* H: hparams['hidden_size']      (must be 256)  net.py:86     */
+  int32_t residual_layers;       /* L: hparams['residual_layers']                 net.py:87     */
+  int32_t dilation_cycle_length; /* dilation of layer i = 2^(i % cycle), <= 8     net.py:99     */
+  int32_t max_steps;             /* rows of step_table (>= diffusion timesteps)                 */
+} bsg_diffnet_cfg;
+
+/* dev_weights: 10 + 8*L device pointers in DiffNet.state_dict() order (net.py:91-105):
+ *   input_projection.{weight[C,M,1],bias[C]}, mlp.0.{weight[4C,C],bias}, mlp.2.{weight[C,4C],bias},
+ *   residual_layers.i.{dilated_conv.weight[2C,C,3],bias, diffusion_projection.weight[C,C],bias,
+ *                      conditioner_projection.weight[2C,H,1],bias, output_projection.weight[2C,C,1],bias},
+ *   skip_projection.{weight[C,C,1],bias}, output_projection.{weight[M,C,1],bias}.
+ * step_table: device [max_steps, C] = SinusoidalPosEmb(C)(arange(max_steps)) (net.py:32-44), built by
+ *   the host with the same fp32 ops as the reference so the embedding is bit-identical.
+ * The call packs the weights into MFMA fragment order and tabulates mlp(step_table) and every layer's
+ * diffusion_projection of it (net.py:119-120, :67) — work that does not depend on the input.
+ * Synchronises `stream` before returning (the caller may free/modify its weight tensors afterwards). */
+int bsg_diffnet_create(bsg_diffnet** out, const bsg_diffnet_cfg* cfg, const void* const* dev_weights,
+                       int32_t n_weights, const float* step_table, void* stream);
+void bsg_diffnet_destroy(bsg_diffnet* h);
+
+/* Bind a condition: cond [B,H,T] (= decoder_inp^T, shallow_diffusion_tts.py:235).  Computes every
+ * layer's conditioner_projection(cond) + its bias + the dilated conv's bias once ([L,B,2C,T], the
+ * step-invariant part of net.py:68-71) and sizes the workspaces for (B,T).  May allocate. */
+int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B, int32_t T, void* stream);
+
+/* eps = DiffNet(x, t, cond bound by prepare).  x, eps: [B,M,T] (the reference's [B,1,M,T]); t: [B] i64. */
+int bsg_diffnet_forward(bsg_diffnet* h, const float* x, const int64_t* t, float* eps, int32_t B,
+                        int32_t T, void* stream);
+
+/* Per-layer fused residual block alone (net.py:66-78), exported for unit tests and micro-benchmarks:
+ * x_in [B,C,T], t [B] -> x_out [B,C,T]; skip [B,C,T] is read-modify-written unless layer == 0
+ * (first layer stores); the last layer stores skip_sum / sqrt(L) (net.py:126). */
+int bsg_diffnet_residual_layer(bsg_diffnet* h, int32_t layer, const float* x_in, const int64_t* t,
+                               float* x_out, float* skip, int32_t B, int32_t T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Samplers.  Stand behind GaussianDiffusion.p_sample / p_sample_plms and the inference loops
+ * (usr/diff/shallow_diffusion_tts.py:159-201, :258-267).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t num_timesteps;
+  /* host arrays [num_timesteps] = the module's fp32 buffers (shallow_diffusion_tts.py:103-122) */
+  const float* sqrt_recip_alphas_cumprod;
+  const float* sqrt_recipm1_alphas_cumprod;
+  const float* posterior_mean_coef1;
+  const float* posterior_mean_coef2;
+  const float* sigma;          /* exp(0.5*posterior_log_variance_clipped), sigma[0] = 0 (:165-166) */
+  const float* alphas_cumprod; /* PLMS only (:175-176)                                            */
+} bsg_schedule;
+
+/* DDPM ancestral loop B (:265-267): for i = t_start, t_start-1, ..., t_start-n_steps+1:
+ *     x <- p_sample(x, full((B,), i), cond)
+ * x: [B,M,T] in (x_{t_start+1}) / out.  noise: [n_steps,B,M,T] N(0,1) draws, one per executed step
+ * (parity mode), or NULL: draws come from the on-device Philox4x32-10 stream (seed, global row, step)
+ * documented in bisinger_amd/synth.py (bench mode).  row0/B_total: global batch row of this shard's
+ * row 0 and global batch size, so a sharded run reproduces the unsharded noise. */
+int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float* noise, uint64_t seed,
+                    int32_t t_start, int32_t n_steps, int32_t B, int32_t T, int32_t row0,
+                    int32_t B_total, void* stream);
+
+/* x[0..n) <- N(0,1) from the same Philox4x32-10 stream family: element i = lane i%4 of counter
+ * ((offset+i)/4, stream_id, 0, 0), key = seed (x_T under gaussian_start uses stream_id 0, the step with
+ * timestep i uses stream_id i+1).  n and offset must be multiples of 4. */
+int bsg_philox_normal(float* x, int64_t n, uint64_t seed, uint32_t stream_id, uint64_t offset, void* stream);
+
+/* PLMS / PNDM loop A (:258-264, p_sample_plms :168-201): for i in reversed(range(0,K_step,interval)).
+ * Batched semantics = element-wise clamp of t-interval (the reference raises for B>1, :189). */
+int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, int32_t K_step, int32_t interval,
+                    int32_t B, int32_t T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building block exported for unit tests: C[b] = op(A[b]) * B[b] (+bias)(+epilogue), fp32 MFMA.
+ *   A: [M,K] row-major (lda);  B: trans_b ? [N,K] row-major : [K,N] row-major (ldb);  C: [M,N] (ldc).
+ * ---------------------------------------------------------------------------------------------- */
+int bsg_gemm_f32(const float* A, const float* Bm, float* C, const float* bias_m, const float* bias_n,
+                 int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc, int32_t trans_b,
+                 int32_t batch, int64_t strideA, int64_t strideB, int64_t strideC, int32_t relu,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BISINGER_HIP_H */

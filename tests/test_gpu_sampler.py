@@ -1,0 +1,98 @@
+"""GPU parity: DDPM / PLMS loops in libbisinger_hip against the goldens produced by the reference."""
+import numpy as np
+import pytest
+import torch
+
+from bisinger_amd import synth
+from bisinger_amd.hparams import hparams
+from oracle import diffnet as odn, diffusion as odf
+from tests.util import cpu_sd, load_formula_weights, maxabs, use_config
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+T_ = torch.from_numpy
+
+
+class _Enc:
+    def __len__(self):
+        return 65
+
+    def pad(self):
+        return 0
+
+
+@pytest.fixture(scope='module')
+def model():
+    use_config()
+    from bisinger_amd.diffnet import DIFF_DECODERS
+    from bisinger_amd.diffusion import GaussianDiffusion
+    m = GaussianDiffusion(_Enc(), 80, DIFF_DECODERS['wavenet'](hparams), timesteps=100, K_step=100,
+                          spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+    load_formula_weights(m, 0, synth.DIFFNET_GAIN)
+    return m.cuda()
+
+
+def _cond():
+    rs = np.random.RandomState(11)
+    rs.standard_normal((2, 1, 80, 64))
+    return T_(rs.standard_normal((2, 256, 64)).astype(np.float32))
+
+
+def test_schedule_buffers_bit_exact(model, gold):
+    g = gold('schedules')
+    for k in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
+              'log_one_minus_alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
+              'posterior_variance', 'posterior_log_variance_clipped', 'posterior_mean_coef1', 'posterior_mean_coef2'):
+        assert np.array_equal(getattr(model, k).cpu().numpy(), g[f'lin100_006.{k}']), k
+    assert np.array_equal(model.spec_min.cpu().numpy(), g['spec_min'])
+
+
+def test_p_sample_and_trajectory_golden(model, gold):
+    g = gold('sampler')
+    cond = _cond().cuda()
+    noise = synth.synth_noise(100, 2, 80, 64, seed=1)
+    x1 = model.p_sample(T_(noise[0][:, None]).cuda(), torch.full((2,), 99, dtype=torch.long).cuda(), cond,
+                        noise=T_(noise[1]).cuda())
+    assert maxabs(x1, g['p_sample_t99']) <= 5e-5
+    # intermediate checkpoints of the trajectory, then the end point: the 1e-3 bar of BASELINE.json
+    x = T_(noise[0][:, None]).cuda().contiguous()
+    nz = T_(noise[1:]).cuda()
+    model.K_step = 100
+    x = model.sample(cond, x, noise=nz[:10], n_steps=10)          # t = 99..90
+    assert maxabs(x, g['x_t90']) <= 2e-4
+    model.K_step = 90
+    x = model.sample(cond, x, noise=nz[10:50], n_steps=40)        # t = 89..50
+    assert maxabs(x, g['x_t50']) <= 5e-4
+    model.K_step = 50
+    x = model.sample(cond, x, noise=nz[50:])                      # t = 49..0
+    model.K_step = 100
+    assert maxabs(x, g['x_t0']) <= 1e-3 / 2.2                     # normalised units; denorm scales by <= 3
+
+
+def test_plms_vs_oracle(model):
+    """Shipped sampler (pndm_speedup) with batched semantics; oracle = same algorithm on the CPU."""
+    sd = cpu_sd(model)
+    cond = _cond()
+    noise = synth.synth_noise(1, 2, 80, 64, seed=9)
+    x0 = T_(noise[0][:, None])
+    den = lambda x_, t_: odn.diffnet_forward(sd, x_, t_, cond, 'denoise_fn.')
+    sch = odf.make_schedule(100, 'linear', 0.06)
+    want = odf.plms_sample(sch, den, x0, 100, 5)
+    hparams['pndm_speedup'] = 5
+    try:
+        got = model.sample(cond.cuda(), x0.cuda().contiguous())
+    finally:
+        hparams['pndm_speedup'] = 0
+    assert maxabs(got, want) <= 5e-4
+
+
+def test_philox_mode_is_reproducible_and_shard_invariant(model):
+    cond = torch.randn(4, 256, 64, generator=torch.Generator().manual_seed(3)).cuda()
+    def run(rows, row0):
+        x = model.philox_normal((len(rows), 1, 80, 64), 'cuda', 77, 0, row0 * 80 * 64)
+        return model.sample(cond[rows].contiguous(), x, seed=77, row0=row0, B_total=4, n_steps=5)
+    full = run([0, 1, 2, 3], 0)
+    again = run([0, 1, 2, 3], 0)
+    assert torch.equal(full, again)
+    half = run([2, 3], 2)
+    assert torch.equal(full[2:], half)
