@@ -20,6 +20,12 @@ class DiffnetCfg(Structure):
                 ('residual_layers', c_int32), ('dilation_cycle_length', c_int32), ('max_steps', c_int32)]
 
 
+class Fs2Cfg(Structure):
+    _fields_ = [(n, c_int32) for n in ('hidden_size', 'vocab', 'enc_layers', 'dec_layers', 'num_heads',
+                                       'enc_ffn_kernel_size', 'dec_ffn_kernel_size', 'out_dims', 'dur_layers',
+                                       'dur_kernel', 'spk_rows', 'esm_heads', 'n_pos', 'n_rel')]
+
+
 class Schedule(Structure):
     _fields_ = [('num_timesteps', c_int32),
                 ('sqrt_recip_alphas_cumprod', POINTER(c_float)), ('sqrt_recipm1_alphas_cumprod', POINTER(c_float)),
@@ -40,6 +46,14 @@ _SIGS = {
                                   c_int32, c_int32, c_int32, c_void_p]),
     'bsg_plms_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_philox_normal': (c_int32, [c_void_p, c_int64, c_uint64, c_uint32, c_uint64, c_void_p]),
+    'bsg_fs2midi_n_weights': (c_int32, [POINTER(Fs2Cfg)]),
+    'bsg_fs2midi_create': (c_int32, [POINTER(c_void_p), POINTER(Fs2Cfg), POINTER(c_void_p), c_int32, c_void_p, c_void_p, c_void_p]),
+    'bsg_fs2midi_destroy': (None, [c_void_p]),
+    'bsg_fs2midi_encode': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    'bsg_length_regulator': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_fs2midi_decode': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                     c_void_p, c_void_p]),
     'bsg_gemm_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),
 }

@@ -48,7 +48,9 @@ struct GemmArgs {
   float* C;
   int M, N, K;
   int lda, ldb, ldc;
-  long long sA, sB, sC;  // batch strides (elements)
+  long long sA, sB, sC;  // batch strides (elements) of the outer batch index z / batch2
+  int batch2;            // inner batch count (0/1 = none): z = zo*batch2 + zi, offset = zo*s + zi*s2
+  long long sA2, sB2, sC2;
   int trans_b;           // 1: B is [N,K] row-major; 0: B is [K,N] row-major
   int taps;              // conv-as-GEMM over A rows: K-segments; A row = i + tap_shift0 + tap
   int tap_shift0;
@@ -56,6 +58,7 @@ struct GemmArgs {
   const float* bias_m;   // per output row
   const float* bias_n;   // per output column
   float alpha;           // v = (acc + bias) * alpha
+  int alpha_ncols;       // 0: every column; n > 0: only columns < n are scaled (q part of a fused QKV projection)
   int act;
   const float* R;        // residual added after the activation: v += R[b][i][j]
   int ldr;

@@ -525,11 +525,10 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
 }
 
 static int pick_nb(int B, int T) {
-  // fill the 256 CUs: prefer the widest tile that still yields >= 256 workgroups
-  for (int nb : {4, 2}) {
-    const long long wgs = (long long)B * cdiv(T, 32 * nb);
-    if (wgs >= 256) return nb;
-  }
+  // Measured on MI355X (tools/bench_layer.py, profiles/): the 32-frame tile (48 KB LDS, 3 workgroups per
+  // CU, every wave a different 32-row slice of the same frames) is fastest at every batch size tried
+  // (B = 1..64, T = 500..1000): more resident workgroups hide the L2 latency of the weight stream.
+  (void)B; (void)T;
   return 1;
 }
 

@@ -29,10 +29,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int bm = blockIdx.y * BM, bn = blockIdx.x * BN, bz = blockIdx.z;
 
-  const float* __restrict__ A = g.A + (long long)bz * g.sA;
-  const float* __restrict__ Bp = g.B + (long long)bz * g.sB;
+  const int b2 = g.batch2 > 1 ? g.batch2 : 1;
+  const int zo = bz / b2, zi = bz - zo * b2;
+  const float* __restrict__ A = g.A + (long long)zo * g.sA + (long long)zi * g.sA2;
+  const float* __restrict__ Bp = g.B + (long long)zo * g.sB + (long long)zi * g.sB2;
 
-  const bool vecA = ((g.lda | g.K) & 3) == 0 && ((((uintptr_t)A) & 15) == 0);
+  const bool vecA = ((g.lda | g.K) & 3) == 0 && ((((uintptr_t)A) & 15) == 0);   // A, Bp include the batch offsets
   const bool vecB = TRANS_B ? (((g.ldb | g.K) & 3) == 0 && ((((uintptr_t)Bp) & 15) == 0) && ((g.sTapB & 3) == 0))
                             : (((g.ldb | g.N) & 3) == 0 && ((((uintptr_t)Bp) & 15) == 0) && ((g.sTapB & 3) == 0));
 
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 
   // epilogue: lanes 0..31 of a register hold 32 consecutive columns of one row -> 128-B stores
-  float* __restrict__ C = g.C + (long long)bz * g.sC;
-  const float* __restrict__ R = g.R ? g.R + (long long)bz * g.sR : nullptr;
-  const float* __restrict__ RS = g.rowscale ? g.rowscale + (long long)bz * g.sRS : nullptr;
+  float* __restrict__ C = g.C + (long long)zo * g.sC + (long long)zi * g.sC2;
+  const float* __restrict__ R = g.R ? g.R + (long long)zo * g.sR : nullptr;
+  const float* __restrict__ RS = g.rowscale ? g.rowscale + (long long)zo * g.sRS : nullptr;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (row < g.M && col < g.N) {
           float v = acc[mi][ni][r] + bn_v;
           if (g.bias_m) v += g.bias_m[row];
-          v *= g.alpha;
+          if (g.alpha_ncols == 0 || col < g.alpha_ncols) v *= g.alpha;
           if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
           else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
           else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));

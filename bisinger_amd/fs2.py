@@ -212,6 +212,108 @@ class FastSpeech2MIDI(nn.Module):
         self._h = None
         self._h_key = None
 
+    # ------------------------------------------------------------------ handle management
+    def _weights(self):
+        return list(self.state_dict(keep_vars=True).values())
+
+    def _key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
+
+    def handle(self):
+        key = self._key()
+        if self._h is not None and key == self._h_key:
+            return self._h
+        self.release()
+        ws = [p.detach() for p in self._weights()]
+        for p in ws:
+            if not p.is_cuda:
+                raise _lib.BsgError('FastSpeech2MIDI parameters must live on the GPU (model.cuda()); there is no CPU path')
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.BsgError('FastSpeech2MIDI parameters must be contiguous float32')
+        hp = hparams
+        lib = _lib.load()
+        self._n_pos = max(DEFAULT_MAX_TARGET_POSITIONS, int(hp.get('max_frames', 5000))) + 2
+        self._n_rel = self.encoder.embed_positions.max_len
+        cfg = _lib.Fs2Cfg(self.hidden_size, self.encoder_embed_tokens.num_embeddings, self.enc_layers, self.dec_layers,
+                          hp['num_heads'], hp['enc_ffn_kernel_size'], hp['dec_ffn_kernel_size'], self.out_dims,
+                          hp['dur_predictor_layers'], hp['dur_predictor_kernel'], self.spk_embed_proj.num_embeddings, 8,
+                          self._n_pos, self._n_rel)
+        assert lib.bsg_fs2midi_n_weights(byref(cfg)) == len(ws)
+        dev = ws[0].device
+        dec_table = self.decoder.embed_positions.table(self._n_pos).to(dev).contiguous()
+        rel_table = self.encoder.embed_positions.table(self._n_rel).to(dev).contiguous()
+        arr = (c_void_p * len(ws))(*[p.data_ptr() for p in ws])
+        h = c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(lib.bsg_fs2midi_create(byref(h), byref(cfg), cast(arr, POINTER(c_void_p)), len(ws),
+                                              _lib.ptr(dec_table), _lib.ptr(rel_table), _lib.stream_ptr()),
+                       'bsg_fs2midi_create')
+        self._h, self._h_key = h, key
+        return h
+
+    def release(self):
+        if self._h is not None:
+            _lib.load().bsg_fs2midi_destroy(self._h)
+        self._h = self._h_key = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference forward (fs2.py:94-197)
+    @torch.no_grad()
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
                 skip_decoder=False, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
-        raise _lib.BsgError('bsg_fs2midi_* kernels not linked yet')
+        lib = _lib.load()
+        h = self.handle()
+        dev = txt_tokens.device
+        i64 = lambda t: t.to(device=dev, dtype=torch.long).contiguous()
+        txt = i64(txt_tokens)
+        B, Tt = txt.shape
+        if Tt > self._n_rel:
+            raise _lib.BsgError(f'T_txt={Tt} exceeds the positional table ({self._n_rel})')
+        pitch_midi, lang, speechsing = i64(kwargs['pitch_midi']), i64(kwargs['lang']), i64(kwargs['speechsing'])
+        midi_dur = kwargs.get('midi_dur')
+        midi_dur = torch.zeros(B, Tt, device=dev) if midi_dur is None else midi_dur.to(dev, torch.float32).contiguous()
+        is_slur = kwargs.get('is_slur')
+        is_slur = torch.zeros(B, Tt, dtype=torch.long, device=dev) if is_slur is None else i64(is_slur)
+        if kwargs.get('midi_dur') is None or kwargs.get('is_slur') is None:
+            raise _lib.BsgError('midi_dur and is_slur are required (every BiSinger entry point passes them)')
+        spk = i64(spk_embed)
+        ret = {}
+        enc_out = torch.empty(B, Tt, self.hidden_size, device=dev)
+        predict = mel2ph is None
+        dur_xs = torch.empty(B, Tt, device=dev) if predict else None
+        dur = torch.empty(B, Tt, dtype=torch.long, device=dev) if predict else None
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr()
+            _lib.check(lib.bsg_fs2midi_encode(h, _lib.ptr(txt), _lib.ptr(pitch_midi), _lib.ptr(midi_dur), _lib.ptr(is_slur),
+                                              _lib.ptr(lang), _lib.ptr(spk), B, Tt, _lib.ptr(enc_out), _lib.ptr(dur_xs),
+                                              _lib.ptr(dur), st), 'bsg_fs2midi_encode')
+            if predict:
+                # the reference's one host sync: the output length is data dependent (tts_modules.py:182)
+                T = int((dur * (txt != 0)).sum(-1).max().item())
+                if T <= 0:
+                    raise _lib.BsgError('duration predictor produced an empty utterance')
+                mel2ph = torch.empty(B, T, dtype=torch.long, device=dev)
+                _lib.check(lib.bsg_length_regulator(_lib.ptr(dur), _lib.ptr(txt), _lib.ptr(mel2ph), B, Tt, T, st),
+                           'bsg_length_regulator')
+                ret['dur'] = dur_xs[:, :, None]
+                ret['dur_choice'] = dur
+            else:
+                mel2ph = i64(mel2ph)
+                # (the reference also evaluates the predictor here for the training loss; not needed to infer)
+            T = mel2ph.shape[1]
+            if T >= self._n_pos:
+                raise _lib.BsgError(f'T={T} exceeds the decoder position table ({self._n_pos})')
+            ret['mel2ph'] = mel2ph
+            decoder_inp = torch.empty(B, T, self.hidden_size, device=dev)
+            mel_out = None if skip_decoder else torch.empty(B, T, self.out_dims, device=dev)
+            _lib.check(lib.bsg_fs2midi_decode(h, _lib.ptr(enc_out), _lib.ptr(mel2ph), _lib.ptr(spk), _lib.ptr(speechsing),
+                                              B, Tt, T, _lib.ptr(decoder_inp), _lib.ptr(mel_out), st), 'bsg_fs2midi_decode')
+        ret['decoder_inp'] = decoder_inp
+        if not skip_decoder:
+            ret['mel_out'] = mel_out
+        return ret

@@ -121,6 +121,63 @@ int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, int32_t K_s
                     int32_t B, int32_t T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * FastSpeech2-MIDI: phoneme/pitch encoder -> per-frame condition, and the FFT mel decoder.
+ * Stands behind FastSpeech2MIDI.forward (modules/diffsinger_midi/fs2.py:94-197), split at the one
+ * data-dependent point of the reference (the length regulator's output length, tts_modules.py:182):
+ *   encode  = embeddings + ESM + FastspeechMIDIEncoder (+ DurationPredictor.inference)     fs2.py:111-165
+ *   bsg_length_regulator = LengthRegulator.forward                                 tts_modules.py:161-191
+ *   decode  = gather by mel2ph, +spk +style, mask -> decoder_inp; FastspeechDecoder + mel_out  fs2.py:166-195
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bsg_fs2midi bsg_fs2midi;
+
+typedef struct {
+  int32_t hidden_size;          /* must be 256                                  hparams['hidden_size']   */
+  int32_t vocab;                /* len(phone_encoder)                           fastspeech/fs2.py:94     */
+  int32_t enc_layers, dec_layers, num_heads;
+  int32_t enc_ffn_kernel_size, dec_ffn_kernel_size;
+  int32_t out_dims;             /* mel bins                                                              */
+  int32_t dur_layers, dur_kernel;
+  int32_t spk_rows;             /* num_spk + 1                                  fastspeech/fs2.py:40     */
+  int32_t esm_heads;            /* 8                                            diffsinger_midi/fs2.py:83 */
+  int32_t n_pos;                /* rows of dec_pos_table (frames T must be < n_pos)                      */
+  int32_t n_rel;                /* rows of rel_pos_table (T_txt must be <= n_rel)                        */
+} bsg_fs2midi_cfg;
+
+/* Number of entries of FastSpeech2MIDI.state_dict() for this configuration (143 for BiSinger). */
+int bsg_fs2midi_n_weights(const bsg_fs2midi_cfg* cfg);
+
+/* dev_weights: device pointers in FastSpeech2MIDI.state_dict() order (tests/golden/state_dict_spec.json,
+ * keys 'fs2.*'): encoder_embed_tokens, decoder.{pos_embed_alpha, embed_positions._float_tensor,
+ * layers.i.op.{layer_norm1.w,b, self_attn.in_proj_weight, self_attn.out_proj.weight, layer_norm2.w,b,
+ * ffn.ffn_1.w,b, ffn.ffn_2.w,b}, layer_norm.w,b}, mel_out.w,b, spk_embed_proj, dur_predictor.{conv.i.1.w,b,
+ * conv.i.3.w,b, linear.w,b}, esm.{mh.in_proj_weight, in_proj_bias, out_proj.w,b, ffn.0.w,b, ffn.2.w,b,
+ * ln1.w,b, ln2.w,b}, encoder.{layers..., layer_norm.w,b, embed_tokens (alias), esm.* (alias)},
+ * midi_embed, midi_dur_layer.w,b, is_slur_embed, lang_embed, style_embed.
+ * dec_pos_table [n_pos,H]: SinusoidalPositionalEmbedding table (common_layers.py:124-146, row 0 zero);
+ * rel_pos_table [n_rel,H]: RelPositionalEncoding's reversed table rows 0..n_rel-1 of max_len 5000
+ * (espnet_positional_embedding.py:25-46) — both built by the host with the reference's own fp32 ops.
+ * The library keeps its own (re-packed) copies; synchronises `stream` before returning. */
+int bsg_fs2midi_create(bsg_fs2midi** out, const bsg_fs2midi_cfg* cfg, const void* const* dev_weights,
+                       int32_t n_weights, const float* dec_pos_table, const float* rel_pos_table, void* stream);
+void bsg_fs2midi_destroy(bsg_fs2midi* h);
+
+/* txt, pitch_midi, is_slur, lang: [B,T_txt] i64; midi_dur [B,T_txt] f32; spk_id [B] i64.
+ * enc_out [B,T_txt,H].  dur_xs [B,T_txt] f32 (log-domain predictor output, ret['dur']) and dur [B,T_txt] i64
+ * (ret['dur_choice']) are both NULL (mel2ph given) or both set (mel2ph predicted).  May grow workspaces. */
+int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
+                       const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B,
+                       int32_t T_txt, float* enc_out, float* dur_xs, int64_t* dur, void* stream);
+
+/* mel2ph [B,T] from dur [B,T_txt] (padded tokens, txt == 0, count 0 when txt != NULL); T = max_b sum(dur). */
+int bsg_length_regulator(const int64_t* dur, const int64_t* txt, int64_t* mel2ph, int32_t B, int32_t T_txt,
+                         int32_t T, void* stream);
+
+/* decoder_inp [B,T,H] (ret['decoder_inp']); mel_out [B,T,out_dims] (ret['mel_out']) or NULL = skip_decoder. */
+int bsg_fs2midi_decode(bsg_fs2midi* h, const float* enc_out, const int64_t* mel2ph, const int64_t* spk_id,
+                       const int64_t* speechsing, int32_t B, int32_t T_txt, int32_t T, float* decoder_inp,
+                       float* mel_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building block exported for unit tests: C[b] = op(A[b]) * B[b] (+bias)(+epilogue), fp32 MFMA.
  *   A: [M,K] row-major (lda);  B: trans_b ? [N,K] row-major : [K,N] row-major (ldb);  C: [M,N] (ldc).
  * ---------------------------------------------------------------------------------------------- */

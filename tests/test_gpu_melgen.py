@@ -1,0 +1,69 @@
+"""GPU parity: the whole drop-in GaussianDiffusion.forward(infer=True) against the reference's goldens
+(the 1e-3 max-abs bar on fp32 mels of BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+from bisinger_amd import synth
+from bisinger_amd.hparams import hparams
+from tests.util import load_formula_weights, maxabs, use_config
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+class _Enc:
+    def __len__(self):
+        return 65
+
+    def pad(self):
+        return 0
+
+
+@pytest.fixture(scope='module')
+def model():
+    use_config()
+    from bisinger_amd.diffnet import DIFF_DECODERS
+    from bisinger_amd.diffusion import GaussianDiffusion
+    m = GaussianDiffusion(_Enc(), 80, DIFF_DECODERS[hparams['diff_decoder_type']](hparams), timesteps=100, K_step=100,
+                          spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+    load_formula_weights(m, 0, synth.DIFFNET_GAIN)
+    return m.cuda()
+
+
+def _call(model, inp, noise):
+    d = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
+    return model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True,
+                 noise=torch.from_numpy(noise), **kw)
+
+
+@pytest.mark.parametrize('tag,B,Tt,Tm,ragged', [('B2', 2, 12, 64, False), ('B3r', 3, 10, 50, True)])
+def test_melgen_golden(model, gold, tag, B, Tt, Tm, ragged):
+    g = gold('melgen')
+    out = _call(model, synth.synth_inputs(B, Tt, Tm, seed=2, ragged=ragged), synth.synth_noise(100, B, 80, Tm, seed=3))
+    assert set(('mel_out', 'fs2_mel', 'mel2ph', 'decoder_inp')) <= set(out)
+    assert out['mel_out'].shape == (B, Tm, 80)
+    assert maxabs(out['mel_out'], g[f'{tag}.mel_out']) <= 1e-3
+
+
+def test_melgen_shallow_start(model, gold):
+    g = gold('melgen')
+    hparams['gaussian_start'] = False
+    model.K_step = 51
+    try:
+        out = _call(model, synth.synth_inputs(2, 12, 64, seed=2), synth.synth_noise(51, 2, 80, 64, seed=4))
+    finally:
+        hparams['gaussian_start'] = True
+        model.K_step = 100
+    assert maxabs(out['mel_out'], g['shallow51.mel_out']) <= 1e-3
+
+
+def test_melgen_plms_b1(model, gold):
+    g = gold('melgen')
+    hparams['pndm_speedup'] = 5
+    try:
+        out = _call(model, synth.synth_inputs(1, 12, 64, seed=2), synth.synth_noise(100, 1, 80, 64, seed=5))
+    finally:
+        hparams['pndm_speedup'] = 0
+    assert maxabs(out['mel_out'], g['plms5.mel_out']) <= 1e-3
