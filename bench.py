@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — mel-frames/s of the BiSinger mel-generation hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic utterances already resident in HBM:
+GaussianDiffusion.forward(infer=True) = FastSpeech2-MIDI encoder+decoder, 100 DDPM ancestral sampler
+steps of the 20-layer DiffNet (on-device Philox noise), de-normalisation — and, for N > 1, the RCCL
+all-gather of the generated mels.  Workload at N = 1: BASELINE.json configs[1] (B=16, T=1000, 80 mel,
+fp32).  Weak scaling: every rank generates 16 utterances of the 16*N batch.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fused residual layer), timed live with HIP events on the launch
+                 stream during the timed steps, against the fp32 MFMA peak;
+  cpu_baseline : the oracle (PyTorch-CPU restatement of the reference, oracle/) timed on this host on a
+                 bounded sample of the same workload (rank 0, N = 1 only), extrapolated to 100 steps;
+                 the same sample is also replayed on the GPU with the same supplied noise -> `parity`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_FRAME_LAYER = 2 * (512 * 768 + 512 * 256)   # dilated conv + output projection
+PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+B_PER_GPU, T_FRAMES, T_TXT, N_MEL, N_DIFF_STEPS = 16, 1000, 100, 80, 100
+
+
+class PhoneEncoder:
+    """Stand-in for TokenTextEncoder: the model only needs len() and pad() (fastspeech/fs2.py:28,92)."""
+
+    def __len__(self):
+        return 65
+
+    def pad(self):
+        return 0
+
+
+def build_model(device):
+    from bisinger_amd import synth
+    from bisinger_amd.diffnet import DIFF_DECODERS
+    from bisinger_amd.diffusion import GaussianDiffusion
+    from bisinger_amd.hparams import hparams, set_hparams
+    set_hparams(os.path.join(ROOT, 'bisinger_amd', 'configs', 'bisinger_diff100.yaml'), print_hparams=False)
+    model = GaussianDiffusion(PhoneEncoder(), N_MEL, DIFF_DECODERS[hparams['diff_decoder_type']](hparams),
+                              timesteps=hparams['timesteps'], K_step=hparams['K_step'],
+                              spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+    from collections import OrderedDict
+    spec = OrderedDict((k, tuple(v.shape)) for k, v in model.state_dict().items())
+    w = synth.synth_state_dict(spec, 0, synth.DIFFNET_GAIN)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    return model.to(device).eval()
+
+
+def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps):
+    """Oracle on the host CPU for FS2 + n_sample_steps sampler steps; the same steps on the GPU with the same noise."""
+    from bisinger_amd import synth
+    from oracle import fs2 as ofs2, melgen as omg
+    B = inp_np['txt_tokens'].shape[0]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    inp = {k: torch.from_numpy(v) for k, v in inp_np.items()}
+    noise = torch.from_numpy(synth.synth_noise(n_sample_steps, B, N_MEL, T_FRAMES, seed=1))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        fs2_out = ofs2.fs2_forward(sd, inp)
+        t1 = time.perf_counter()
+        ret = omg.mel_gen(sd, inp, noise, fs2_out=fs2_out, n_steps=n_sample_steps)
+        t2 = time.perf_counter()
+    est = (t1 - t0) + (t2 - t1) / n_sample_steps * N_DIFF_STEPS
+    # replay on the GPU
+    d = {k: v.to(device) for k, v in inp.items()}
+    kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
+    g = model.fs2(d['txt_tokens'], d['mel2ph'], d['spk_embed'], None, None, None, None, skip_decoder=False, infer=True, **kw)
+    x = noise[0][:, None].to(device).contiguous()
+    x = model.sample(g['decoder_inp'].transpose(1, 2).contiguous(), x, noise=noise[1:].to(device), n_steps=n_sample_steps)
+    torch.cuda.synchronize()
+    parity = {
+        'what': f'GPU vs oracle after FS2 + the first {n_sample_steps} sampler steps, same supplied noise, full bench shape',
+        'x_max_abs': float((x.cpu() - ret['x']).abs().max()),
+        'cond_max_abs': float((g['decoder_inp'].cpu() - fs2_out['decoder_inp']).abs().max()),
+        'fs2_mel_max_abs': float((g['mel_out'].cpu() - fs2_out['mel_out']).abs().max()),
+    }
+    base = {
+        'value': B * T_FRAMES / est, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+        'sample': f'oracle (PyTorch-CPU restatement, fp32): full FS2-MIDI enc+dec ({t1 - t0:.2f} s) + {n_sample_steps} of '
+                  f'{N_DIFF_STEPS} sampler steps ({t2 - t1:.2f} s) at B={B}, T={T_FRAMES}; steps extrapolated x{N_DIFF_STEPS}/{n_sample_steps}',
+        'est_seconds_per_pass': est,
+    }
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--cpu-steps', type=int, default=6, help='sampler steps of the CPU-baseline sample (0 = skip)')
+    args = ap.parse_args()
+
+    from bisinger_amd import dist as bdist, synth
+    rank, local_rank, world = bdist.env_world()
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs one process per GPU: launch with '
+                     f'python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...')
+        world, rank, local_rank = 1, 0, 0
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        bdist.init_distributed('nccl')
+    import torch.distributed as dist
+
+    torch.set_grad_enabled(False)
+    model = build_model(device)
+    B_total = B_PER_GPU * world
+    inp_np = synth.synth_inputs(B_total, T_TXT, T_FRAMES, seed=1)
+    d = {k: torch.from_numpy(v).to(device) for k, v in inp_np.items()}     # inputs resident in HBM
+    kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
+    rows = bdist.shard_rows(B_total, rank, world)
+
+    def step(seed):
+        out = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True,
+                    seed=seed, rows=rows if world > 1 else None, **kw)
+        return bdist.all_gather_rows(out['mel_out'], B_total, world, rank)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        mel = step(1000 + i)
+    fence()
+    model.denoise_fn.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        mel = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    layer_ms, n_layer = model.denoise_fn.profile_read()
+    model.denoise_fn.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert mel.shape == (B_total, T_FRAMES, N_MEL) and bool(torch.isfinite(mel).all())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = B_total * T_FRAMES * args.steps / dt
+        frames_per_launch = B_PER_GPU * T_FRAMES
+        avg_ms = layer_ms / max(n_layer, 1)
+        achieved = FLOP_PER_FRAME_LAYER * frames_per_launch / (avg_ms * 1e-3) / 1e12 if n_layer else None
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get('residual_layer_kernel_hbm_bytes_per_launch')
+        rec = {
+            'metric': 'mel_frames_per_sec', 'value': value, 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE.json configs[1]: B={B_PER_GPU}/GPU x T={T_FRAMES} x {N_MEL}-mel, FS2-MIDI enc+dec + '
+                                   f'{N_DIFF_STEPS}-step DDPM sampler (20-layer DiffNet, 256 ch), fp32, formula weights',
+                       'global_batch': B_total, 'frames_per_utt': T_FRAMES, 'diffusion_steps': N_DIFF_STEPS,
+                       'parallelism': f'utterance-sharded x{world}, RCCL all-gather of mels' if world > 1 else 'single GPU'},
+            'roofline': {'kernel': 'residual_layer_kernel<1> (fused DiffNet residual block)', 'bound': 'mfma',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': traffic,
+                         'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
+                         'flop_per_launch': FLOP_PER_FRAME_LAYER * frames_per_launch},
+        }
+        if world == 1 and args.cpu_steps > 0:
+            base, parity = cpu_baseline_and_parity(model, inp_np, device, args.cpu_steps)
+            rec['cpu_baseline'] = base
+            rec['parity'] = parity
+            rec['gpu_over_cpu'] = value / base['value']
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -4,7 +4,7 @@ There is NO fallback: if the library is missing or a call fails, the product pat
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
@@ -46,6 +46,10 @@ _SIGS = {
                                   c_int32, c_int32, c_int32, c_void_p]),
     'bsg_plms_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_philox_normal': (c_int32, [c_void_p, c_int64, c_uint64, c_uint32, c_uint64, c_void_p]),
+    'bsg_mel_start': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_mel_finish': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_diffnet_profile': (c_int32, [c_void_p, c_int32]),
+    'bsg_diffnet_profile_read': (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'bsg_fs2midi_n_weights': (c_int32, [POINTER(Fs2Cfg)]),
     'bsg_fs2midi_create': (c_int32, [POINTER(c_void_p), POINTER(Fs2Cfg), POINTER(c_void_p), c_int32, c_void_p, c_void_p, c_void_p]),
     'bsg_fs2midi_destroy': (None, [c_void_p]),

@@ -301,6 +301,56 @@ __global__ void philox_fill_kernel(float* __restrict__ x, long long n4, unsigned
   reinterpret_cast<f32x4*>(x)[i] = philox_normal4(seed, stream, quad0 + (unsigned long long)i);
 }
 
+// mel_out[b,t,m] = denorm(x[b,m,t]) * (mel2ph[b,t] > 0)     (shallow_diffusion_tts.py:268-272, :278-279)
+// [M][64]-frame tile through LDS: reads coalesced along t, writes coalesced along m.
+__global__ __launch_bounds__(256) void mel_finish_kernel(const float* __restrict__ x, const float* __restrict__ smin,
+                                                         const float* __restrict__ smax, const long long* __restrict__ mel2ph,
+                                                         float* __restrict__ out, int M, int T) {
+  extern __shared__ float tile[];   // [M][65]
+  const int b = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int i = tid; i < M * 64; i += 256) {
+    const int m = i >> 6, j = i & 63;
+    const int t = t0 + j;
+    tile[m * 65 + j] = t < T ? x[((long long)b * M + m) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * M; i += 256) {
+    const int j = i / M, m = i - j * M;
+    const int t = t0 + j;
+    if (t >= T) continue;
+    const float lo = smin[m], hi = smax[m];
+    float v = __fadd_rn(__fmul_rn(__fadd_rn(tile[m * 65 + j], 1.0f) / 2.0f, __fsub_rn(hi, lo)), lo);
+    if (mel2ph && mel2ph[(long long)b * T + t] <= 0) v = v * 0.f;
+    out[((long long)b * T + t) * M + m] = v;
+  }
+}
+
+// shallow-diffusion start x = q_sample(norm_spec(fs2_mel)^T, K_step-1)          (:249-252, :203-208, :275-276)
+__global__ __launch_bounds__(256) void mel_start_kernel(const float* __restrict__ mel, const float* __restrict__ smin,
+                                                        const float* __restrict__ smax, const float* __restrict__ noise,
+                                                        float ca, float cb, float* __restrict__ x, int M, int T) {
+  extern __shared__ float tile[];   // [64][M+1]
+  const int b = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int i = tid; i < 64 * M; i += 256) {
+    const int j = i / M, m = i - j * M;
+    const int t = t0 + j;
+    float v = 0.f;
+    if (t < T) {
+      const float lo = smin[m], hi = smax[m];
+      v = __fsub_rn(__fmul_rn(__fsub_rn(mel[((long long)b * T + t) * M + m], lo) / __fsub_rn(hi, lo), 2.0f), 1.0f);
+    }
+    tile[j * (M + 1) + m] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < M * 64; i += 256) {
+    const int m = i >> 6, j = i & 63;
+    const int t = t0 + j;
+    if (t >= T) continue;
+    const long long o = ((long long)b * M + m) * T + t;
+    x[o] = __fadd_rn(__fmul_rn(ca, tile[j * (M + 1) + m]), __fmul_rn(cb, noise[o]));
+  }
+}
+
 // PLMS transfer x_pred = x + x_delta  (shallow_diffusion_tts.py:174-182); eps' = blend of eps history (:191-198)
 struct PlmsCoef {
   float a_t, a_prev;
@@ -364,6 +414,10 @@ struct bsg_diffnet {
   float* eps = nullptr;       // [B][M][T]
   float* eps_hist[4] = {nullptr, nullptr, nullptr, nullptr};  // PLMS history + x_pred scratch
   float* xpred = nullptr;
+  // live timing of the dominant kernel: one event pair around the L residual-layer launches of a forward
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
 };
 
 static int dev_alloc(float** p, size_t n) {
@@ -381,6 +435,7 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
                    &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
+  for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -579,9 +634,15 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
   TRY(conv1x1(h->w_in, h->b_in, x, h->xa, C, h->M, B, T, ACT_RELU, st));  // net.py:116-118
   float* cur = h->xa;
   float* nxt = h->xb;
+  const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+  if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   for (int l = 0; l < h->L; ++l) {
     TRY(launch_layer(h, l, cur, t_dev, t_uniform, nxt, h->skip, B, T, st));
     float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (prof) {
+    BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+    h->prof_used += 2;
   }
   TRY(conv1x1(h->w_skip, h->b_skip, h->skip, h->hid, C, C, B, T, ACT_RELU, st));   // net.py:127-128
   TRY(conv1x1(h->w_fin, h->b_fin, h->hid, eps, h->M, C, B, T, ACT_NONE, st));      // net.py:129
@@ -642,6 +703,49 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
                        noise ? noise + (long long)k * n : nullptr, c, n4, (unsigned long long)seed, (unsigned)(i + 1), quad0);
     BSG_LAUNCH_CHECK();
   }
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable) {
+  BSG_REQUIRE(h, "diffnet_profile: null handle");
+  if (enable && h->prof_ev.empty()) {
+    h->prof_ev.resize(2 * 4096);
+    for (hipEvent_t& e : h->prof_ev) BSG_HIP(hipEventCreate(&e));
+  }
+  h->prof_on = enable != 0;
+  h->prof_used = 0;
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_layer_launches) {
+  BSG_REQUIRE(h && layer_ms_total && n_layer_launches, "diffnet_profile_read: null argument");
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    BSG_HIP(hipEventSynchronize(h->prof_ev[i + 1]));
+    float ms = 0.f;
+    BSG_HIP(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+    total += ms;
+  }
+  *layer_ms_total = total;
+  *n_layer_launches = (int64_t)(h->prof_used / 2) * h->L;
+  return BSG_OK;
+}
+
+extern "C" int bsg_mel_finish(const float* x, const float* spec_min, const float* spec_max, const int64_t* mel2ph,
+                              float* mel_out, int32_t B, int32_t M, int32_t T, void* stream) {
+  BSG_REQUIRE(x && spec_min && spec_max && mel_out && B > 0 && M > 0 && M <= 512 && T > 0, "mel_finish: bad argument");
+  hipLaunchKernelGGL(mel_finish_kernel, dim3(cdiv(T, 64), B), dim3(256), (size_t)M * 65 * sizeof(float), (hipStream_t)stream, x,
+                     spec_min, spec_max, (const long long*)mel2ph, mel_out, M, T);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+extern "C" int bsg_mel_start(const float* fs2_mel, const float* spec_min, const float* spec_max, const float* noise,
+                             float sqrt_ac, float sqrt_1m_ac, float* x, int32_t B, int32_t M, int32_t T, void* stream) {
+  BSG_REQUIRE(fs2_mel && spec_min && spec_max && noise && x && B > 0 && M > 0 && M <= 512 && T > 0, "mel_start: bad argument");
+  hipLaunchKernelGGL(mel_start_kernel, dim3(cdiv(T, 64), B), dim3(256), (size_t)64 * (M + 1) * sizeof(float), (hipStream_t)stream,
+                     fs2_mel, spec_min, spec_max, noise, sqrt_ac, sqrt_1m_ac, x, M, T);
+  BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
 

@@ -149,6 +149,17 @@ class DiffNet(nn.Module):
                                                        _lib.stream_ptr()), 'bsg_diffnet_forward')
         return eps[:, None, :, :]
 
+    def profile(self, enable):
+        """Record hipEvent pairs around the residual-layer launches of every evaluation (bench.py roofline)."""
+        _lib.check(_lib.load().bsg_diffnet_profile(self.handle(), int(enable)), 'bsg_diffnet_profile')
+
+    def profile_read(self):
+        """-> (summed device ms of the recorded residual-layer chains, number of layer launches covered)."""
+        from ctypes import c_double, c_int64
+        ms, n = c_double(), c_int64()
+        _lib.check(_lib.load().bsg_diffnet_profile_read(self._h, byref(ms), byref(n)), 'bsg_diffnet_profile_read')
+        return ms.value, n.value
+
     @torch.no_grad()
     def residual_layer(self, layer, x, t, skip):
         """One fused ResidualBlock (net.py:66-78) — unit-test / micro-benchmark hook."""

@@ -153,10 +153,21 @@ class GaussianDiffusion(nn.Module):
     # ------------------------------------------------------------------ reference forward (:230-273)
     @torch.no_grad()
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
-                infer=False, noise=None, seed=None, row0=0, B_total=None, **kwargs):
+                infer=False, noise=None, seed=None, rows=None, **kwargs):
+        """Extensions over the reference signature: ``noise`` (supplied draws, parity mode), ``seed`` (Philox
+        key, default hparams['seed']) and ``rows`` (slice of the batch this process generates; outputs then
+        have len(rows) rows and reproduce the same rows of the unsharded call — SURVEY.md §8e)."""
         if not infer:
             raise NotImplementedError('training (p_losses) is outside the accelerated hot path (SURVEY.md §8)')
-        ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=False, infer=True, **kwargs)
+        B_total = txt_tokens.shape[0]
+        row0 = 0
+        if rows is not None:
+            row0, stop, stride = rows.indices(B_total)
+            assert stride == 1 and stop > row0, 'rows must be a contiguous non-empty slice'
+        ret = self.fs2(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, skip_decoder=False, infer=True,
+                       rows=rows, **kwargs)
+        if mel2ph is not None and rows is not None:
+            mel2ph = mel2ph[rows]
         cond = ret['decoder_inp'].transpose(1, 2).contiguous()
         ret['fs2_mel'] = ret['mel_out']
         B, H, T = cond.shape
@@ -165,21 +176,30 @@ class GaussianDiffusion(nn.Module):
         M = self.mel_bins
         if noise is not None:
             noise = noise.to(cond.device, torch.float32)
+            if rows is not None and noise.shape[1] == B_total:
+                noise = noise[:, rows]
             draw0, steps = noise[0][:, None].contiguous(), noise[1:]
         else:
             off = row0 * M * T
             draw0 = self.philox_normal((B, 1, M, T), cond.device, seed, 0, off)
             steps = None
+        lib = _lib.load()
+        smin, smax = self.spec_min.reshape(-1).contiguous(), self.spec_max.reshape(-1).contiguous()
         if hparams.get('gaussian_start'):
             x = draw0
         else:
-            fm = self.norm_spec(ret['mel_out']).transpose(1, 2)[:, None]
-            x = (self.sqrt_alphas_cumprod[t - 1] * fm + self.sqrt_one_minus_alphas_cumprod[t - 1] * draw0).contiguous()
+            _s, host = self._schedule()
+            x = torch.empty_like(draw0)
+            with torch.cuda.device(cond.device):
+                _lib.check(lib.bsg_mel_start(_lib.ptr(ret['mel_out'].contiguous()), _lib.ptr(smin), _lib.ptr(smax), _lib.ptr(draw0),
+                                             float(self.sqrt_alphas_cumprod[t - 1]), float(self.sqrt_one_minus_alphas_cumprod[t - 1]),
+                                             _lib.ptr(x), B, M, T, _lib.stream_ptr()), 'bsg_mel_start')
         x = self.sample(cond, x, noise=steps, seed=seed, row0=row0, B_total=B_total)
-        x = x[:, 0].transpose(1, 2)
-        out = self.denorm_spec(x)
-        if mel2ph is not None:
-            out = out * (mel2ph > 0).float()[:, :, None]
+        out = torch.empty(B, T, M, device=cond.device)
+        m2p = None if mel2ph is None else mel2ph.to(device=cond.device, dtype=torch.long).contiguous()
+        with torch.cuda.device(cond.device):
+            _lib.check(lib.bsg_mel_finish(_lib.ptr(x), _lib.ptr(smin), _lib.ptr(smax), _lib.ptr(m2p), _lib.ptr(out), B, M, T,
+                                          _lib.stream_ptr()), 'bsg_mel_finish')
         ret['mel_out'] = out
         return ret
 

@@ -264,8 +264,10 @@ class FastSpeech2MIDI(nn.Module):
 
     # ------------------------------------------------------------------ reference forward (fs2.py:94-197)
     @torch.no_grad()
-    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
-                skip_decoder=False, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, **kwargs):
+    def encode(self, txt_tokens, spk_embed, predict_dur=False, **kwargs):
+        """Token-level front: embeddings + ESM + FFT encoder (+ duration predictor)   (fs2.py:111-165).
+        ESM attends over the batch axis (common_layers.py:853), so a sharded run must call this with
+        the *whole* batch and slice rows afterwards."""
         lib = _lib.load()
         h = self.handle()
         dev = txt_tokens.device
@@ -274,46 +276,70 @@ class FastSpeech2MIDI(nn.Module):
         B, Tt = txt.shape
         if Tt > self._n_rel:
             raise _lib.BsgError(f'T_txt={Tt} exceeds the positional table ({self._n_rel})')
-        pitch_midi, lang, speechsing = i64(kwargs['pitch_midi']), i64(kwargs['lang']), i64(kwargs['speechsing'])
-        midi_dur = kwargs.get('midi_dur')
-        midi_dur = torch.zeros(B, Tt, device=dev) if midi_dur is None else midi_dur.to(dev, torch.float32).contiguous()
-        is_slur = kwargs.get('is_slur')
-        is_slur = torch.zeros(B, Tt, dtype=torch.long, device=dev) if is_slur is None else i64(is_slur)
         if kwargs.get('midi_dur') is None or kwargs.get('is_slur') is None:
             raise _lib.BsgError('midi_dur and is_slur are required (every BiSinger entry point passes them)')
+        pitch_midi, lang, is_slur = i64(kwargs['pitch_midi']), i64(kwargs['lang']), i64(kwargs['is_slur'])
+        midi_dur = kwargs['midi_dur'].to(dev, torch.float32).contiguous()
         spk = i64(spk_embed)
-        ret = {}
         enc_out = torch.empty(B, Tt, self.hidden_size, device=dev)
-        predict = mel2ph is None
-        dur_xs = torch.empty(B, Tt, device=dev) if predict else None
-        dur = torch.empty(B, Tt, dtype=torch.long, device=dev) if predict else None
+        dur_xs = torch.empty(B, Tt, device=dev) if predict_dur else None
+        dur = torch.empty(B, Tt, dtype=torch.long, device=dev) if predict_dur else None
         with torch.cuda.device(dev):
-            st = _lib.stream_ptr()
             _lib.check(lib.bsg_fs2midi_encode(h, _lib.ptr(txt), _lib.ptr(pitch_midi), _lib.ptr(midi_dur), _lib.ptr(is_slur),
                                               _lib.ptr(lang), _lib.ptr(spk), B, Tt, _lib.ptr(enc_out), _lib.ptr(dur_xs),
-                                              _lib.ptr(dur), st), 'bsg_fs2midi_encode')
-            if predict:
-                # the reference's one host sync: the output length is data dependent (tts_modules.py:182)
-                T = int((dur * (txt != 0)).sum(-1).max().item())
-                if T <= 0:
-                    raise _lib.BsgError('duration predictor produced an empty utterance')
-                mel2ph = torch.empty(B, T, dtype=torch.long, device=dev)
-                _lib.check(lib.bsg_length_regulator(_lib.ptr(dur), _lib.ptr(txt), _lib.ptr(mel2ph), B, Tt, T, st),
-                           'bsg_length_regulator')
-                ret['dur'] = dur_xs[:, :, None]
-                ret['dur_choice'] = dur
-            else:
-                mel2ph = i64(mel2ph)
-                # (the reference also evaluates the predictor here for the training loss; not needed to infer)
-            T = mel2ph.shape[1]
-            if T >= self._n_pos:
-                raise _lib.BsgError(f'T={T} exceeds the decoder position table ({self._n_pos})')
-            ret['mel2ph'] = mel2ph
-            decoder_inp = torch.empty(B, T, self.hidden_size, device=dev)
-            mel_out = None if skip_decoder else torch.empty(B, T, self.out_dims, device=dev)
-            _lib.check(lib.bsg_fs2midi_decode(h, _lib.ptr(enc_out), _lib.ptr(mel2ph), _lib.ptr(spk), _lib.ptr(speechsing),
-                                              B, Tt, T, _lib.ptr(decoder_inp), _lib.ptr(mel_out), st), 'bsg_fs2midi_decode')
-        ret['decoder_inp'] = decoder_inp
+                                              _lib.ptr(dur), _lib.stream_ptr()), 'bsg_fs2midi_encode')
+        return dict(enc_out=enc_out, txt=txt, spk=spk, dur_xs=dur_xs, dur=dur)
+
+    @torch.no_grad()
+    def regulate(self, enc):
+        """LengthRegulator on the predicted durations (tts_modules.py:161-191); one host sync, as in the
+        reference (the output length is data dependent, :182)."""
+        dur, txt = enc['dur'], enc['txt']
+        B, Tt = txt.shape
+        T = int((dur * (txt != 0)).sum(-1).max().item())
+        if T <= 0:
+            raise _lib.BsgError('duration predictor produced an empty utterance')
+        mel2ph = torch.empty(B, T, dtype=torch.long, device=txt.device)
+        with torch.cuda.device(txt.device):
+            _lib.check(_lib.load().bsg_length_regulator(_lib.ptr(dur), _lib.ptr(txt), _lib.ptr(mel2ph), B, Tt, T,
+                                                        _lib.stream_ptr()), 'bsg_length_regulator')
+        return mel2ph
+
+    @torch.no_grad()
+    def decode(self, enc_out, mel2ph, spk, speechsing, skip_decoder=False):
+        """Frame-level part: gather by mel2ph, +spk +style, mask; FFT decoder + mel_out   (fs2.py:166-195)."""
+        dev = enc_out.device
+        h = self.handle()
+        B, Tt, _ = enc_out.shape
+        mel2ph = mel2ph.to(device=dev, dtype=torch.long).contiguous()
+        T = mel2ph.shape[1]
+        if T >= self._n_pos:
+            raise _lib.BsgError(f'T={T} exceeds the decoder position table ({self._n_pos})')
+        speechsing = speechsing.to(device=dev, dtype=torch.long).contiguous()
+        decoder_inp = torch.empty(B, T, self.hidden_size, device=dev)
+        mel_out = None if skip_decoder else torch.empty(B, T, self.out_dims, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().bsg_fs2midi_decode(h, _lib.ptr(enc_out.contiguous()), _lib.ptr(mel2ph), _lib.ptr(spk.contiguous()),
+                                                      _lib.ptr(speechsing), B, Tt, T, _lib.ptr(decoder_inp), _lib.ptr(mel_out),
+                                                      _lib.stream_ptr()), 'bsg_fs2midi_decode')
+        return decoder_inp, mel_out
+
+    def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
+                skip_decoder=False, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, rows=None, **kwargs):
+        """``rows`` (slice, extension): decode only these batch rows — the token-level front still sees the whole
+        batch, which is what keeps a sharded run identical to the unsharded reference."""
+        ret = {}
+        enc = self.encode(txt_tokens, spk_embed, predict_dur=mel2ph is None, **kwargs)
+        if mel2ph is None:
+            mel2ph = self.regulate(enc)
+            ret['dur'] = enc['dur_xs'][:, :, None]
+            ret['dur_choice'] = enc['dur']
+        # (with mel2ph given the reference also runs the predictor for its training loss; inference does not use it)
+        enc_out, spk, speechsing = enc['enc_out'], enc['spk'], kwargs['speechsing']
+        if rows is not None:
+            enc_out, spk, speechsing, mel2ph = enc_out[rows], spk[rows], speechsing[rows], mel2ph[rows]
+        ret['mel2ph'] = mel2ph
+        ret['decoder_inp'], mel_out = self.decode(enc_out, mel2ph, spk, speechsing, skip_decoder)
         if not skip_decoder:
             ret['mel_out'] = mel_out
         return ret

@@ -115,6 +115,21 @@ int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float
  * timestep i uses stream_id i+1).  n and offset must be multiples of 4. */
 int bsg_philox_normal(float* x, int64_t n, uint64_t seed, uint32_t stream_id, uint64_t offset, void* stream);
 
+/* Glue of GaussianDiffusion.forward around the loop (shallow_diffusion_tts.py:244-272), all [B,M,T] <-> [B,T,M]:
+ *   bsg_mel_start : x = sqrt_ac * norm_spec(fs2_mel)^T + sqrt_1m_ac * noise      (q_sample at t = K_step-1, :249-252)
+ *   bsg_mel_finish: mel_out = denorm_spec(x^T) * (mel2ph > 0)   (mel2ph NULL: no mask, the non-singing branch :271-272)
+ * spec_min / spec_max: device [M] (the module's buffers). */
+int bsg_mel_start(const float* fs2_mel, const float* spec_min, const float* spec_max, const float* noise,
+                  float sqrt_ac, float sqrt_1m_ac, float* x, int32_t B, int32_t M, int32_t T, void* stream);
+int bsg_mel_finish(const float* x, const float* spec_min, const float* spec_max, const int64_t* mel2ph,
+                   float* mel_out, int32_t B, int32_t M, int32_t T, void* stream);
+
+/* Live timing of the dominant kernel (bench.py's roofline): while enabled, every DiffNet evaluation records
+ * a hipEvent pair around its L fused residual-layer launches on the launch stream.  profile_read waits for the
+ * recorded events and returns the summed device time and the number of layer launches they cover. */
+int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable);
+int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_layer_launches);
+
 /* PLMS / PNDM loop A (:258-264, p_sample_plms :168-201): for i in reversed(range(0,K_step,interval)).
  * Batched semantics = element-wise clamp of t-interval (the reference raises for B>1, :189). */
 int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, int32_t K_step, int32_t interval,

@@ -164,7 +164,7 @@ def length_regulator(dur, dur_padding):
 
 
 # ----------------------------------------------------------------------------- model
-def fs2_forward(sd, inp, prefix='fs2.', hp=None, skip_decoder=False, dtype=torch.float32):
+def fs2_forward(sd, inp, prefix='fs2.', hp=None, skip_decoder=False, dtype=torch.float32, rows=None):
     """FastSpeech2MIDI.forward(infer=True) with use_spk_id, no pitch/energy embed
     (diffsinger_midi/fs2.py:94-197).  ``inp``: dict of tensors (see bisinger_amd/synth.py)."""
     hp = {**DEFAULT_HP, **(hp or {})}
@@ -197,6 +197,10 @@ def fs2_forward(sd, inp, prefix='fs2.', hp=None, skip_decoder=False, dtype=torch
         ret['dur'] = xs
         ret['dur_choice'] = dur
         mel2ph = length_regulator(dur, txt == 0)
+    if rows is not None:
+        # sharded evaluation: the token-level front above saw the whole batch (ESM couples
+        # rows); everything frame-level is per-row, so only this rank's rows continue
+        enc, spk, style, mel2ph = enc[rows], spk[rows], style[rows], mel2ph[rows]
     ret['mel2ph'] = mel2ph
     dec_in = F.pad(enc, [0, 0, 1, 0])
     dec_in = torch.gather(dec_in, 1, mel2ph[..., None].repeat([1, 1, H]))

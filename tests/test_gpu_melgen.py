@@ -67,3 +67,21 @@ def test_melgen_plms_b1(model, gold):
     finally:
         hparams['pndm_speedup'] = 0
     assert maxabs(out['mel_out'], g['plms5.mel_out']) <= 1e-3
+
+
+def test_rows_shard_reproduces_unsharded_rows(model):
+    """Philox (bench) mode: a rank generating rows [2,4) of a batch of 4 gets the same mels as the unsharded call."""
+    inp = synth.synth_inputs(4, 10, 48, seed=8, ragged=True)
+    d = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
+    full = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], infer=True, seed=5, **kw)['mel_out']
+    part = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], infer=True, seed=5, rows=slice(2, 4), **kw)['mel_out']
+    assert part.shape == (2, 48, 80)
+    assert maxabs(part, full[2:4]) <= 1e-5
+    other = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], infer=True, seed=6, **kw)['mel_out']
+    assert maxabs(other, full) > 1e-2      # the seed matters
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
