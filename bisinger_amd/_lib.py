@@ -26,6 +26,13 @@ class Fs2Cfg(Structure):
                                        'dur_kernel', 'spk_rows', 'esm_heads', 'n_pos', 'n_rel')]
 
 
+class HifiganCfg(Structure):
+    _fields_ = [('n_mel', c_int32), ('upsample_initial_channel', c_int32), ('n_ups', c_int32),
+                ('upsample_rates', c_int32 * 8), ('upsample_kernel_sizes', c_int32 * 8), ('n_kernels', c_int32),
+                ('resblock_kernel_sizes', c_int32 * 8), ('n_dil', c_int32), ('resblock_dilations', (c_int32 * 4) * 8),
+                ('weight_norm', c_int32)]
+
+
 class Schedule(Structure):
     _fields_ = [('num_timesteps', c_int32),
                 ('sqrt_recip_alphas_cumprod', POINTER(c_float)), ('sqrt_recipm1_alphas_cumprod', POINTER(c_float)),
@@ -58,6 +65,11 @@ _SIGS = {
     'bsg_length_regulator': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_fs2midi_decode': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_void_p]),
+    'bsg_hifigan_n_weights': (c_int32, [POINTER(HifiganCfg)]),
+    'bsg_hifigan_create': (c_int32, [POINTER(c_void_p), POINTER(HifiganCfg), POINTER(c_void_p), c_int32, c_void_p]),
+    'bsg_hifigan_destroy': (None, [c_void_p]),
+    'bsg_hifigan_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_weight_norm_fold': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_gemm_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),
 }

@@ -1,0 +1,382 @@
+// HiFi-GAN generator forward (mel -> waveform) on gfx950.
+//
+// Reference semantics: /root/reference/train_bisinger/modules/hifigan/hifigan.py
+//   ResBlock1.forward :54-61, HifiGanGenerator.__init__ :105-142, forward :144-173, remove_weight_norm :175-182.
+//
+// The generator is 72 small-channel convolutions (128 -> 8 channels while the time axis grows 256x):
+// arithmetic intensity ~10 FLOP/B, i.e. HBM/LDS-bound elementwise-like work, not matrix work — and fp32
+// MFMA has no rate advantage over fp32 VALU on gfx950 anyway (both 256 FLOP/clk/CU).  So the convs are
+// direct VALU kernels on the native [B,C,T] layout:
+//   * a wave's 64 lanes own 64 consecutive samples (x TT strided repeats): every HBM/LDS access of a
+//     wave is one contiguous 256-B row segment;
+//   * input channels are staged through LDS in chunks ([CI_CHUNK][tile + halo], input LeakyReLU applied
+//     while staging), shared by the workgroup's waves;
+//   * the CO_BLK output channels a workgroup produces are wave-uniform, so the weights are scalar loads
+//     (SGPR operands of v_fma): the inner loop is one ds_read_b32 per CO_BLK FMAs;
+//   * bias, residual add, the MRF sum / num_kernels and tanh are fused epilogues.
+#include <math.h>
+
+#include <vector>
+
+#include "bsg_common.h"
+
+namespace bsg {
+namespace {
+
+constexpr int TT = 4;           // samples per lane (stride 64)
+constexpr int TILE = 256 * TT;  // samples per workgroup
+constexpr int CI_CHUNK = 8;
+
+struct ConvArgs {
+  const float* x;      // [B][Cin][L]
+  const float* w;      // [Cout][Cin][K]
+  const float* bias;   // [Cout]
+  float* y;            // [B][Cout][L]
+  const float* res;    // optional [B][Cout][L]: y = conv + res
+  const float* acc_in; // optional [B][Cout][L]: y = acc_in + y   (MRF running sum, hifigan.py:161-166)
+  float out_div;       // y /= out_div (num_kernels on the last resblock, :167)
+  float in_slope;      // LeakyReLU slope applied to the input (1 = identity)
+  int out_tanh;
+  int Cin, Cout, L, dil, pad;
+};
+
+template <int K, int CO_BLK>
+__global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
+  extern __shared__ float xs[];   // [CI_CHUNK][TILE + (K-1)*dil]
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * TILE;
+  const int co0 = blockIdx.y * CO_BLK;
+  const int b = blockIdx.z;
+  const int span = TILE + (K - 1) * a.dil;
+  const float* __restrict__ xb = a.x + (long long)b * a.Cin * a.L;
+
+  float acc[CO_BLK][TT];
+#pragma unroll
+  for (int c = 0; c < CO_BLK; ++c) {
+    const float bv = (co0 + c < a.Cout) ? a.bias[co0 + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[c][j] = bv;
+  }
+
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CHUNK) {
+    __syncthreads();
+    for (int idx = tid; idx < CI_CHUNK * span; idx += 256) {
+      const int ci = idx / span, j = idx - ci * span;
+      const int t = t0 - a.pad + j;
+      float v = 0.f;
+      if (ci0 + ci < a.Cin && t >= 0 && t < a.L) {
+        v = xb[(long long)(ci0 + ci) * a.L + t];
+        v = v > 0.f ? v : v * a.in_slope;
+      }
+      xs[idx] = v;
+    }
+    __syncthreads();
+    const int nci = (a.Cin - ci0) < CI_CHUNK ? (a.Cin - ci0) : CI_CHUNK;
+#pragma unroll 1
+    for (int ci = 0; ci < nci; ++ci) {
+      const float* __restrict__ wp = a.w + ((long long)co0 * a.Cin + (ci0 + ci)) * K;   // wave-uniform -> scalar loads
+      const float* __restrict__ xr = xs + ci * span + tid;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float xv[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) xv[j] = xr[k * a.dil + 256 * j];
+#pragma unroll
+        for (int c = 0; c < CO_BLK; ++c) {
+          const float wv = (co0 + c < a.Cout) ? wp[(long long)c * a.Cin * K + k] : 0.f;
+#pragma unroll
+          for (int j = 0; j < TT; ++j) acc[c][j] = fmaf(wv, xv[j], acc[c][j]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int c = 0; c < CO_BLK; ++c) {
+    const long long rowo = ((long long)b * a.Cout + co0 + c) * a.L;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+      const int t = t0 + tid + 256 * j;
+      if (t >= a.L || co0 + c >= a.Cout) continue;
+      float v = acc[c][j];
+      if (a.res) v += a.res[rowo + t];
+      if (a.acc_in) v = a.acc_in[rowo + t] + v;
+      if (a.out_div != 1.0f) v = v / a.out_div;
+      if (a.out_tanh) v = tanhf(v);
+      a.y[rowo + t] = v;
+    }
+  }
+}
+
+// ConvTranspose1d(Cin -> Cout, K, stride u, padding p) on LeakyReLU(x): y[co][t'] = b[co] + sum over (ci, k, i) with
+// t' = i*u - p + k.  ~3 % of the generator's FLOPs: one thread per output sample, CO_BLK channels, taps gathered.
+struct ConvTArgs {
+  const float* x;     // [B][Cin][Lin]
+  const float* w;     // [Cin][Cout][K]
+  const float* bias;
+  float* y;           // [B][Cout][Lin*u]
+  float in_slope;
+  int Cin, Cout, Lin, K, u, p;
+};
+template <int CO_BLK>
+__global__ __launch_bounds__(256) void conv_transpose1d_kernel(ConvTArgs a) {
+  const int Lout = a.Lin * a.u;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int co0 = blockIdx.y * CO_BLK;
+  const int b = blockIdx.z;
+  if (t >= Lout) return;
+  float acc[CO_BLK];
+#pragma unroll
+  for (int c = 0; c < CO_BLK; ++c) acc[c] = (co0 + c < a.Cout) ? a.bias[co0 + c] : 0.f;
+  const int tp = t + a.p;
+  const int r = tp % a.u, q = tp / a.u;
+  const float* __restrict__ xb = a.x + (long long)b * a.Cin * a.Lin;
+  for (int k = r; k < a.K; k += a.u) {
+    const int i = q - (k - r) / a.u;
+    if (i < 0 || i >= a.Lin) continue;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+      float xv = xb[(long long)ci * a.Lin + i];
+      xv = xv > 0.f ? xv : xv * a.in_slope;
+      const float* __restrict__ wp = a.w + ((long long)ci * a.Cout + co0) * a.K + k;
+#pragma unroll
+      for (int c = 0; c < CO_BLK; ++c)
+        if (co0 + c < a.Cout) acc[c] = fmaf(wp[(long long)c * a.K], xv, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CO_BLK; ++c)
+    if (co0 + c < a.Cout) a.y[((long long)b * a.Cout + co0 + c) * Lout + t] = acc[c];
+}
+
+// weight = g * v / ||v||, norm over every dim but 0  (torch.nn.utils.weight_norm, dim = 0).  One wave per slice.
+__global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v, float* __restrict__ w,
+                                        int dim0, int inner) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= dim0) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int i = lane; i < inner; i += 64) {
+    const float x = v[(long long)row * inner + i];
+    s += x * x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float scale = g[row] / sqrtf(s);
+  for (int i = lane; i < inner; i += 64) w[(long long)row * inner + i] = v[(long long)row * inner + i] * scale;
+}
+
+template <int K>
+int launch_conv_k(const ConvArgs& a, int B, hipStream_t st) {
+  const size_t lds = (size_t)CI_CHUNK * (TILE + (K - 1) * a.dil) * sizeof(float);
+  if (a.Cout >= 16) {
+    dim3 grid(cdiv(a.L, TILE), cdiv(a.Cout, 16), B);
+    hipLaunchKernelGGL((conv1d_kernel<K, 16>), grid, dim3(256), lds, st, a);
+  } else {
+    dim3 grid(cdiv(a.L, TILE), cdiv(a.Cout, 8), B);
+    hipLaunchKernelGGL((conv1d_kernel<K, 8>), grid, dim3(256), lds, st, a);
+  }
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+int launch_conv(const ConvArgs& a, int K, int B, hipStream_t st) {
+  switch (K) {
+    case 3: return launch_conv_k<3>(a, B, st);
+    case 7: return launch_conv_k<7>(a, B, st);
+    case 11: return launch_conv_k<11>(a, B, st);
+    default: set_error("hifigan: conv kernel size %d not built (3, 7, 11)", K); return BSG_EINVAL;
+  }
+}
+
+}  // namespace
+}  // namespace bsg
+
+using namespace bsg;
+
+#define TRY(expr)                  \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != BSG_OK) return _rc; \
+  } while (0)
+
+struct ConvW {
+  float* w = nullptr;
+  float* b = nullptr;
+  int cout = 0, cin = 0, k = 0;
+};
+
+struct bsg_hifigan {
+  bsg_hifigan_cfg cfg;
+  std::vector<float*> owned;
+  ConvW pre, post;
+  std::vector<ConvW> ups;                 // weight [Cin][Cout][K]
+  std::vector<ConvW> rb1, rb2;            // [n_ups * n_kernels * n_dil]
+  size_t cap = 0;                         // elements of one stage buffer
+  float* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
+  if (!h) return;
+  for (float* p : h->owned) (void)hipFree(p);
+  for (float* p : h->buf)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+static int hg_alloc(bsg_hifigan* h, float** p, size_t n) {
+  BSG_HIP(hipMalloc((void**)p, n * sizeof(float)));
+  h->owned.push_back(*p);
+  return BSG_OK;
+}
+
+// consumes (bias, weight) or (bias, weight_g, weight_v) from the state_dict-ordered pointer list
+static int take_conv(bsg_hifigan* h, ConvW& c, const void* const*& w, int dim0, int inner, hipStream_t st) {
+  const size_t n = (size_t)dim0 * inner;
+  TRY(hg_alloc(h, &c.w, n));
+  const void* bias = *w++;
+  if (h->cfg.weight_norm) {
+    const float* g = (const float*)*w++;
+    const float* v = (const float*)*w++;
+    hipLaunchKernelGGL(weight_norm_fold_kernel, dim3(cdiv(dim0, 4)), dim3(256), 0, st, g, v, c.w, dim0, inner);
+    BSG_LAUNCH_CHECK();
+  } else {
+    BSG_HIP(hipMemcpyAsync(c.w, *w++, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  TRY(hg_alloc(h, &c.b, c.cout));
+  BSG_HIP(hipMemcpyAsync(c.b, bias, c.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return BSG_OK;
+}
+
+extern "C" int bsg_hifigan_n_weights(const bsg_hifigan_cfg* c) {
+  const int convs = 2 + c->n_ups + 2 * c->n_ups * c->n_kernels * c->n_dil;
+  return convs * (c->weight_norm ? 3 : 2);
+}
+
+extern "C" int bsg_weight_norm_fold(const float* g, const float* v, float* w, int32_t dim0, int32_t inner, void* stream) {
+  BSG_REQUIRE(g && v && w && dim0 > 0 && inner > 0, "weight_norm_fold: bad argument");
+  hipLaunchKernelGGL(weight_norm_fold_kernel, dim3(cdiv(dim0, 4)), dim3(256), 0, (hipStream_t)stream, g, v, w, dim0, inner);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg, const void* const* dev_weights,
+                                  int32_t n_weights, void* stream) {
+  BSG_REQUIRE(out && cfg && dev_weights, "hifigan_create: null argument");
+  BSG_REQUIRE(cfg->n_ups > 0 && cfg->n_ups <= 8 && cfg->n_kernels > 0 && cfg->n_kernels <= 8 && cfg->n_dil > 0 && cfg->n_dil <= 4,
+              "hifigan_create: bad stage counts");
+  BSG_REQUIRE(cfg->n_mel > 0 && cfg->upsample_initial_channel >= (1 << cfg->n_ups), "hifigan_create: bad channel config");
+  BSG_REQUIRE(n_weights == bsg_hifigan_n_weights(cfg), "hifigan_create: expected %d weight tensors, got %d",
+              bsg_hifigan_n_weights(cfg), n_weights);
+  for (int i = 0; i < cfg->n_ups; ++i) {
+    const int k = cfg->upsample_kernel_sizes[i], u = cfg->upsample_rates[i];
+    BSG_REQUIRE(u > 0 && k >= u && (k - u) % 2 == 0, "hifigan_create: upsample stage %d (k=%d, u=%d) unsupported", i, k, u);
+  }
+  for (int j = 0; j < cfg->n_kernels; ++j) {
+    const int k = cfg->resblock_kernel_sizes[j];
+    BSG_REQUIRE(k == 3 || k == 7 || k == 11, "hifigan_create: resblock kernel %d not built (3, 7, 11)", k);
+    for (int m = 0; m < cfg->n_dil; ++m)
+      BSG_REQUIRE(cfg->resblock_dilations[j][m] >= 1 && cfg->resblock_dilations[j][m] <= 16, "hifigan_create: dilation out of range");
+  }
+  for (int i = 0; i < n_weights; ++i) BSG_REQUIRE(dev_weights[i] != nullptr, "hifigan_create: weight %d is null", i);
+  hipStream_t st = (hipStream_t)stream;
+  bsg_hifigan* h = new bsg_hifigan();
+  h->cfg = *cfg;
+  const void* const* w = dev_weights;
+  int rc = BSG_OK;
+  auto fail = [&](int code) { bsg_hifigan_destroy(h); return code; };
+  const int C0 = cfg->upsample_initial_channel;
+  h->pre.cout = C0; h->pre.cin = cfg->n_mel; h->pre.k = 7;
+  if ((rc = take_conv(h, h->pre, w, C0, cfg->n_mel * 7, st)) != BSG_OK) return fail(rc);
+  h->ups.resize(cfg->n_ups);
+  for (int i = 0; i < cfg->n_ups; ++i) {
+    ConvW& c = h->ups[i];
+    c.cin = C0 >> i; c.cout = C0 >> (i + 1); c.k = cfg->upsample_kernel_sizes[i];
+    if ((rc = take_conv(h, c, w, c.cin, c.cout * c.k, st)) != BSG_OK) return fail(rc);   // weight [Cin][Cout][K], g over dim 0 = Cin
+  }
+  const int nrb = cfg->n_ups * cfg->n_kernels;
+  h->rb1.resize((size_t)nrb * cfg->n_dil);
+  h->rb2.resize((size_t)nrb * cfg->n_dil);
+  for (int r = 0; r < nrb; ++r) {
+    const int ch = C0 >> (r / cfg->n_kernels + 1);
+    const int k = cfg->resblock_kernel_sizes[r % cfg->n_kernels];
+    for (int pass = 0; pass < 2; ++pass)
+      for (int m = 0; m < cfg->n_dil; ++m) {
+        ConvW& c = (pass == 0 ? h->rb1 : h->rb2)[(size_t)r * cfg->n_dil + m];
+        c.cin = c.cout = ch; c.k = k;
+        if ((rc = take_conv(h, c, w, ch, ch * k, st)) != BSG_OK) return fail(rc);
+      }
+  }
+  h->post.cout = 1; h->post.cin = C0 >> cfg->n_ups; h->post.k = 7;
+  if ((rc = take_conv(h, h->post, w, 1, h->post.cin * 7, st)) != BSG_OK) return fail(rc);
+  if (hipStreamSynchronize(st) != hipSuccess) { set_error("hifigan_create: stream sync failed"); return fail(BSG_EHIP); }
+  *out = h;
+  return BSG_OK;
+}
+
+static int run_conv(const ConvW& c, const float* x, float* y, int B, int L, int dil, float in_slope, const float* res,
+                    const float* acc_in, float out_div, int out_tanh, hipStream_t st) {
+  ConvArgs a{};
+  a.x = x; a.w = c.w; a.bias = c.b; a.y = y; a.res = res; a.acc_in = acc_in; a.out_div = out_div; a.in_slope = in_slope;
+  a.out_tanh = out_tanh; a.Cin = c.cin; a.Cout = c.cout; a.L = L; a.dil = dil; a.pad = (c.k * dil - dil) / 2;
+  return launch_conv(a, c.k, B, st);
+}
+
+extern "C" int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream) {
+  BSG_REQUIRE(h && mel && wav && B > 0 && T > 0, "hifigan_forward: bad argument");
+  BSG_REQUIRE(B <= 65535, "hifigan_forward: B=%d > 65535", B);
+  hipStream_t st = (hipStream_t)stream;
+  const bsg_hifigan_cfg& c = h->cfg;
+  // largest stage tensor: channels halve while length grows by u_i
+  size_t need = (size_t)B * c.upsample_initial_channel * T;
+  {
+    long long L = T;
+    for (int i = 0; i < c.n_ups; ++i) {
+      L *= c.upsample_rates[i];
+      const size_t n = (size_t)B * (c.upsample_initial_channel >> (i + 1)) * L;
+      if (n > need) need = n;
+    }
+    BSG_REQUIRE(L < (1LL << 31) / 4, "hifigan_forward: output length %lld too large", L);
+  }
+  if (need > h->cap) {
+    BSG_HIP(hipStreamSynchronize(st));
+    for (float*& p : h->buf) { if (p) (void)hipFree(p); p = nullptr; }
+    h->cap = 0;
+    for (float*& p : h->buf) BSG_HIP(hipMalloc((void**)&p, need * sizeof(float)));
+    h->cap = need;
+  }
+  float *x = h->buf[0], *ya = h->buf[1], *yb = h->buf[2], *tmp = h->buf[3], *xs = h->buf[4];
+  const float slope = 0.1f;   // LRELU_SLOPE, hifigan.py:11
+  TRY(run_conv(h->pre, mel, x, B, T, 1, 1.0f, nullptr, nullptr, 1.0f, 0, st));            // conv_pre :150
+  int L = T;
+  float* cur = x;
+  for (int i = 0; i < c.n_ups; ++i) {
+    const ConvW& up = h->ups[i];
+    ConvTArgs t{};
+    t.x = cur; t.w = up.w; t.bias = up.b; t.y = (cur == x ? xs : x); t.in_slope = slope; t.Cin = up.cin; t.Cout = up.cout;
+    t.Lin = L; t.K = up.k; t.u = c.upsample_rates[i]; t.p = (up.k - c.upsample_rates[i]) / 2;
+    const int Lout = L * t.u;
+    if (up.cout >= 16) hipLaunchKernelGGL(conv_transpose1d_kernel<16>, dim3(cdiv(Lout, 256), cdiv(up.cout, 16), B), dim3(256), 0, st, t);
+    else hipLaunchKernelGGL(conv_transpose1d_kernel<8>, dim3(cdiv(Lout, 256), cdiv(up.cout, 8), B), dim3(256), 0, st, t);
+    BSG_LAUNCH_CHECK();
+    float* xin = t.y;                       // stage input (after upsampling)
+    float* sum = (xin == x ? xs : x);       // MRF running sum / stage output
+    L = Lout;
+    for (int j = 0; j < c.n_kernels; ++j) {
+      const int r = i * c.n_kernels + j;
+      const float* y = xin;
+      for (int m = 0; m < c.n_dil; ++m) {
+        const bool last = m == c.n_dil - 1;
+        const ConvW& c1 = h->rb1[(size_t)r * c.n_dil + m];
+        const ConvW& c2 = h->rb2[(size_t)r * c.n_dil + m];
+        TRY(run_conv(c1, y, tmp, B, L, c.resblock_dilations[j][m], slope, nullptr, nullptr, 1.0f, 0, st));     // :56-57
+        float* dst = last ? sum : (y == ya ? yb : ya);
+        TRY(run_conv(c2, tmp, dst, B, L, 1, slope, y, (last && j > 0) ? sum : nullptr,
+                     (last && j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f, 0, st));                     // :58-60, :161-167
+        y = dst;
+      }
+    }
+    cur = sum;
+  }
+  TRY(run_conv(h->post, cur, wav, B, L, 1, 0.01f, nullptr, nullptr, 1.0f, 1, st));          // :169-171 (default slope 0.01)
+  return BSG_OK;
+}

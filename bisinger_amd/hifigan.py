@@ -1,0 +1,177 @@
+"""``HifiGanGenerator`` — drop-in for modules/hifigan/hifigan.py:104-182 (generator forward only) on HIP kernels.
+
+Constructed like the reference (``HifiGanGenerator(h)`` with ``h`` = the vocoder config dict); parameters are
+registered in the checkpoint layout (``bias, weight_g, weight_v`` per conv) so that
+``load_state_dict(ckpt['state_dict']['model_gen'], strict=True)`` followed by ``remove_weight_norm()`` works as in
+vocoders/hifigan.py:27-29; an already folded ``weight`` layout loads too.  Discriminators / GAN losses
+(hifigan.py:185-369) are training-only and out of scope.
+"""
+from ctypes import POINTER, byref, c_void_p, cast
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+LRELU_SLOPE = 0.1
+
+
+class _WNConv(nn.Module):
+    """Parameter holder for one weight-normed Conv1d / ConvTranspose1d (torch's weight_norm, dim=0)."""
+
+    def __init__(self, weight_shape, n_bias):
+        super().__init__()
+        self.weight_shape = tuple(weight_shape)
+        self.bias = nn.Parameter(torch.zeros(n_bias))
+        self.weight_g = nn.Parameter(torch.ones(weight_shape[0], *([1] * (len(weight_shape) - 1))))
+        self.weight_v = nn.Parameter(torch.empty(*weight_shape).normal_(0.0, 0.01))
+
+    @property
+    def folded(self):
+        return 'weight' in self._parameters
+
+    def fold(self):
+        """remove_weight_norm: weight = g * v / ||v|| (computed by the library on the GPU, by torch on the CPU)."""
+        if self.folded:
+            return
+        g, v = self.weight_g.detach(), self.weight_v.detach()
+        if v.is_cuda:
+            w = torch.empty_like(v)
+            with torch.cuda.device(v.device):
+                _lib.check(_lib.load().bsg_weight_norm_fold(_lib.ptr(g.contiguous()), _lib.ptr(v.contiguous()), _lib.ptr(w),
+                                                            v.shape[0], v[0].numel(), _lib.stream_ptr()), 'bsg_weight_norm_fold')
+        else:  # host-side model surgery before .cuda(); not on the inference path
+            w = v * (g / v.reshape(v.shape[0], -1).norm(dim=1).reshape(g.shape))
+        del self._parameters['weight_g'], self._parameters['weight_v']
+        self.register_parameter('weight', nn.Parameter(w))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kw):
+        # accept the other layout than the one currently registered
+        if prefix + 'weight' in state_dict and not self.folded:
+            del self._parameters['weight_g'], self._parameters['weight_v']
+            self.register_parameter('weight', nn.Parameter(torch.empty(self.weight_shape, device=self.bias.device)))
+        elif prefix + 'weight_v' in state_dict and self.folded:
+            dev = self.bias.device
+            del self._parameters['weight']
+            self.register_parameter('weight_g', nn.Parameter(torch.ones(self.weight_shape[0], *([1] * (len(self.weight_shape) - 1)), device=dev)))
+            self.register_parameter('weight_v', nn.Parameter(torch.empty(self.weight_shape, device=dev)))
+        super()._load_from_state_dict(state_dict, prefix, *args, **kw)
+
+
+class ResBlock1(nn.Module):
+    """hifigan.py:30-52 (parameters only)."""
+
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.convs1 = nn.ModuleList([_WNConv((channels, channels, kernel_size), channels) for _ in dilation])
+        self.convs2 = nn.ModuleList([_WNConv((channels, channels, kernel_size), channels) for _ in dilation])
+
+    def remove_weight_norm(self):
+        for c in list(self.convs1) + list(self.convs2):
+            c.fold()
+
+
+class HifiGanGenerator(nn.Module):
+    def __init__(self, h, c_out=1):
+        super().__init__()
+        self.h = h
+        if h.get('use_pitch_embed'):
+            raise NotImplementedError('NSF source (use_pitch_embed) is SURVEY.md §8 row f2: not built')
+        if str(h['resblock']) != '1':
+            raise NotImplementedError("only resblock: '1' (TB/configs/tts/hifigan.yaml:3) is built")
+        assert c_out == 1
+        self.num_kernels = len(h['resblock_kernel_sizes'])
+        self.num_upsamples = len(h['upsample_rates'])
+        C0 = h['upsample_initial_channel']
+        self.conv_pre = _WNConv((C0, 80, 7), C0)
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+            c_cur = C0 // (2 ** (i + 1))
+            self.ups.append(_WNConv((c_cur * 2, c_cur, k), c_cur))      # ConvTranspose1d weight [Cin, Cout, K]
+        self.resblocks = nn.ModuleList()
+        ch = C0
+        for i in range(len(self.ups)):
+            ch = C0 // (2 ** (i + 1))
+            for k, d in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
+                self.resblocks.append(ResBlock1(h, ch, k, d))
+        self.conv_post = _WNConv((c_out, ch, 7), c_out)
+        self._h = None
+        self._h_key = None
+
+    def remove_weight_norm(self):
+        print('Removing weight norm...')
+        for l in self.ups:
+            l.fold()
+        for l in self.resblocks:
+            l.remove_weight_norm()
+        self.conv_pre.fold()
+        self.conv_post.fold()
+
+    # ------------------------------------------------------------------ handle
+    def _weights(self):
+        return list(self.state_dict(keep_vars=True).values())
+
+    def _key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
+
+    def handle(self):
+        key = self._key()
+        if self._h is not None and key == self._h_key:
+            return self._h
+        self.release()
+        ws = [p.detach() for p in self._weights()]
+        for p in ws:
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.BsgError('HifiGanGenerator parameters must be contiguous float32 on the GPU; there is no CPU path')
+        states = {c.folded for c in self.modules() if isinstance(c, _WNConv)}
+        if len(states) != 1:
+            raise _lib.BsgError('mixed weight-norm / folded layers')
+        h = self.h
+        cfg = _lib.HifiganCfg()
+        cfg.n_mel, cfg.upsample_initial_channel, cfg.n_ups = 80, h['upsample_initial_channel'], self.num_upsamples
+        for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
+            cfg.upsample_rates[i], cfg.upsample_kernel_sizes[i] = u, k
+        cfg.n_kernels = self.num_kernels
+        cfg.n_dil = len(h['resblock_dilation_sizes'][0])
+        for j, (k, d) in enumerate(zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes'])):
+            cfg.resblock_kernel_sizes[j] = k
+            assert len(d) == cfg.n_dil
+            for m, dd in enumerate(d):
+                cfg.resblock_dilations[j][m] = dd
+        cfg.weight_norm = 0 if states.pop() else 1
+        lib = _lib.load()
+        assert lib.bsg_hifigan_n_weights(byref(cfg)) == len(ws), (lib.bsg_hifigan_n_weights(byref(cfg)), len(ws))
+        arr = (c_void_p * len(ws))(*[p.data_ptr() for p in ws])
+        hd = c_void_p()
+        with torch.cuda.device(ws[0].device):
+            _lib.check(lib.bsg_hifigan_create(byref(hd), byref(cfg), cast(arr, POINTER(c_void_p)), len(ws), _lib.stream_ptr()),
+                       'bsg_hifigan_create')
+        self._h, self._h_key = hd, key
+        return hd
+
+    def release(self):
+        if self._h is not None:
+            _lib.load().bsg_hifigan_destroy(self._h)
+        self._h = self._h_key = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def forward(self, x, f0=None):
+        """x [B,80,T] -> [B,1,T*hop]   (hifigan.py:144-173)."""
+        if f0 is not None:
+            raise NotImplementedError('NSF source (f0) is SURVEY.md §8 row f2: not built')
+        hd = self.handle()
+        x = x.contiguous().float()
+        B, M, T = x.shape
+        assert M == 80
+        hop = int(np.prod(self.h['upsample_rates']))
+        y = torch.empty(B, 1, T * hop, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().bsg_hifigan_forward(hd, _lib.ptr(x), _lib.ptr(y), B, T, _lib.stream_ptr()), 'bsg_hifigan_forward')
+        return y

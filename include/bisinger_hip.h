@@ -193,6 +193,39 @@ int bsg_fs2midi_decode(bsg_fs2midi* h, const float* enc_out, const int64_t* mel2
                        float* mel_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * HiFi-GAN generator forward (mel -> waveform).
+ * Stands behind HifiGanGenerator(h)(x [B,80,T]) -> [B,1,T*prod(upsample_rates)]  (modules/hifigan/hifigan.py:104-173)
+ * as used by HifiGAN.spec2wav (vocoders/hifigan.py:55-69).  NSF source (use_pitch_embed) is not built.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bsg_hifigan bsg_hifigan;
+
+typedef struct {
+  int32_t n_mel;                      /* 80 (conv_pre in-channels, hifigan.py:119)                       */
+  int32_t upsample_initial_channel;   /* h['upsample_initial_channel']                                   */
+  int32_t n_ups;                      /* len(h['upsample_rates'])                                        */
+  int32_t upsample_rates[8];
+  int32_t upsample_kernel_sizes[8];
+  int32_t n_kernels;                  /* len(h['resblock_kernel_sizes']); kernels must be 3, 7 or 11     */
+  int32_t resblock_kernel_sizes[8];
+  int32_t n_dil;                      /* dilations per ResBlock1 (3)                                     */
+  int32_t resblock_dilations[8][4];
+  int32_t weight_norm;                /* 1: weights come as (bias, weight_g, weight_v) triples           */
+} bsg_hifigan_cfg;
+
+int bsg_hifigan_n_weights(const bsg_hifigan_cfg* cfg);
+/* dev_weights in HifiGanGenerator.state_dict() order: conv_pre, ups.i, resblocks.r.convs1.m (all m), then
+ * resblocks.r.convs2.m, ..., conv_post; each conv contributes (bias, weight) — the layout after
+ * remove_weight_norm() — or (bias, weight_g, weight_v) when cfg->weight_norm (checkpoint layout; folded here
+ * as w = g * v / ||v||, norm over dims != 0).  Synchronises `stream` before returning. */
+int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg, const void* const* dev_weights,
+                       int32_t n_weights, void* stream);
+void bsg_hifigan_destroy(bsg_hifigan* h);
+/* mel [B,n_mel,T] -> wav [B,1,T*prod(upsample_rates)].  May grow the workspace when B*T grows. */
+int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream);
+/* w[d0,...] = g[d0] * v[d0,...] / ||v[d0,...]||   (remove_weight_norm, hifigan.py:175-182) */
+int bsg_weight_norm_fold(const float* g, const float* v, float* w, int32_t dim0, int32_t inner, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Building block exported for unit tests: C[b] = op(A[b]) * B[b] (+bias)(+epilogue), fp32 MFMA.
  *   A: [M,K] row-major (lda);  B: trans_b ? [N,K] row-major : [K,N] row-major (ldb);  C: [M,N] (ldc).
  * ---------------------------------------------------------------------------------------------- */

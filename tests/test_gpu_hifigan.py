@@ -1,0 +1,51 @@
+"""GPU parity: HiFi-GAN generator (HIP, via the C ABI) against the goldens produced by the reference."""
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import hifigan as ohg
+from tests.util import ROOT, maxabs
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _gen(hifigan_sd, fold_before_cuda=None):
+    from bisinger_amd.hifigan import HifiGanGenerator
+    cfg = yaml.safe_load(open(f'{ROOT}/bisinger_amd/configs/hifigan.yaml'))
+    g = HifiGanGenerator(cfg)
+    g.load_state_dict(hifigan_sd, strict=True)          # checkpoint (weight-norm) layout
+    return g, cfg
+
+
+@pytest.mark.parametrize('mode', ['weight_norm', 'folded_on_gpu', 'folded_state_dict'])
+def test_hifigan_golden(gold, hifigan_sd, mode):
+    g, cfg = _gen(hifigan_sd)
+    if mode == 'folded_state_dict':
+        from bisinger_amd.hifigan import HifiGanGenerator
+        g2 = HifiGanGenerator(cfg)
+        g2.load_state_dict(ohg.fold_weight_norm(hifigan_sd), strict=True)   # already-folded checkpoint
+        g = g2
+    g = g.cuda()
+    if mode == 'folded_on_gpu':
+        g.remove_weight_norm()
+        assert 'conv_pre.weight' in g.state_dict() and 'conv_pre.weight_g' not in g.state_dict()
+    gd = gold('hifigan')
+    rs = np.random.RandomState(21)
+    for tag, (B, Th) in {'B1T16': (1, 16), 'B2T37': (2, 37)}.items():
+        mel = (rs.standard_normal((B, 80, Th)) * 1.5 - 3.0).astype(np.float32)
+        y = g(torch.from_numpy(mel).cuda())
+        assert y.shape == (B, 1, Th * 256)
+        assert maxabs(y, gd[f'{tag}.wav']) <= 2e-5, (mode, tag)
+
+
+def test_hifigan_longer_vs_oracle(hifigan_sd, sd_spec):
+    """Several 1024-sample tiles per stage + batch: tile seams, halos and the zero padding at both ends."""
+    g, cfg = _gen(hifigan_sd)
+    g = g.cuda()
+    rs = np.random.RandomState(3)
+    mel = (rs.standard_normal((3, 80, 150)) * 1.5 - 3.0).astype(np.float32)
+    want = ohg.hifigan_forward(hifigan_sd, torch.from_numpy(mel), sd_spec['hifigan_cfg'])
+    got = g(torch.from_numpy(mel).cuda())
+    assert maxabs(got, want) <= 5e-5
