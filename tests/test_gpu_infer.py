@@ -1,0 +1,94 @@
+"""GPU: the inference entry points (DiffSingerE2EInfer) on a synthetic checkpoint directory laid out like the
+reference's (checkpoints/<exp>/model_ckpt_steps_N.ckpt with 'model.' keys, vocoder dir with config.yaml +
+['state_dict']['model_gen'], binary_data_dir with phone_set.json / spk_map.json) — end to end against the oracle."""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from bisinger_amd import synth
+from tests.util import ROOT, maxabs
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture()
+def workdir(tmp_path, sd_spec, gd_sd, hifigan_sd, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('checkpoints/exp_diff_e2e')
+    os.makedirs('checkpoints/hifigan')
+    os.makedirs('data/binary')
+    full = dict(gd_sd)
+    full['fs2.decoder.embed_positions._float_tensor'] = torch.zeros(1)
+    torch.save({'state_dict': {'model.' + k: v for k, v in full.items()}, 'global_step': 1000}, 'checkpoints/exp_diff_e2e/model_ckpt_steps_1000.ckpt')
+    torch.save({'state_dict': {'model.' + k: v * 0 for k, v in full.items()}}, 'checkpoints/exp_diff_e2e/model_ckpt_steps_200.ckpt')
+    torch.save({'state_dict': {'model_gen': hifigan_sd}}, 'checkpoints/hifigan/model_ckpt_steps_5.ckpt')
+    hcfg = yaml.safe_load(open(f'{ROOT}/bisinger_amd/configs/hifigan.yaml'))
+    yaml.safe_dump(hcfg, open('checkpoints/hifigan/config.yaml', 'w'))
+    json.dump(['<AP>', '<SP>'] + [f'p{i}' for i in range(60)], open('data/binary/phone_set.json', 'w'))
+    json.dump({'Tenor-1': 3, 'Alto-2': 7}, open('data/binary/spk_map.json', 'w'))
+    cfg = {'base_config': f'{ROOT}/bisinger_amd/configs/bisinger_diff100.yaml', 'binary_data_dir': 'data/binary',
+           'vocoder_ckpt': 'checkpoints/hifigan', 'pe_enable': False, 'use_nsf': False, 'max_frames': 5000}
+    yaml.safe_dump(cfg, open('exp.yaml', 'w'))
+    return tmp_path
+
+
+def _item(n, seed):
+    rs = np.random.RandomState(seed)
+    names = ['C4', 'D#4', 'Gb3', 'A4', 'rest', 'E4/E4']
+    return {'input_type': 'phoneme', 'item_name': f'it{seed}', 'spk_name': 'Tenor-1' if seed % 2 else 'Alto-2', 'text': 'x',
+            'ph_seq': ' '.join(['<AP>'] + [f'p{rs.randint(60)}' for _ in range(n - 1)]),
+            'note_seq': ' '.join(names[rs.randint(len(names))] for _ in range(n)),
+            'note_dur_seq': ' '.join(f'{rs.uniform(0.1, 0.6):.3f}' for _ in range(n)),
+            'is_slur_seq': ' '.join(str(rs.randint(2)) for _ in range(n)),
+            'lang_seq': ' '.join(str(rs.randint(2)) for _ in range(n))}
+
+
+def _oracle_wav(infer, sample, seed, hifigan_sd, sd_spec):
+    """Oracle pipeline with the same Philox noise stream as the device (bisinger_amd/synth.py)."""
+    from oracle import fs2 as ofs2, hifigan as ohg, melgen as omg
+    sd = {k: v.detach().cpu() for k, v in infer.model.state_dict().items()}
+    inp = {'txt_tokens': sample['txt_tokens'].cpu(), 'spk_embed': sample['spk_ids'].cpu(), 'pitch_midi': sample['pitch_midi'].cpu(),
+           'midi_dur': sample['midi_dur'].cpu(), 'is_slur': sample['is_slur'].cpu(), 'lang': sample['lang'].cpu(),
+           'speechsing': sample['speechsing'].cpu()}
+    f = ofs2.fs2_forward(sd, inp)
+    B, T = f['mel2ph'].shape
+    n = B * 80 * T
+    noise = np.stack([synth.philox_normal(seed, 0, n)] + [synth.philox_normal(seed, i + 1, n) for i in reversed(range(100))])
+    r = omg.mel_gen(sd, inp, torch.from_numpy(noise.reshape(101, B, 80, T)), fs2_out=f)
+    return r, ohg.hifigan_forward(hifigan_sd, r['mel_out'].transpose(1, 2), sd_spec['hifigan_cfg'])
+
+
+def test_e2e_infer_once_and_batch(workdir, hifigan_sd, sd_spec):
+    from bisinger_amd.hparams import hparams, set_hparams
+    from bisinger_amd.infer import DiffSingerE2EInfer, note_to_midi
+    assert [note_to_midi(x) for x in ('C4', 'A4', 'F#3', 'Gb3', 'C-1')] == [60, 69, 54, 54, 0]
+    set_hparams('exp.yaml', exp_name='exp_diff_e2e', print_hparams=False, hparams_str='seed=4321')
+    assert hparams['work_dir'] == 'checkpoints/exp_diff_e2e' and hparams['timesteps'] == 100
+    assert os.path.exists('checkpoints/exp_diff_e2e/config.yaml')      # saved like the reference (hparams.py:98-101)
+    infer = DiffSingerE2EInfer(hparams)
+    assert 'conv_pre.weight' in infer.vocoder.state_dict()             # weight norm removed
+    inp = _item(9, 1)
+    wav = infer.infer_once(inp)                                         # predicted durations, Philox noise seed 4321
+    item = infer.preprocess_input(inp, 'phoneme')
+    assert item['pitch_midi'].tolist()[0] in (60, 63, 54, 69, 0, 64)
+    sample = infer.input_to_batch(item)
+    r, want = _oracle_wav(infer, sample, 4321, hifigan_sd, sd_spec)
+    assert wav.ndim == 1 and wav.shape[0] == r['mel_out'].shape[1] * 256
+    assert maxabs(wav, want.reshape(-1)) <= 2e-3
+    # batched extension: 3 items of different lengths
+    items = [infer.preprocess_input(_item(n, s), 'phoneme') for n, s in ((9, 1), (6, 2), (11, 3))]
+    wavs = infer.forward_batch(items, seed=77)
+    sample = infer.collate(items)
+    r, want = _oracle_wav(infer, sample, 77, hifigan_sd, sd_spec)
+    for i, w in enumerate(wavs):
+        n = int((r['mel2ph'][i] > 0).sum()) * 256
+        assert w.shape == (n,)
+        assert maxabs(w, want[i, 0, :n]) <= 2e-3
+    with pytest.raises(NotImplementedError):
+        infer.preprocess_input({'text': 'AP 你好 AP', 'notes': 'rest | C4 | rest', 'notes_duration': '0.1 | 0.2 | 0.1'}, 'word')
