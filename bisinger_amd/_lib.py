@@ -49,6 +49,7 @@ _SIGS = {
     'bsg_diffnet_prepare': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_diffnet_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_diffnet_residual_layer': (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_diffnet_debug_stamps': (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'bsg_ddpm_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_void_p, c_uint64, c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_void_p]),
     'bsg_plms_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

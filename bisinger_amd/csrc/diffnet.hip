@@ -17,7 +17,7 @@
 //          -> LDS [C][N_TILE] (aliases xs)
 //   GEMM2  o = W_out[2C x C] * z ; residual half: x_out = (x + o)/sqrt(2) ; skip half: skip += o
 //
-// 8 waves per workgroup = NB column blocks (32 frames each) x MS = 8/NB row slices.  Algorithmic work:
+// 8 waves per workgroup, each a 32-row slice of the gate/filter (GEMM1) and residual/skip (GEMM2) rows.  Algorithmic work:
 // 2*(2C*3C + 2C*C) = 1,048,576 FLOP per frame per layer (C = 256); algorithmic HBM bytes per frame per
 // layer = 6*C*4 = 6 KB (x in, x out, conditioner term 2C, skip read+write)  -> AI = 171 FLOP/B: bound by
 // the fp32 MFMA roof (157.3 TFLOP/s), not HBM.
@@ -77,163 +77,248 @@ struct ResArgs {
   int B, T, L, layer, dil, tiles_per_row;
   int first;             // layer 0: skip is stored, not accumulated
   float skip_div;        // last layer: skip_sum / sqrt(L) (net.py:126); 1 otherwise
+  unsigned long long* stamps;  // diagnostic build only (STAMP = true): [workgroup][wave][8] s_memtime values
 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+#define BSG_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (STAMP) {                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      const unsigned long long _t = __builtin_amdgcn_s_memtime();                                      \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
+      if (lane == 0) a.stamps[((long long)blockIdx.x * 8 + wave) * 10 + (i)] = _t;                      \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
+  } while (0)
 
-template <int NB>
-__global__ __launch_bounds__(512, (NB == 4 ? 2 : 4)) void residual_layer_kernel(ResArgs a) {
-  constexpr int NT = 32 * NB;          // frames per workgroup
-  constexpr int LDX = NT + 2 * HALO;   // xs row stride
+// fast gate math: v_exp_f32 / v_rcp_f32 based (abs error ~2e-7, far inside the 1e-3 mel budget); the libm
+// versions cost ~60 VALU instructions per element and the gate phase runs with the MFMA pipe idle.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+// Buffer (SRSRC) addressing: one wave-uniform 128-bit descriptor per tensor, a per-lane 32-bit byte offset that
+// is computed once, and a wave-uniform SGPR offset per access — the 32 row-strided loads of an accumulator tile
+// then need ONE address VGPR instead of 32 64-bit pairs (what keeps the kernel at <= 80 VGPRs = 3 workgroups/CU).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldf(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 ldf4(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void stf(float v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+// uniform part of acc_row(): register r of a 32x32 accumulator covers row (r&3) + 8*(r>>2) (+ 4 for lanes >= 32)
+__device__ __forceinline__ constexpr int acc_row0(int r) { return (r & 3) + 8 * (r >> 2); }
+
+#define BSG_MFMA8(ACC0, ACC1, A0_, A1_, B_)                                                  \
+  ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0_[0], B_[0], ACC0, 0, 0, 0);                  \
+  ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1_[0], B_[0], ACC1, 0, 0, 0);                  \
+  ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0_[1], B_[1], ACC0, 0, 0, 0);                  \
+  ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1_[1], B_[1], ACC1, 0, 0, 0);                  \
+  ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0_[2], B_[2], ACC0, 0, 0, 0);                  \
+  ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1_[2], B_[2], ACC1, 0, 0, 0);                  \
+  ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0_[3], B_[3], ACC0, 0, 0, 0);                  \
+  ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1_[3], B_[3], ACC1, 0, 0, 0);
+
+// One workgroup = 8 waves = one 32-frame tile of one utterance; wave w owns gate rows [32w,32w+32) and filter
+// rows [256+32w, ...) in GEMM1 and residual rows [32w, ...) + skip rows [256+32w, ...) in GEMM2.
+// Both GEMM loops are software-pipelined by hand: A fragments (global, L2) are requested a full 8-MFMA group
+// before use and B fragments (LDS) one group before use; sched_barrier pins that order (left alone, hipcc
+// sinks the prefetch loads next to their consumers, which exposes the L2 latency on every trip).
+template <bool STAMP = false>
+__global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
+  constexpr int NT = 32;               // frames per workgroup
+  constexpr int LDX = NT + 2 * HALO;   // xs row stride (48 floats = 12 x 16 B)
   constexpr int LDZ = NT;              // zs row stride
-  constexpr int CPW = NB;              // 32-channel chunks (gate+filter tile pairs) per wave = 8 / MS
-  constexpr int G = CPW >= 2 ? 2 : 1;  // chunks multiplied together (share the B fragment)
-  constexpr int P1 = CPW / G;          // GEMM1 passes
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;
   float* zs = lds;  // aliases xs after the barrier that ends GEMM1
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int nb = wave % NB, ms = wave / NB;
   const int b = blockIdx.x / a.tiles_per_row;
   const int t0 = (blockIdx.x - b * a.tiles_per_row) * NT;
   const int T = a.T;
   const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
-  const int col = t0 + 32 * nb + l31;       // this lane's frame in every accumulator tile
+  const int col = t0 + l31;            // this lane's frame in every accumulator tile
   const bool col_ok = col < T;
+  const int colc = col_ok ? col : T - 1;   // clamped: loads stay unconditional, results are masked
 
-  // ---- stage xs = x + d (zero padded) ----------------------------------------------------------
-  {
-    const float* __restrict__ xb = a.x_in + (long long)b * C * T;
-    const float* __restrict__ dp = a.dproj + ((long long)tb * a.L + a.layer) * C;
-#pragma unroll 8
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(a.x_in + (long long)b * C * T, plane);
+  const rsrc_t rs_xo = mk_rsrc(a.x_out + (long long)b * C * T, plane);
+  const rsrc_t rs_sk = mk_rsrc(a.skip + (long long)b * C * T, plane);
+  const rsrc_t rs_ct = mk_rsrc(a.condterm + (long long)b * 2 * C * T, 2 * plane);
+  const rsrc_t rs_a1 = mk_rsrc(a.apack1, 2 * C * 3 * C * 4);
+  const rsrc_t rs_a2 = mk_rsrc(a.apack2, 2 * C * C * 4);
+  const rsrc_t rs_bo = mk_rsrc(a.bias_out, 2 * C * 4);
+  const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * a.L + a.layer) * C, C * 4);
+  const int vcol = (lh * 4 * T + colc) * 4;   // per-lane byte offset inside a [rows][T] plane (row half + frame)
+  const int rowT = T * 4;                     // bytes per row
+  const int vfrag = lane * 16;                // per-lane byte offset inside a packed 1-KB A fragment group
+
+  BSG_STAMP(0);
+  if (STAMP && lane == 0) a.stamps[((long long)blockIdx.x * 8 + wave) * 10 + 8] = __builtin_amdgcn_s_memrealtime();
+  // ---- (1) the first A fragments fly while the x tile is staged ------------------------------------
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  const int sa_g = wave * 96 * 1024, sa_f = (8 + wave) * 96 * 1024;   // gate / filter tile of the packed dilated conv
+  f32x4 A0g = ldf4(rs_a1, vfrag, sa_g), A0f = ldf4(rs_a1, vfrag, sa_f);
+  f32x4 A1g = ldf4(rs_a1, vfrag, sa_g + 1024), A1f = ldf4(rs_a1, vfrag, sa_f + 1024);
+
+  // ---- (2) stage xs = x + d (zero padded) ------------------------------------------------------
+  if ((T & 3) == 0) {
+    // 256 rows x 12 float4; a float4 is entirely inside or entirely outside [0,T)
+#pragma unroll 3
+    for (int k = 0; k < 6; ++k) {
+      const int idx = tid + 512 * k;
+      const int c = idx / 12, j4 = idx - c * 12;
+      const int t = t0 - HALO + 4 * j4;
+      const bool ok = t >= 0 && t < T;
+      f32x4 v = ldf4(rs_x, ok ? (c * T + t) * 4 : 0, 0);
+      const float d = ldf(rs_dp, c * 4, 0);
+      v += d;
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(xs + c * LDX + 4 * j4) = v;
+    }
+  } else {
+#pragma unroll 4
     for (int idx = tid; idx < C * LDX; idx += 512) {
       const int c = idx / LDX, j = idx - c * LDX;
       const int t = t0 - HALO + j;
-      float v = 0.f;
-      if (t >= 0 && t < T) v = xb[(long long)c * T + t] + dp[c];
-      xs[idx] = v;
+      const bool ok = t >= 0 && t < T;
+      const float v = ldf(rs_x, ok ? (c * T + t) * 4 : 0, 0) + ldf(rs_dp, c * 4, 0);
+      xs[idx] = ok ? v : 0.f;
     }
   }
-
-  // ---- GEMM1 accumulators start from the conditioner term --------------------------------------
-  float z[CPW][16];
-  const float* __restrict__ ct = a.condterm + (long long)b * 2 * C * T;
   __syncthreads();
+  BSG_STAMP(1);
 
-#pragma unroll
-  for (int p = 0; p < P1; ++p) {
-    f32x16 acc[2 * G];
-    int mt[2 * G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int chunk = ms * CPW + p * G + g;
-      mt[2 * g] = chunk;          // gate rows   [32*chunk, +32)
-      mt[2 * g + 1] = 8 + chunk;  // filter rows [C + 32*chunk, +32)
-    }
-#pragma unroll
-    for (int i = 0; i < 2 * G; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        acc[i][r] = col_ok ? ct[(long long)(32 * mt[i] + acc_row(r, lh)) * T + col] : 0.f;
-
-    const f32x4* __restrict__ ap[2 * G];
-#pragma unroll
-    for (int i = 0; i < 2 * G; ++i) ap[i] = reinterpret_cast<const f32x4*>(a.apack1) + ((long long)mt[i] * 96) * 64 + lane;
-
-    f32x4 cur[2 * G], nxt[2 * G];
-#pragma unroll
-    for (int i = 0; i < 2 * G; ++i) cur[i] = ap[i][0];
-    for (int q = 0; q < 96; ++q) {
-      const int qn = q + 1 < 96 ? q + 1 : q;
-#pragma unroll
-      for (int i = 0; i < 2 * G; ++i) nxt[i] = ap[i][(long long)qn * 64];
+  // ---- (3) GEMM1: y = W_dil * im2col(xs); 8 k-steps (two groups of 8 MFMAs) per trip --------------
+  {
+    const float* xrow = xs + lh * LDX + HALO + l31;
+    auto ldb = [&](int q) {
       const int tap = q >> 5, cg = q & 31;
-      const float* bp = xs + (8 * cg + lh) * LDX + (HALO + (tap - 1) * a.dil + 32 * nb + l31);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float bv = bp[2 * j * LDX];
-#pragma unroll
-        for (int i = 0; i < 2 * G; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i][j], bv, acc[i], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 2 * G; ++i) cur[i] = nxt[i];
+      const float* p = xrow + 8 * cg * LDX + (tap - 1) * a.dil;
+      return f32x4{p[0], p[2 * LDX], p[4 * LDX], p[6 * LDX]};
+    };
+    f32x4 B0 = ldb(0), B1;
+    BSG_STAMP(2);
+#pragma unroll 1
+    for (int q = 0; q < 96; q += 2) {
+      B1 = ldb(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      BSG_MFMA8(acc0, acc1, A0g, A0f, B0)
+      __builtin_amdgcn_sched_barrier(0);
+      const int q2 = q + 2 < 96 ? q + 2 : 95;
+      A0g = ldf4(rs_a1, vfrag, sa_g + q2 * 1024);
+      A0f = ldf4(rs_a1, vfrag, sa_f + q2 * 1024);
+      B0 = ldb(q2);
+      __builtin_amdgcn_sched_barrier(0);
+      BSG_MFMA8(acc0, acc1, A1g, A1f, B1)
+      __builtin_amdgcn_sched_barrier(0);
+      const int q3 = q + 3 < 96 ? q + 3 : 95;
+      A1g = ldf4(rs_a1, vfrag, sa_g + q3 * 1024);
+      A1f = ldf4(rs_a1, vfrag, sa_f + q3 * 1024);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // gate: z = sigmoid(gate) * tanh(filter)   (net.py:73-74)
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) z[p * G + g][r] = sigmoid_f(acc[2 * g][r]) * tanhf(acc[2 * g + 1][r]);
   }
+  BSG_STAMP(3);
 
+  // ---- (4) + hoisted conditioner term, gate: z = sigmoid(gate) * tanh(filter)   (net.py:71-74) ----------
+  // The 64 KB/workgroup conditioner tile is the largest HBM stream of the layer.  It is requested here, not at
+  // kernel start: all workgroups of a launch start together, and 32 MB requested at t=0 by an idle chip costs
+  // ~15k cycles with the MFMA pipe empty; by now the co-resident workgroups have drifted apart, so this
+  // latency hides under their MFMA work.
+  float z[16];
+  {
+    float cg[16], cf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      cg[r] = ldf(rs_ct, vcol, (32 * wave + acc_row0(r)) * rowT);
+      cf[r] = ldf(rs_ct, vcol, (C + 32 * wave + acc_row0(r)) * rowT);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = fast_sigmoid(acc0[r] + cg[r]) * fast_tanh(acc1[r] + cf[r]);
+  }
+  BSG_STAMP(4);
+  // loads GEMM2 needs first fly across the two barriers: its first A fragments and the residual input x,
+  // which becomes the initial accumulator of the residual rows (x + b_out + W_out z, then / sqrt(2))
+  const int sb_r = wave * 32 * 1024, sb_s = (8 + wave) * 32 * 1024;   // residual / skip tile of the packed output projection
+  A0g = ldf4(rs_a2, vfrag, sb_r); A0f = ldf4(rs_a2, vfrag, sb_s);
+  A1g = ldf4(rs_a2, vfrag, sb_r + 1024); A1f = ldf4(rs_a2, vfrag, sb_s + 1024);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
   __syncthreads();  // every wave is done reading xs
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    const int chunk = ms * CPW + c;
+  for (int r = 0; r < 16; ++r) zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] = z[r];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) zs[(32 * chunk + acc_row(r, lh)) * LDZ + 32 * nb + l31] = z[c][r];
+  for (int r = 0; r < 16; ++r) {
+    acc0[r] += ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
+    acc1[r] = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
   }
   __syncthreads();
+  BSG_STAMP(5);
 
-  // ---- GEMM2: pass 0 = residual rows, pass 1 = skip rows ----------------------------------------
-  const float* __restrict__ xb = a.x_in + (long long)b * C * T;
-  float* __restrict__ xo = a.x_out + (long long)b * C * T;
-  float* __restrict__ sk = a.skip + (long long)b * C * T;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    f32x16 acc[NB];
-    float prev[NB][16];
-    int mt[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      mt[i] = pass * 8 + ms * NB + i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = 32 * (ms * NB + i) + acc_row(r, lh);
-        acc[i][r] = a.bias_out[pass * C + ch];
-        if (pass == 0)
-          prev[i][r] = col_ok ? xb[(long long)ch * T + col] : 0.f;
-        else
-          prev[i][r] = (col_ok && !a.first) ? sk[(long long)ch * T + col] : 0.f;
-      }
+  // ---- (5) GEMM2: o = W_out * z; residual rows and skip rows share the B fragment ---------------
+  float prevs[16];
+  {
+    const float* zrow = zs + lh * LDZ + l31;
+    auto ldb = [&](int q) {
+      const float* p = zrow + 8 * q * LDZ;
+      return f32x4{p[0], p[2 * LDZ], p[4 * LDZ], p[6 * LDZ]};
+    };
+    f32x4 B0 = ldb(0), B1;
+#define BSG_G2_TRIP(q)                                                                        \
+    {                                                                                         \
+      B1 = ldb(q + 1);                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      BSG_MFMA8(acc0, acc1, A0g, A0f, B0)                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      const int q2 = q + 2 < 32 ? q + 2 : 31;                                                 \
+      A0g = ldf4(rs_a2, vfrag, sb_r + q2 * 1024);                                             \
+      A0f = ldf4(rs_a2, vfrag, sb_s + q2 * 1024);                                             \
+      B0 = ldb(q2);                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      BSG_MFMA8(acc0, acc1, A1g, A1f, B1)                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
+      const int q3 = q + 3 < 32 ? q + 3 : 31;                                                 \
+      A1g = ldf4(rs_a2, vfrag, sb_r + q3 * 1024);                                             \
+      A1f = ldf4(rs_a2, vfrag, sb_s + q3 * 1024);                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                      \
     }
-    const f32x4* __restrict__ ap[NB];
+#pragma unroll 1
+    for (int q = 0; q < 16; q += 2) BSG_G2_TRIP(q)
+    // the running skip sum is added after the chain (keeps the small products out of a large accumulator)
 #pragma unroll
-    for (int i = 0; i < NB; ++i) ap[i] = reinterpret_cast<const f32x4*>(a.apack2) + ((long long)mt[i] * 32) * 64 + lane;
-    f32x4 cur[NB], nxt[NB];
+    for (int r = 0; r < 16; ++r) prevs[r] = ldf(rs_sk, vcol, (32 * wave + acc_row0(r)) * rowT);
+#pragma unroll 1
+    for (int q = 16; q < 32; q += 2) BSG_G2_TRIP(q)
+#undef BSG_G2_TRIP
+  }
+  BSG_STAMP(6);
+  if (col_ok) {
+    const int vst = (lh * 4 * T + col) * 4;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) cur[i] = ap[i][0];
-    for (int q = 0; q < 32; ++q) {
-      const int qn = q + 1 < 32 ? q + 1 : q;
-#pragma unroll
-      for (int i = 0; i < NB; ++i) nxt[i] = ap[i][(long long)qn * 64];
-      const float* bp = zs + (8 * q + lh) * LDZ + 32 * nb + l31;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float bv = bp[2 * j * LDZ];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[i][j], bv, acc[i], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) cur[i] = nxt[i];
-    }
-    if (col_ok) {
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ch = 32 * (ms * NB + i) + acc_row(r, lh);
-          if (pass == 0) {
-            xo[(long long)ch * T + col] = (prev[i][r] + acc[i][r]) / 1.41421356237309504880f;  // net.py:78
-          } else {
-            sk[(long long)ch * T + col] = (prev[i][r] + acc[i][r]) / a.skip_div;
-          }
-        }
+    for (int r = 0; r < 16; ++r) {
+      const int so = (32 * wave + acc_row0(r)) * rowT;
+      stf(acc0[r] / 1.41421356237309504880f, rs_xo, vst, so);                      // (x + residual) / sqrt(2), net.py:78
+      stf(((a.first ? 0.f : prevs[r]) + acc1[r]) / a.skip_div, rs_sk, vst, so);    // running skip sum (/ sqrt(L) last, :126)
     }
   }
+  BSG_STAMP(7);
+  if (STAMP && lane == 0) a.stamps[((long long)blockIdx.x * 8 + wave) * 10 + 9] = __builtin_amdgcn_s_memrealtime();
 }
+#undef BSG_MFMA8
 
 // ------------------------------------------------------------------------------------------------
 // sampler: one ancestral step, elementwise over [B][M][T]   (shallow_diffusion_tts.py:134-166)
@@ -579,16 +664,8 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   return BSG_OK;
 }
 
-static int pick_nb(int B, int T) {
-  // Measured on MI355X (tools/bench_layer.py, profiles/): the 32-frame tile (48 KB LDS, 3 workgroups per
-  // CU, every wave a different 32-row slice of the same frames) is fastest at every batch size tried
-  // (B = 1..64, T = 500..1000): more resident workgroups hide the L2 latency of the weight stream.
-  (void)B; (void)T;
-  return 1;
-}
-
 static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long long* t_dev, int t_uniform, float* x_out,
-                        float* skip, int B, int T, hipStream_t st, int force_nb = 0) {
+                        float* skip, int B, int T, hipStream_t st, unsigned long long* stamps = nullptr) {
   ResArgs a{};
   a.x_in = x_in; a.x_out = x_out; a.skip = skip;
   a.condterm = h->condterm + (size_t)layer * 2 * C * (size_t)B * T;
@@ -600,21 +677,21 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   a.dil = 1 << (layer % h->cfg.dilation_cycle_length);
   a.first = layer == 0;
   a.skip_div = layer == h->L - 1 ? sqrtf((float)h->L) : 1.0f;
-  const int nb = force_nb ? force_nb : pick_nb(B, T);
-  const int NT = 32 * nb;
-  a.tiles_per_row = cdiv(T, NT);
+  a.stamps = stamps;
+  // 32-frame tiles: 48 KB of LDS -> 3 workgroups per CU.  (Wider tiles of 64 / 128 frames were built and
+  // measured in round 1: 0-50 % slower at every batch size, because fewer workgroups per CU hide less of the
+  // L2 latency of the weight stream.)
+  a.tiles_per_row = cdiv(T, 32);
   const dim3 grid(B * a.tiles_per_row), block(512);
-  const size_t lds = (size_t)C * (NT + 2 * HALO) * sizeof(float);
+  const size_t lds = (size_t)C * (32 + 2 * HALO) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, C * (128 + 2 * HALO) * 4));
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C * (64 + 2 * HALO) * 4));
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C * (32 + 2 * HALO) * 4));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  if (nb == 4) hipLaunchKernelGGL(residual_layer_kernel<4>, grid, block, lds, st, a);
-  else if (nb == 2) hipLaunchKernelGGL(residual_layer_kernel<2>, grid, block, lds, st, a);
-  else hipLaunchKernelGGL(residual_layer_kernel<1>, grid, block, lds, st, a);
+  if (stamps) hipLaunchKernelGGL(residual_layer_kernel<true>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(residual_layer_kernel<false>, grid, block, lds, st, a);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
@@ -661,11 +738,7 @@ extern "C" int bsg_diffnet_residual_layer(bsg_diffnet* h, int32_t layer, const f
   TRY(check_bound(h, B, T, "diffnet_residual_layer"));
   BSG_REQUIRE(x_in && t && x_out && skip && x_in != x_out, "diffnet_residual_layer: null or aliased argument");
   BSG_REQUIRE(layer >= 0 && layer < h->L, "diffnet_residual_layer: layer %d out of range", layer);
-  // test hook: BSG_FORCE_NB in {1,2,4} overrides the tile width chosen by pick_nb()
-  int force_nb = 0;
-  if (const char* e = getenv("BSG_FORCE_NB")) force_nb = atoi(e);
-  BSG_REQUIRE(force_nb == 0 || force_nb == 1 || force_nb == 2 || force_nb == 4, "BSG_FORCE_NB=%d", force_nb);
-  return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream, force_nb);
+  return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream);
 }
 
 static int check_schedule(const bsg_schedule* s, const char* who, bool plms) {
@@ -704,6 +777,14 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     BSG_LAUNCH_CHECK();
   }
   return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_debug_stamps(bsg_diffnet* h, int32_t layer, const float* x_in, const int64_t* t, float* x_out,
+                                       float* skip, int32_t B, int32_t T, uint64_t* stamps, void* stream) {
+  TRY(check_bound(h, B, T, "diffnet_debug_stamps"));
+  BSG_REQUIRE(x_in && t && x_out && skip && stamps && x_in != x_out, "diffnet_debug_stamps: null or aliased argument");
+  BSG_REQUIRE(layer >= 0 && layer < h->L, "diffnet_debug_stamps: layer %d out of range", layer);
+  return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream, (unsigned long long*)stamps);
 }
 
 extern "C" int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable) {

@@ -130,6 +130,14 @@ int bsg_mel_finish(const float* x, const float* spec_min, const float* spec_max,
 int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable);
 int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_layer_launches);
 
+/* Diagnostic build of the fused residual layer (separate kernel instantiation; the product kernel executes no
+ * stamp): same computation, plus s_memtime stamps per wave at the phase boundaries
+ * {0 start, 1 staged, 2 acc init, 3 GEMM1 done, 4 gate done, 5 z in LDS, 6 GEMM2 residual pass, 7 skip pass}
+ * into stamps [B*ceil(T/32)][8 waves][10] (device, uint64; slots 8, 9 = s_memrealtime (100 MHz) at start / end, which
+ * gives the shader clock the chip held).  Never timed; used by tools/stamp_layer.py. */
+int bsg_diffnet_debug_stamps(bsg_diffnet* h, int32_t layer, const float* x_in, const int64_t* t, float* x_out,
+                             float* skip, int32_t B, int32_t T, uint64_t* stamps, void* stream);
+
 /* PLMS / PNDM loop A (:258-264, p_sample_plms :168-201): for i in reversed(range(0,K_step,interval)).
  * Batched semantics = element-wise clamp of t-interval (the reference raises for B>1, :189). */
 int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, int32_t K_step, int32_t interval,

@@ -47,10 +47,11 @@ def test_gemm_f32(M, N, K, trans_b, batch):
     assert maxabs(c, ref) <= 2e-6 * K ** 0.5 * 4 + 1e-5
 
 
-@pytest.mark.parametrize('B,T,force_nb', [(2, 64, 1), (2, 64, 2), (2, 64, 4), (3, 77, 1), (3, 77, 2), (3, 77, 4), (5, 333, 0)])
+@pytest.mark.parametrize('B,T', [(2, 64), (3, 77), (1, 31), (5, 333), (2, 1000)])
 @pytest.mark.parametrize('layer', [0, 3, 19])
-def test_residual_layer(net, B, T, force_nb, layer):
-    """One fused ResidualBlock vs oracle.residual_block (net.py:66-78), every tile width."""
+def test_residual_layer(net, B, T, layer):
+    """One fused ResidualBlock vs oracle.residual_block (net.py:66-78): vector (T%4==0) and scalar staging,
+    partial last tiles, every dilation class, first-layer store and last-layer scaling of the skip sum."""
     sd = cpu_sd(net, 'denoise_fn.')
     rs = np.random.RandomState(100 * B + T + layer)
     x = rs.standard_normal((B, 256, T)).astype(np.float32)
@@ -64,11 +65,9 @@ def test_residual_layer(net, B, T, force_nb, layer):
         want_skip = want_skip / 20 ** 0.5
     net.prepare(T_(cond).cuda())
     skip = T_(skip0).cuda()
-    os.environ['BSG_FORCE_NB'] = str(force_nb)
-    try:
-        out = net.residual_layer(layer, T_(x).cuda(), T_(t).cuda(), skip)
-    finally:
-        os.environ.pop('BSG_FORCE_NB')
+    if layer == 0:
+        skip.fill_(float('nan'))          # the first layer must store, never read, the skip buffer
+    out = net.residual_layer(layer, T_(x).cuda(), T_(t).cuda(), skip)
     torch.cuda.synchronize()
     assert maxabs(out, rx) <= 2e-5
     assert maxabs(skip, want_skip) <= 2e-5

@@ -25,8 +25,7 @@ for B, T in [(16, 1000), (64, 1000), (8, 1000), (1, 500)]:
     skip = torch.zeros(B, 256, T, device='cuda')
     t = torch.full((B,), 50, dtype=torch.long, device='cuda')
     net.prepare(cond)
-    for nb in ([1, 2, 4] if B >= 8 else [1, 2]):
-        os.environ['BSG_FORCE_NB'] = str(nb)
+    for nb in [1]:
         for _ in range(3):
             net.residual_layer(3, x, t, skip)
         torch.cuda.synchronize()
@@ -38,8 +37,7 @@ for B, T in [(16, 1000), (64, 1000), (8, 1000), (1, 500)]:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        print(f'layer B={B} T={T} NB={nb}: {ms * 1e3:.1f} us  {FLOP_LAYER * B * T / ms / 1e9:.1f} TFLOP/s', flush=True)
-    os.environ.pop('BSG_FORCE_NB')
+        print(f'layer B={B} T={T}: {ms * 1e3:.1f} us  {FLOP_LAYER * B * T / ms / 1e9:.1f} TFLOP/s', flush=True)
     spec = torch.randn(B, 1, 80, T, device='cuda')
     for _ in range(2):
         net(spec, t, cond)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Phase timeline of the fused residual-layer kernel from the diagnostic (stamped) build."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bisinger_amd import _lib, synth  # noqa: E402
+from tests.util import load_formula_weights, use_config  # noqa: E402
+
+torch.set_grad_enabled(False)
+use_config()
+from bisinger_amd.diffnet import DiffNet  # noqa: E402
+
+B, T = int(os.environ.get('PB', 16)), int(os.environ.get('PT', 1000))
+net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+cond = torch.randn(B, 256, T, device='cuda')
+x = torch.randn(B, 256, T, device='cuda')
+out = torch.empty_like(x)
+skip = torch.zeros(B, 256, T, device='cuda')
+t = torch.full((B,), 50, dtype=torch.long, device='cuda')
+net.prepare(cond)
+nwg = B * ((T + 31) // 32)
+st = torch.zeros(nwg, 8, 10, dtype=torch.int64, device='cuda')
+lib = _lib.load()
+for it in range(3):
+    for _ in range(200):
+        net.residual_layer(3, x, t, skip)
+    _lib.check(lib.bsg_diffnet_debug_stamps(net._h, 3, _lib.ptr(x), _lib.ptr(t), _lib.ptr(out), _lib.ptr(skip), B, T, _lib.ptr(st),
+                                            _lib.stream_ptr()), 'stamps')
+    torch.cuda.synchronize()
+s = st.cpu().numpy().astype(np.float64)
+t0 = s[:, :, 0].min()
+names = ['start', 'staged+barrier', 'acc-init issued', 'GEMM1 done', 'gate done', 'z in LDS (2 barriers)', 'GEMM2 residual', 'GEMM2 skip']
+print(f'B={B} T={T} workgroups={nwg}; s_memtime ticks (100 MHz constant clock if memrealtime, else shader cycles)')
+print('kernel span (first start -> last end):', s[:, :, 7].max() - t0)
+print('wg start spread:', s[:, :, 0].min(axis=1).max() - t0)
+clk = (s[:, :, 7] - s[:, :, 0]) / np.maximum(s[:, :, 9] - s[:, :, 8], 1) * 100.0
+print(f'shader clock held (MHz): median {np.median(clk):.0f}  p10 {np.percentile(clk, 10):.0f}  p90 {np.percentile(clk, 90):.0f}')
+rt = s[:, :, 8:10]
+print(f'kernel span by the 100 MHz clock: {(rt[:, :, 1].max() - rt[:, :, 0].min()) / 100.0:.1f} us')
+d = np.diff(s[:, :, :8], axis=2)
+for i in range(7):
+    print(f'  phase {i}->{i + 1} {names[i + 1]:28s} mean {d[:, :, i].mean():10.0f}  p10 {np.percentile(d[:, :, i], 10):10.0f}  p90 {np.percentile(d[:, :, i], 90):10.0f}')
+print('  per-wave total mean', (s[:, :, 7] - s[:, :, 0]).mean())
