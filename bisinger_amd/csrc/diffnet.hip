@@ -379,6 +379,180 @@ __global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict_
   reinterpret_cast<f32x4*>(x)[i] = o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// step tail + next head, fused (DDPM loop only): for one 32-frame tile
+//   h    = relu(W_skip * s + b)            s = skip sum / sqrt(L), written by the last residual layer   (net.py:126-128)
+//   eps  = W_out * h + b                                                                               (net.py:129)
+//   x   <- p_sample(x, eps, noise)         same arithmetic as ddpm_step_kernel                  (shallow_diffusion_tts.py:149-166)
+//   xa   = relu(W_in * x + b)              the NEXT step's input projection                            (net.py:116-118)
+// Replaces three GEMM launches + the sampler launch per step (~150 us -> ~20 us at B=16, T=1000): the three
+// projections are too small (0.04-0.13 MFLOP/frame) to fill the chip as separate 128x128-tile GEMMs.
+// ------------------------------------------------------------------------------------------------
+struct TailArgs {
+  const float* skip;    // [B][C][T]
+  float* x;             // [B][M][T] in/out
+  const float* noise;   // [B][M][T] or null (Philox)
+  float* xa_next;       // [B][C][T]
+  const float* ws_pack; // [8][32][64][4]
+  const float* wo_pack; // [3][32][64][4]  (rows >= M are zero)
+  const float* wi_pack; // [8][MP/8][64][4]
+  const float* b_skip;  // [C]
+  const float* b_fin;   // [96] (zero padded)
+  const float* b_in;    // [C]
+  StepCoef k;
+  unsigned long long seed, quad_row0;   // Philox: key, and the flat element index of this shard's row 0
+  unsigned stream;
+  int B, T, M, tiles_per_row, do_head;
+};
+
+__device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigned stream, unsigned long long idx) {
+  const f32x4 z = philox_normal4(seed, stream, idx >> 2);
+  const int s = (int)(idx & 3);
+  return s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3];
+}
+
+#define BSG_MFMA4(ACC, A_, B_)                                                \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[0], B_[0], ACC, 0, 0, 0);      \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[1], B_[1], ACC, 0, 0, 0);      \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[2], B_[2], ACC, 0, 0, 0);      \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[3], B_[3], ACC, 0, 0, 0);
+
+// acc += A[tile rows] * Bs, K = 8*NQ, A fragments from `rs` at byte offset `sbase`, B rows from LDS `bs` (stride 32)
+template <int NQ>
+__device__ __forceinline__ void tile_gemm(f32x16& acc, rsrc_t rs, int vfrag, int sbase, const float* brow) {
+  auto ldb = [&](int q) {
+    const float* p = brow + 8 * q * 32;
+    return f32x4{p[0], p[2 * 32], p[4 * 32], p[6 * 32]};
+  };
+  f32x4 A0 = ldf4(rs, vfrag, sbase), A1 = ldf4(rs, vfrag, sbase + (NQ > 1 ? 1024 : 0));
+  f32x4 B0 = ldb(0), B1;
+#pragma unroll 1
+  for (int q = 0; q < NQ; q += 2) {
+    B1 = ldb(q + 1 < NQ ? q + 1 : NQ - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    BSG_MFMA4(acc, A0, B0)
+    __builtin_amdgcn_sched_barrier(0);
+    const int q2 = q + 2 < NQ ? q + 2 : NQ - 1;
+    A0 = ldf4(rs, vfrag, sbase + q2 * 1024);
+    B0 = ldb(q2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 1 < NQ) { BSG_MFMA4(acc, A1, B1) }
+    __builtin_amdgcn_sched_barrier(0);
+    const int q3 = q + 3 < NQ ? q + 3 : NQ - 1;
+    A1 = ldf4(rs, vfrag, sbase + q3 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int MP>   // MP = in_dims padded to a multiple of 8 (K of the head GEMM); in_dims <= 96
+__global__ __launch_bounds__(512, 4) void step_tail_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ss = lds;               // [C][32]  skip tile, then h tile
+  float* xin = lds + C * 32;     // [96][32] updated x tile (rows >= M zero)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / a.tiles_per_row;
+  const int t0 = (blockIdx.x - b * a.tiles_per_row) * 32;
+  const int T = a.T, M = a.M;
+  const int col = t0 + l31;
+  const bool col_ok = col < T;
+  const int colc = col_ok ? col : T - 1;
+  const rsrc_t rs_s = mk_rsrc(a.skip + (long long)b * C * T, (unsigned)C * T * 4);
+  const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, (unsigned)C * T * 4);
+  const rsrc_t rs_x = mk_rsrc(a.x + (long long)b * M * T, (unsigned)M * T * 4);
+  const rsrc_t rs_ws = mk_rsrc(a.ws_pack, C * C * 4);
+  const rsrc_t rs_wo = mk_rsrc(a.wo_pack, 96 * C * 4);
+  const rsrc_t rs_wi = mk_rsrc(a.wi_pack, C * MP * 4);
+  const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
+  const rsrc_t rs_bf = mk_rsrc(a.b_fin, 96 * 4);
+  const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
+  const int vfrag = lane * 16, rowT = T * 4;
+  const int vcol = (lh * 4 * T + colc) * 4;
+
+  // ---- stage the skip tile ---------------------------------------------------------------------
+  if ((T & 3) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 512 * k;
+      const int c = idx >> 3, j4 = idx & 7;
+      const int t = t0 + 4 * j4;
+      f32x4 v = ldf4(rs_s, t < T ? (c * T + t) * 4 : 0, 0);
+      if (t >= T) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(ss + c * 32 + 4 * j4) = v;
+    }
+  } else {
+    for (int idx = tid; idx < C * 32; idx += 512) {
+      const int c = idx >> 5, t = t0 + (idx & 31);
+      const float v = ldf(rs_s, t < T ? (c * T + t) * 4 : 0, 0);
+      ss[idx] = t < T ? v : 0.f;
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4);
+  __syncthreads();
+  // ---- h = relu(W_skip s + b) ------------------------------------------------------------------
+  tile_gemm<32>(acc, rs_ws, vfrag, wave * 32 * 1024, ss + lh * 32 + l31);
+  __syncthreads();   // every wave is done reading s
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ss[(32 * wave + acc_row(r, lh)) * 32 + l31] = fmaxf(acc[r], 0.f);
+  __syncthreads();
+  // ---- eps = W_out h + b; sampler update on the 3 row tiles that cover the M mel bins -----------
+  if (wave < 3) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = ldf(rs_bf, lh * 16, (32 * wave + acc_row0(r)) * 4);
+    float xv[16], nv[16];
+    const rsrc_t rs_n = mk_rsrc(a.noise ? a.noise + (long long)b * M * T : a.x, a.noise ? (unsigned)M * T * 4 : 0u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // the lane's row is m0 + 4*lh; rows >= M fall outside the descriptor's range and read as 0 (raw-buffer
+      // range check), and are never stored
+      const int m0 = 32 * wave + acc_row0(r);
+      xv[r] = ldf(rs_x, vcol, m0 * rowT);
+      nv[r] = a.noise ? ldf(rs_n, vcol, m0 * rowT) : 0.f;
+    }
+    tile_gemm<32>(acc, rs_wo, vfrag, wave * 32 * 1024, ss + lh * 32 + l31);
+    const int vst = (lh * 4 * T + col) * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * wave + acc_row(r, lh);
+      float o = 0.f;
+      if (m < M) {
+        float nz = nv[r];
+        if (!a.noise && a.k.sigma != 0.f)
+          nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + colc);
+        float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, acc[r]));
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
+        o = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
+        if (col_ok) stf(o, rs_x, vst, (32 * wave + acc_row0(r)) * rowT);
+      }
+      xin[m * 32 + l31] = o;
+    }
+  }
+  if (!a.do_head) return;
+  __syncthreads();
+  // ---- next step's input projection: xa = relu(W_in x + b) --------------------------------------
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4);
+  tile_gemm<MP / 8>(acc, rs_wi, vfrag, wave * (MP / 8) * 1024, xin + lh * 32 + l31);
+  if (col_ok) {
+    const int vst = (lh * 4 * T + col) * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stf(fmaxf(acc[r], 0.f), rs_xa, vst, (32 * wave + acc_row0(r)) * rowT);
+  }
+}
+#undef BSG_MFMA4
+
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows_src, int rows_dst, int cols_src,
+                                int cols_dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_dst * cols_dst) return;
+  const int r = i / cols_dst, c = i - r * cols_dst;
+  dst[i] = (r < rows_src && c < cols_src) ? src[(long long)r * cols_src + c] : 0.f;
+}
+
 __global__ void philox_fill_kernel(float* __restrict__ x, long long n4, unsigned long long seed, unsigned stream,
                                    unsigned long long quad0) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,6 +662,12 @@ struct bsg_diffnet {
   float* w_fin = nullptr;   // [M][C]
   float* b_fin = nullptr;
   float* dproj = nullptr;   // [S][L][C]
+  // fused step tail/head (DDPM loop): packed skip / output / input projections
+  float* ws_pack = nullptr;  // [C*C]
+  float* wo_pack = nullptr;  // [96*C]
+  float* wi_pack = nullptr;  // [C*MP]
+  float* b_fin96 = nullptr;  // [96]
+  int MP = 0;
   // workspaces for the bound (B,T)
   int B = 0, T = 0;
   size_t cap_bt = 0;
@@ -517,7 +697,7 @@ static void dev_free(float*& p) {
 extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (!h) return;
   float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
-                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
+                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -601,9 +781,31 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   if (rc == BSG_OK) rc = copy_dev(h->b_skip, tw[1], C, st);
   if (rc == BSG_OK) rc = copy_dev(h->w_fin, tw[2], (size_t)M * C, st);
   if (rc == BSG_OK) rc = copy_dev(h->b_fin, tw[3], M, st);
+  float *wo_pad = nullptr, *wi_pad = nullptr;
+  if (rc == BSG_OK && M <= 96) {
+    const int MP = (M + 7) / 8 * 8;
+    h->MP = MP;
+    rc = dev_alloc(&h->ws_pack, (size_t)C * C);
+    if (rc == BSG_OK) rc = dev_alloc(&h->wo_pack, (size_t)96 * C);
+    if (rc == BSG_OK) rc = dev_alloc(&h->wi_pack, (size_t)C * MP);
+    if (rc == BSG_OK) rc = dev_alloc(&h->b_fin96, 96);
+    if (rc == BSG_OK) rc = dev_alloc(&wo_pad, (size_t)96 * C);
+    if (rc == BSG_OK) rc = dev_alloc(&wi_pad, (size_t)C * MP);
+    if (rc == BSG_OK) {
+      hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv((long long)C * C, 256)), dim3(256), 0, st, (const float*)tw[0], h->ws_pack, C, C, C, (long long)C, 1LL, 0LL);
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(96 * C, 256)), dim3(256), 0, st, (const float*)tw[2], wo_pad, M, 96, C, C);
+      hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv((long long)96 * C, 256)), dim3(256), 0, st, (const float*)wo_pad, h->wo_pack, 96, C, C, (long long)C, 1LL, 0LL);
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(C * MP, 256)), dim3(256), 0, st, (const float*)w[0], wi_pad, C, C, M, MP);
+      hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv((long long)C * MP, 256)), dim3(256), 0, st, (const float*)wi_pad, h->wi_pack, C, MP, MP, (long long)MP, 1LL, 0LL);
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(1), dim3(256), 0, st, (const float*)tw[3], h->b_fin96, M, 96, 1, 1);
+      if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: tail pack kernels failed"); rc = BSG_EHIP; }
+    }
+  }
   hipError_t e = hipStreamSynchronize(st);
   dev_free(hid);
   dev_free(dtab);
+  dev_free(wo_pad);
+  dev_free(wi_pad);
   if (rc != BSG_OK) return rc;
   BSG_HIP(e);
   return BSG_OK;
@@ -767,13 +969,53 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   BSG_REQUIRE(n % 4 == 0, "ddpm_sample: B*M*T must be a multiple of 4");
   const long long n4 = n / 4;
   const unsigned long long quad0 = (unsigned long long)row0 * h->M * T / 4;
+  const bool fused = h->ws_pack != nullptr && (h->MP == 80 || h->MP == 96) && !getenv("BSG_NO_FUSED_TAIL");
+  if (!fused) {
+    for (int k = 0; k < n_steps; ++k) {
+      const int i = t_start - k;
+      TRY(forward_impl(h, x, nullptr, i, h->eps, B, T, st));
+      StepCoef c{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
+                 s->posterior_mean_coef2[i], s->sigma[i]};
+      hipLaunchKernelGGL(ddpm_step_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, x, (const float*)h->eps,
+                         noise ? noise + (long long)k * n : nullptr, c, n4, (unsigned long long)seed, (unsigned)(i + 1), quad0);
+      BSG_LAUNCH_CHECK();
+    }
+    return BSG_OK;
+  }
+  // fused loop: [in-projection once] -> per step: 20 residual layers -> step_tail_kernel (skip projection, output
+  // projection, sampler update, next step's in-projection)
+  static bool tail_attr = false;
+  const size_t tail_lds = (size_t)(C * 32 + 96 * 32) * sizeof(float);
+  if (!tail_attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    tail_attr = true;
+  }
+  if (n_steps > 0) TRY(conv1x1(h->w_in, h->b_in, x, h->xa, C, h->M, B, T, ACT_RELU, st));
   for (int k = 0; k < n_steps; ++k) {
     const int i = t_start - k;
-    TRY(forward_impl(h, x, nullptr, i, h->eps, B, T, st));
-    StepCoef c{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
-               s->posterior_mean_coef2[i], s->sigma[i]};
-    hipLaunchKernelGGL(ddpm_step_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, x, (const float*)h->eps,
-                       noise ? noise + (long long)k * n : nullptr, c, n4, (unsigned long long)seed, (unsigned)(i + 1), quad0);
+    float* cur = h->xa;
+    float* nxt = h->xb;
+    const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+    if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    for (int l = 0; l < h->L; ++l) {
+      TRY(launch_layer(h, l, cur, nullptr, i, nxt, h->skip, B, T, st));
+      float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (prof) {
+      BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+    }
+    TailArgs a{};
+    a.skip = h->skip; a.x = x; a.noise = noise ? noise + (long long)k * n : nullptr; a.xa_next = h->xa;
+    a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
+    a.k = StepCoef{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
+                   s->posterior_mean_coef2[i], s->sigma[i]};
+    a.seed = seed; a.quad_row0 = (unsigned long long)row0 * h->M * T; a.stream = (unsigned)(i + 1);
+    a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32); a.do_head = k + 1 < n_steps;
+    const dim3 grid(B * a.tiles_per_row), block(512);
+    if (h->MP == 80) hipLaunchKernelGGL(step_tail_kernel<80>, grid, block, tail_lds, st, a);
+    else hipLaunchKernelGGL(step_tail_kernel<96>, grid, block, tail_lds, st, a);
     BSG_LAUNCH_CHECK();
   }
   return BSG_OK;

@@ -96,3 +96,20 @@ def test_philox_mode_is_reproducible_and_shard_invariant(model):
     assert torch.equal(full, again)
     half = run([2, 3], 2)
     assert torch.equal(full[2:], half)
+
+
+def test_fused_step_tail_matches_separate_kernels(model, monkeypatch):
+    """The DDPM loop's fused tail (skip-proj -> out-proj -> p_sample -> next in-proj) against the separate
+    GEMM + sampler launches, with supplied noise and with the Philox stream (which must be the same stream)."""
+    B, T = 3, 77          # partial tile, scalar staging path
+    cond = torch.randn(B, 256, T, generator=torch.Generator().manual_seed(5)).cuda()
+    noise = T_(synth.synth_noise(12, B, 80, T, seed=2)).cuda()
+    x0 = noise[0][:, None].contiguous()
+    fused = model.sample(cond, x0.clone(), noise=noise[1:], n_steps=12)
+    fused_p = model.sample(cond, x0.clone(), seed=9, n_steps=12)
+    monkeypatch.setenv('BSG_NO_FUSED_TAIL', '1')
+    sep = model.sample(cond, x0.clone(), noise=noise[1:], n_steps=12)
+    sep_p = model.sample(cond, x0.clone(), seed=9, n_steps=12)
+    assert maxabs(fused, sep) <= 2e-5
+    assert maxabs(fused_p, sep_p) <= 2e-5
+    assert maxabs(fused_p, fused) > 1e-2

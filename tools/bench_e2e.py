@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: end-to-end mel generation + HiFi-GAN on one MI355X, 22.05 kHz, real-time factor.
+Also times the vocoder alone.  One JSON line per configuration."""
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from bisinger_amd import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+dev = torch.device('cuda', 0)
+model = bench.build_model(dev)
+from collections import OrderedDict  # noqa: E402
+from bisinger_amd.hifigan import HifiGanGenerator  # noqa: E402
+cfg = yaml.safe_load(open(f'{ROOT}/bisinger_amd/configs/hifigan.yaml'))
+voc = HifiGanGenerator(cfg)
+spec = OrderedDict((k, tuple(v.shape)) for k, v in voc.state_dict().items())
+voc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, 7).items()})
+voc = voc.to(dev)
+voc.remove_weight_norm()
+SR, HOP = cfg['audio_sample_rate'], 256
+
+for B, T in [(1, 1000), (8, 1000), (16, 1000)]:
+    inp = synth.synth_inputs(B, T // 10, T, seed=1)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
+
+    def run():
+        out = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], infer=True, seed=3, **kw)
+        return out['mel_out'], voc(out['mel_out'].transpose(1, 2))
+    mel, wav = run()
+    torch.cuda.synchronize()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        mel, wav = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(10):
+        w2 = voc(mel.transpose(1, 2))
+    torch.cuda.synchronize()
+    dv = (time.perf_counter() - t0) / 10
+    audio_s = B * T * HOP / SR
+    print(json.dumps({'config': f'e2e mel-gen(100 steps)+HiFi-GAN B={B} T={T}', 'seconds': dt, 'audio_seconds': audio_s,
+                      'rtf': dt / audio_s, 'vocoder_ms': dv * 1e3, 'vocoder_rtf': dv / audio_s,
+                      'vocoder_gflops': 38.51e6 * B * T / dv / 1e9, 'wav_finite': bool(torch.isfinite(wav).all())}), flush=True)
