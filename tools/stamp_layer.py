@@ -42,6 +42,12 @@ clk = (s[:, :, 7] - s[:, :, 0]) / np.maximum(s[:, :, 9] - s[:, :, 8], 1) * 100.0
 print(f'shader clock held (MHz): median {np.median(clk):.0f}  p10 {np.percentile(clk, 10):.0f}  p90 {np.percentile(clk, 90):.0f}')
 rt = s[:, :, 8:10]
 print(f'kernel span by the 100 MHz clock: {(rt[:, :, 1].max() - rt[:, :, 0].min()) / 100.0:.1f} us')
+wg_start = rt[:, :, 0].min(axis=1); wg_end = rt[:, :, 1].max(axis=1); k0 = wg_start.min()
+print(f'workgroup start (us after first): p50 {np.percentile(wg_start - k0, 50) / 100:.2f}  p90 {np.percentile(wg_start - k0, 90) / 100:.2f}  max {(wg_start - k0).max() / 100:.2f}')
+print(f'workgroup end   (us after first start): p10 {np.percentile(wg_end - k0, 10) / 100:.1f}  p50 {np.percentile(wg_end - k0, 50) / 100:.1f}  p90 {np.percentile(wg_end - k0, 90) / 100:.1f}  max {(wg_end - k0).max() / 100:.1f}')
+print(f'workgroup duration us: p10 {np.percentile(wg_end - wg_start, 10) / 100:.1f} p50 {np.percentile(wg_end - wg_start, 50) / 100:.1f} p90 {np.percentile(wg_end - wg_start, 90) / 100:.1f}')
+order = np.argsort(wg_end)
+print('last 8 workgroups to finish (blockIdx, start us, end us):', [(int(i), round(float(wg_start[i] - k0) / 100, 1), round(float(wg_end[i] - k0) / 100, 1)) for i in order[-8:]])
 d = np.diff(s[:, :, :8], axis=2)
 for i in range(7):
     print(f'  phase {i}->{i + 1} {names[i + 1]:28s} mean {d[:, :, i].mean():10.0f}  p10 {np.percentile(d[:, :, i], 10):10.0f}  p90 {np.percentile(d[:, :, i], 90):10.0f}')
