@@ -104,6 +104,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--cpu-steps', type=int, default=6, help='sampler steps of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the all-gather even with one rank (self-test)')
     args = ap.parse_args()
 
     from bisinger_amd import dist as bdist, synth
@@ -117,9 +118,13 @@ def main():
         sys.exit('bench.py needs an MI355X: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    import torch.distributed as dist
     if world > 1:
         bdist.init_distributed('nccl')
-    import torch.distributed as dist
+    elif args.force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group(backend='nccl', rank=0, world_size=1)
 
     torch.set_grad_enabled(False)
     model = build_model(device)
@@ -132,10 +137,14 @@ def main():
     def step(seed):
         out = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True,
                     seed=seed, rows=rows if world > 1 else None, **kw)
+        if args.force_dist and world == 1:
+            full = torch.empty_like(out['mel_out'])
+            dist.all_gather_into_tensor(full, out['mel_out'].contiguous())
+            return full
         return bdist.all_gather_rows(out['mel_out'], B_total, world, rank)
 
     def fence():
-        if world > 1:
+        if world > 1 or args.force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +195,7 @@ def main():
             rec['parity'] = parity
             rec['gpu_over_cpu'] = value / base['value']
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

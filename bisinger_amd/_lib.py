@@ -30,7 +30,11 @@ class HifiganCfg(Structure):
     _fields_ = [('n_mel', c_int32), ('upsample_initial_channel', c_int32), ('n_ups', c_int32),
                 ('upsample_rates', c_int32 * 8), ('upsample_kernel_sizes', c_int32 * 8), ('n_kernels', c_int32),
                 ('resblock_kernel_sizes', c_int32 * 8), ('n_dil', c_int32), ('resblock_dilations', (c_int32 * 4) * 8),
-                ('weight_norm', c_int32)]
+                ('weight_norm', c_int32), ('use_nsf', c_int32), ('sample_rate', c_int32), ('harmonic_num', c_int32)]
+
+
+class PitchextCfg(Structure):
+    _fields_ = [(n, c_int32) for n in ('hidden_size', 'n_mel', 'conv_layers', 'predictor_layers', 'predictor_kernel', 'use_uv', 'n_pos')]
 
 
 class Schedule(Structure):
@@ -70,6 +74,11 @@ _SIGS = {
     'bsg_hifigan_create': (c_int32, [POINTER(c_void_p), POINTER(HifiganCfg), POINTER(c_void_p), c_int32, c_void_p]),
     'bsg_hifigan_destroy': (None, [c_void_p]),
     'bsg_hifigan_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_hifigan_forward_nsf': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_pitchext_n_weights': (c_int32, [POINTER(PitchextCfg)]),
+    'bsg_pitchext_create': (c_int32, [POINTER(c_void_p), POINTER(PitchextCfg), POINTER(c_void_p), c_int32, c_void_p, c_void_p]),
+    'bsg_pitchext_destroy': (None, [c_void_p]),
+    'bsg_pitchext_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_weight_norm_fold': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_gemm_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),

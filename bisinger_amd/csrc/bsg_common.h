@@ -60,6 +60,8 @@ struct GemmArgs {
   float alpha;           // v = (acc + bias) * alpha
   int alpha_ncols;       // 0: every column; n > 0: only columns < n are scaled (q part of a fused QKV projection)
   int act;
+  const float* post_scale_n;  // after the activation: v = v * post_scale_n[j] + post_shift_n[j] (eval-mode BatchNorm)
+  const float* post_shift_n;
   const float* R;        // residual added after the activation: v += R[b][i][j]
   int ldr;
   long long sR;

@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int ni = 0; ni < 2; ++ni) {
       const int col = bn + wn * 64 + ni * 32 + l31;
       const float bn_v = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
+      const float ps_v = (g.post_scale_n && col < g.N) ? g.post_scale_n[col] : 1.f;
+      const float pb_v = (g.post_scale_n && col < g.N) ? g.post_shift_n[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = bm + wm * 64 + mi * 32 + acc_row(r, lh);
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
           else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
           else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          if (g.post_scale_n) v = v * ps_v + pb_v;
           if (R) v += R[(long long)row * g.ldr + col];
           if (RS) v *= RS[row];
           C[(long long)row * g.ldc + col] = v;

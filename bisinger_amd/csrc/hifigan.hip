@@ -191,6 +191,12 @@ int launch_conv(const ConvArgs& a, int K, int B, hipStream_t st) {
 }  // namespace
 }  // namespace bsg
 
+namespace bsg {
+int nsf_launch_source(const float* f0, const float* rand_ini, const float* noise, const float* lin_w, const float* lin_b,
+                      float* sw_tmp, float* har, int B, int T, int hop, int NH, float sr, hipStream_t st);
+int nsf_launch_source_add(float* x, const float* har, const float* w, const float* bias, int B, int Cc, int Lx, long long Lh, int k,
+                          int stride, int pad, hipStream_t st);
+}
 using namespace bsg;
 
 #define TRY(expr)                  \
@@ -213,6 +219,11 @@ struct bsg_hifigan {
   std::vector<ConvW> rb1, rb2;            // [n_ups * n_kernels * n_dil]
   size_t cap = 0;                         // elements of one stage buffer
   float* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // NSF (use_pitch_embed): source merge Linear(harmonics+1 -> 1) and one noise conv per upsampling stage
+  float *src_w = nullptr, *src_b = nullptr;
+  std::vector<ConvW> noise_convs;
+  size_t cap_src = 0;
+  float *sw_tmp = nullptr, *har = nullptr;
 };
 
 extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
@@ -220,6 +231,8 @@ extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
   for (float* p : h->owned) (void)hipFree(p);
   for (float* p : h->buf)
     if (p) (void)hipFree(p);
+  if (h->sw_tmp) (void)hipFree(h->sw_tmp);
+  if (h->har) (void)hipFree(h->har);
   delete h;
 }
 
@@ -249,7 +262,7 @@ static int take_conv(bsg_hifigan* h, ConvW& c, const void* const*& w, int dim0, 
 
 extern "C" int bsg_hifigan_n_weights(const bsg_hifigan_cfg* c) {
   const int convs = 2 + c->n_ups + 2 * c->n_ups * c->n_kernels * c->n_dil;
-  return convs * (c->weight_norm ? 3 : 2);
+  return convs * (c->weight_norm ? 3 : 2) + (c->use_nsf ? 2 + 2 * c->n_ups : 0);
 }
 
 extern "C" int bsg_weight_norm_fold(const float* g, const float* v, float* w, int32_t dim0, int32_t inner, void* stream) {
@@ -265,6 +278,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   BSG_REQUIRE(cfg->n_ups > 0 && cfg->n_ups <= 8 && cfg->n_kernels > 0 && cfg->n_kernels <= 8 && cfg->n_dil > 0 && cfg->n_dil <= 4,
               "hifigan_create: bad stage counts");
   BSG_REQUIRE(cfg->n_mel > 0 && cfg->upsample_initial_channel >= (1 << cfg->n_ups), "hifigan_create: bad channel config");
+  BSG_REQUIRE(!cfg->use_nsf || (cfg->harmonic_num >= 0 && cfg->harmonic_num <= 31 && cfg->sample_rate > 0), "hifigan_create: bad NSF config");
   BSG_REQUIRE(n_weights == bsg_hifigan_n_weights(cfg), "hifigan_create: expected %d weight tensors, got %d",
               bsg_hifigan_n_weights(cfg), n_weights);
   for (int i = 0; i < cfg->n_ups; ++i) {
@@ -285,6 +299,27 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   int rc = BSG_OK;
   auto fail = [&](int code) { bsg_hifigan_destroy(h); return code; };
   const int C0 = cfg->upsample_initial_channel;
+  if (cfg->use_nsf) {
+    // m_source.l_linear.{weight [1,NH], bias [1]}, noise_convs.i.{weight [c,1,k], bias [c]} precede conv_pre (hifigan.py:111-132)
+    const int NH = cfg->harmonic_num + 1;
+    auto cp = [&](float** dst, const void* src, size_t n) -> int {
+      int r = hg_alloc(h, dst, n);
+      if (r != BSG_OK) return r;
+      if (hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("hifigan_create: copy failed"); return BSG_EHIP; }
+      return BSG_OK;
+    };
+    if ((rc = cp(&h->src_w, *w++, NH)) != BSG_OK) return fail(rc);
+    if ((rc = cp(&h->src_b, *w++, 1)) != BSG_OK) return fail(rc);
+    h->noise_convs.resize(cfg->n_ups);
+    for (int i = 0; i < cfg->n_ups; ++i) {
+      ConvW& c = h->noise_convs[i];
+      int stride = 1;
+      for (int j = i + 1; j < cfg->n_ups; ++j) stride *= cfg->upsample_rates[j];
+      c.cout = C0 >> (i + 1); c.cin = 1; c.k = i + 1 < cfg->n_ups ? 2 * stride : 1;
+      if ((rc = cp(&c.w, *w++, (size_t)c.cout * c.k)) != BSG_OK) return fail(rc);
+      if ((rc = cp(&c.b, *w++, c.cout)) != BSG_OK) return fail(rc);
+    }
+  }
   h->pre.cout = C0; h->pre.cin = cfg->n_mel; h->pre.k = 7;
   if ((rc = take_conv(h, h->pre, w, C0, cfg->n_mel * 7, st)) != BSG_OK) return fail(rc);
   h->ups.resize(cfg->n_ups);
@@ -321,7 +356,7 @@ static int run_conv(const ConvW& c, const float* x, float* y, int B, int L, int 
   return launch_conv(a, c.k, B, st);
 }
 
-extern "C" int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream) {
+static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream, const float* har, long long Lh) {
   BSG_REQUIRE(h && mel && wav && B > 0 && T > 0, "hifigan_forward: bad argument");
   BSG_REQUIRE(B <= 65535, "hifigan_forward: B=%d > 65535", B);
   hipStream_t st = (hipStream_t)stream;
@@ -358,6 +393,11 @@ extern "C" int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav,
     if (up.cout >= 16) hipLaunchKernelGGL(conv_transpose1d_kernel<16>, dim3(cdiv(Lout, 256), cdiv(up.cout, 16), B), dim3(256), 0, st, t);
     else hipLaunchKernelGGL(conv_transpose1d_kernel<8>, dim3(cdiv(Lout, 256), cdiv(up.cout, 8), B), dim3(256), 0, st, t);
     BSG_LAUNCH_CHECK();
+    if (har) {   // x = x + LayerNorm_C(relu(noise_conv_i(har_source)))                       (hifigan.py:154-160)
+      const ConvW& nc = h->noise_convs[i];
+      const int stride = i + 1 < c.n_ups ? nc.k / 2 : 1;
+      TRY(nsf_launch_source_add(t.y, har, nc.w, nc.b, B, nc.cout, Lout, Lh, nc.k, stride, i + 1 < c.n_ups ? stride / 2 : 0, st));
+    }
     float* xin = t.y;                       // stage input (after upsampling)
     float* sum = (xin == x ? xs : x);       // MRF running sum / stage output
     L = Lout;
@@ -379,4 +419,33 @@ extern "C" int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav,
   }
   TRY(run_conv(h->post, cur, wav, B, L, 1, 0.01f, nullptr, nullptr, 1.0f, 1, st));          // :169-171 (default slope 0.01)
   return BSG_OK;
+}
+
+extern "C" int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream) {
+  BSG_REQUIRE(h && !h->cfg.use_nsf, "hifigan_forward: this generator was created with the NSF source; call bsg_hifigan_forward_nsf");
+  return hifigan_run(h, mel, wav, B, T, stream, nullptr, 0);
+}
+
+extern "C" int bsg_hifigan_forward_nsf(bsg_hifigan* h, const float* mel, const float* f0, const float* rand_ini, const float* noise,
+                                       float* wav, int32_t B, int32_t T, void* stream) {
+  BSG_REQUIRE(h && h->cfg.use_nsf, "hifigan_forward_nsf: generator created without the NSF source");
+  BSG_REQUIRE(mel && f0 && rand_ini && noise && wav && B > 0 && T > 0, "hifigan_forward_nsf: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int hop = 1;
+  for (int i = 0; i < h->cfg.n_ups; ++i) hop *= h->cfg.upsample_rates[i];
+  const long long L = (long long)T * hop;
+  const int NH = h->cfg.harmonic_num + 1;
+  const size_t need = (size_t)B * L;
+  if (need > h->cap_src) {
+    BSG_HIP(hipStreamSynchronize(st));
+    if (h->sw_tmp) (void)hipFree(h->sw_tmp);
+    if (h->har) (void)hipFree(h->har);
+    h->sw_tmp = h->har = nullptr;
+    h->cap_src = 0;
+    BSG_HIP(hipMalloc((void**)&h->sw_tmp, need * NH * sizeof(float)));
+    BSG_HIP(hipMalloc((void**)&h->har, need * sizeof(float)));
+    h->cap_src = need;
+  }
+  TRY(nsf_launch_source(f0, rand_ini, noise, h->src_w, h->src_b, h->sw_tmp, h->har, B, T, hop, NH, (float)h->cfg.sample_rate, st));
+  return hifigan_run(h, mel, wav, B, T, stream, h->har, L);
 }

@@ -59,6 +59,14 @@ class _WNConv(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kw)
 
 
+class SourceModuleHnNSF(nn.Module):
+    """parallel_wavegan/models/source.py:352-399 (parameters: the harmonic merge Linear)."""
+
+    def __init__(self, harmonic_num):
+        super().__init__()
+        self.l_linear = nn.Linear(harmonic_num + 1, 1)
+
+
 class ResBlock1(nn.Module):
     """hifigan.py:30-52 (parameters only)."""
 
@@ -76,14 +84,25 @@ class HifiGanGenerator(nn.Module):
     def __init__(self, h, c_out=1):
         super().__init__()
         self.h = h
-        if h.get('use_pitch_embed'):
-            raise NotImplementedError('NSF source (use_pitch_embed) is SURVEY.md §8 row f2: not built')
+        self.use_nsf = bool(h.get('use_pitch_embed'))
         if str(h['resblock']) != '1':
             raise NotImplementedError("only resblock: '1' (TB/configs/tts/hifigan.yaml:3) is built")
         assert c_out == 1
         self.num_kernels = len(h['resblock_kernel_sizes'])
         self.num_upsamples = len(h['upsample_rates'])
         C0 = h['upsample_initial_channel']
+        if self.use_nsf:      # hifigan.py:111-132: SourceModuleHnNSF(harmonic_num=8) + one noise conv per stage
+            self.harmonic_num = 8
+            self.m_source = SourceModuleHnNSF(self.harmonic_num)
+            self.noise_convs = nn.ModuleList()
+            rates = list(h['upsample_rates'])
+            for i in range(len(rates)):
+                c_cur = C0 // (2 ** (i + 1))
+                if i + 1 < len(rates):
+                    s = int(np.prod(rates[i + 1:]))
+                    self.noise_convs.append(nn.Conv1d(1, c_cur, kernel_size=s * 2, stride=s, padding=s // 2))
+                else:
+                    self.noise_convs.append(nn.Conv1d(1, c_cur, kernel_size=1))
         self.conv_pre = _WNConv((C0, 80, 7), C0)
         self.ups = nn.ModuleList()
         for i, (u, k) in enumerate(zip(h['upsample_rates'], h['upsample_kernel_sizes'])):
@@ -140,6 +159,9 @@ class HifiGanGenerator(nn.Module):
             for m, dd in enumerate(d):
                 cfg.resblock_dilations[j][m] = dd
         cfg.weight_norm = 0 if states.pop() else 1
+        cfg.use_nsf = int(self.use_nsf)
+        cfg.sample_rate = int(h.get('audio_sample_rate', 22050))
+        cfg.harmonic_num = self.harmonic_num if self.use_nsf else 0
         lib = _lib.load()
         assert lib.bsg_hifigan_n_weights(byref(cfg)) == len(ws), (lib.bsg_hifigan_n_weights(byref(cfg)), len(ws))
         arr = (c_void_p * len(ws))(*[p.data_ptr() for p in ws])
@@ -162,16 +184,35 @@ class HifiGanGenerator(nn.Module):
             pass
 
     @torch.no_grad()
-    def forward(self, x, f0=None):
-        """x [B,80,T] -> [B,1,T*hop]   (hifigan.py:144-173)."""
-        if f0 is not None:
-            raise NotImplementedError('NSF source (f0) is SURVEY.md §8 row f2: not built')
+    def forward(self, x, f0=None, rand_ini=None, noise=None, seed=0):
+        """x [B,80,T] (, f0 [B,T]) -> [B,1,T*hop]   (hifigan.py:144-173).
+        NSF draws (source.py:53, :130): supplied (``rand_ini`` [B,9], ``noise`` [B,T*hop,9]) or generated
+        (torch.rand for the 9 initial phases, the library's Philox stream for the noise)."""
         hd = self.handle()
         x = x.contiguous().float()
         B, M, T = x.shape
         assert M == 80
         hop = int(np.prod(self.h['upsample_rates']))
         y = torch.empty(B, 1, T * hop, device=x.device)
+        lib = _lib.load()
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().bsg_hifigan_forward(hd, _lib.ptr(x), _lib.ptr(y), B, T, _lib.stream_ptr()), 'bsg_hifigan_forward')
+            if self.use_nsf:
+                if f0 is None:
+                    raise _lib.BsgError('this generator has the NSF source (use_pitch_embed): f0 is required')
+                NH = self.harmonic_num + 1
+                f0 = f0.to(x.device, torch.float32).contiguous()
+                if rand_ini is None:
+                    rand_ini = torch.rand(B, NH, device=x.device, generator=torch.Generator(device=x.device).manual_seed(seed))
+                if noise is None:
+                    noise = torch.empty(B, T * hop, NH, device=x.device)
+                    _lib.check(lib.bsg_philox_normal(_lib.ptr(noise), noise.numel(), seed, 0x4E5346, 0, _lib.stream_ptr()), 'bsg_philox_normal')
+                rand_ini = rand_ini.to(x.device, torch.float32).contiguous()
+                noise = noise.to(x.device, torch.float32).contiguous()
+                assert tuple(rand_ini.shape) == (B, NH) and tuple(noise.shape) == (B, T * hop, NH) and tuple(f0.shape) == (B, T)
+                _lib.check(lib.bsg_hifigan_forward_nsf(hd, _lib.ptr(x), _lib.ptr(f0), _lib.ptr(rand_ini), _lib.ptr(noise), _lib.ptr(y),
+                                                       B, T, _lib.stream_ptr()), 'bsg_hifigan_forward_nsf')
+            else:
+                if f0 is not None:
+                    raise _lib.BsgError('f0 given but this generator was built without use_pitch_embed')
+                _lib.check(lib.bsg_hifigan_forward(hd, _lib.ptr(x), _lib.ptr(y), B, T, _lib.stream_ptr()), 'bsg_hifigan_forward')
         return y

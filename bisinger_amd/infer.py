@@ -88,8 +88,8 @@ class BaseSVSInfer:
         """c [B,T,80] -> [1, B*T*hop] (a-*.py:209-218; the reference flattens, B is 1 there)."""
         c = c.transpose(2, 1)
         f0 = kwargs.get('f0')
-        if f0 is not None and hparams.get('use_nsf') and self.vocoder.h.get('use_pitch_embed'):
-            raise NotImplementedError('NSF-HiFiGAN is SURVEY.md §8 row f2: not built')
+        if f0 is not None and hparams.get('use_nsf'):
+            return self.vocoder(c, f0, seed=int(kwargs.get('seed', hparams.get('seed', 1234)))).view(-1)[None]
         return self.vocoder(c).view(-1)[None]
 
     # ------------------------------------------------------------------ front end (tensor level)
@@ -199,8 +199,11 @@ class DiffSingerE2EInfer(BaseSVSInfer):
                                   spec_max=hparams['spec_max'])
         model.eval()
         load_ckpt(model, hparams['work_dir'], 'model')
-        if hparams.get('pe_enable') and hparams.get('use_nsf') and hparams.get('vocoder_use_nsf', False):
-            raise NotImplementedError('PitchExtractor + NSF vocoder are SURVEY.md §8 row f2: not built')
+        if hparams.get('pe_enable'):
+            from .pe import PitchExtractor
+            self.pe = PitchExtractor().to(self.device)
+            load_ckpt(self.pe, hparams['pe_ckpt'], 'model', strict=True)
+            self.pe.eval()
         return model
 
     def _generate(self, sample, seed=None):
@@ -213,7 +216,9 @@ class DiffSingerE2EInfer(BaseSVSInfer):
     def forward_model(self, inp, seed=None):
         sample = self.input_to_batch(inp)
         output = self._generate(sample, seed)
-        wav_out = self.run_vocoder(output['mel_out'])
+        mel_out = output['mel_out']
+        f0_pred = self.pe(mel_out)['f0_denorm_pred'] if hparams.get('pe_enable') else None      # a-*.py:629-632
+        wav_out = self.run_vocoder(mel_out, f0=f0_pred)
         return wav_out.cpu().numpy()[0]
 
     def forward_batch(self, items, seed=None):

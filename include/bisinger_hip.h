@@ -203,7 +203,7 @@ int bsg_fs2midi_decode(bsg_fs2midi* h, const float* enc_out, const int64_t* mel2
 /* ------------------------------------------------------------------------------------------------
  * HiFi-GAN generator forward (mel -> waveform).
  * Stands behind HifiGanGenerator(h)(x [B,80,T]) -> [B,1,T*prod(upsample_rates)]  (modules/hifigan/hifigan.py:104-173)
- * as used by HifiGAN.spec2wav (vocoders/hifigan.py:55-69).  NSF source (use_pitch_embed) is not built.
+ * as used by HifiGAN.spec2wav (vocoders/hifigan.py:55-69).  The NSF variant (use_pitch_embed) is bsg_hifigan_forward_nsf below.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct bsg_hifigan bsg_hifigan;
 
@@ -218,6 +218,9 @@ typedef struct {
   int32_t n_dil;                      /* dilations per ResBlock1 (3)                                     */
   int32_t resblock_dilations[8][4];
   int32_t weight_norm;                /* 1: weights come as (bias, weight_g, weight_v) triples           */
+  int32_t use_nsf;                    /* h['use_pitch_embed']: NSF harmonic source (hifigan.py:111-132)   */
+  int32_t sample_rate;                /* h['audio_sample_rate'] (NSF only)                               */
+  int32_t harmonic_num;               /* 8 (hifigan.py:112)                                              */
 } bsg_hifigan_cfg;
 
 int bsg_hifigan_n_weights(const bsg_hifigan_cfg* cfg);
@@ -230,6 +233,32 @@ int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg, const void
 void bsg_hifigan_destroy(bsg_hifigan* h);
 /* mel [B,n_mel,T] -> wav [B,1,T*prod(upsample_rates)].  May grow the workspace when B*T grows. */
 int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream);
+/* NSF-HiFiGAN: with cfg->use_nsf the weight list starts with m_source.l_linear.{weight,bias}
+ * and noise_convs.i.{weight,bias} (state_dict order).  f0 [B,T] (Hz, 0 = unvoiced); the reference's two random draws
+ * are supplied: rand_ini [B,harmonic_num+1] uniform[0,1) (torch.rand, source.py:53; column 0 is ignored) and
+ * noise [B, T*hop, harmonic_num+1] N(0,1) (torch.randn_like, source.py:130). */
+int bsg_hifigan_forward_nsf(bsg_hifigan* h, const float* mel, const float* f0, const float* rand_ini, const float* noise,
+                            float* wav, int32_t B, int32_t T, void* stream);
+
+/* PitchExtractor: mel [B,T,n_mel] -> pitch_pred [B,T,2] (may be NULL) and f0_denorm_pred [B,T]
+ * (modules/fastspeech/pe.py:120-149; pitch_norm 'log', pitch_type 'frame').  dev_weights in PitchExtractor.state_dict()
+ * order; pos_table [n_pos,256] = SinusoidalPositionalEmbedding table (row 0 zero), built by the host. */
+typedef struct bsg_pitchext bsg_pitchext;
+typedef struct {
+  int32_t hidden_size;        /* 256 */
+  int32_t n_mel;              /* 80  */
+  int32_t conv_layers;        /* 2   (pe.py:121)                  */
+  int32_t predictor_layers;   /* 5   (pe.py:134)                  */
+  int32_t predictor_kernel;   /* hparams['predictor_kernel'] = 5  */
+  int32_t use_uv;             /* hparams['pitch_type']=='frame' and hparams['use_uv'] */
+  int32_t n_pos;
+} bsg_pitchext_cfg;
+int bsg_pitchext_n_weights(const bsg_pitchext_cfg* cfg);
+int bsg_pitchext_create(bsg_pitchext** out, const bsg_pitchext_cfg* cfg, const void* const* dev_weights, int32_t n_weights,
+                        const float* pos_table, void* stream);
+void bsg_pitchext_destroy(bsg_pitchext* h);
+int bsg_pitchext_forward(bsg_pitchext* h, const float* mel, float* pitch_pred, float* f0, int32_t B, int32_t T, void* stream);
+
 /* w[d0,...] = g[d0] * v[d0,...] / ||v[d0,...]||   (remove_weight_norm, hifigan.py:175-182) */
 int bsg_weight_norm_fold(const float* g, const float* v, float* w, int32_t dim0, int32_t inner, void* stream);
 
