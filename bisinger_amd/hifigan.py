@@ -187,7 +187,7 @@ class HifiGanGenerator(nn.Module):
     def forward(self, x, f0=None, rand_ini=None, noise=None, seed=0):
         """x [B,80,T] (, f0 [B,T]) -> [B,1,T*hop]   (hifigan.py:144-173).
         NSF draws (source.py:53, :130): supplied (``rand_ini`` [B,9], ``noise`` [B,T*hop,9]) or generated
-        (torch.rand for the 9 initial phases, the library's Philox stream for the noise)."""
+        (numpy RandomState(seed) for the 9 initial phases, the library's Philox stream 0x4E5346 for the noise)."""
         hd = self.handle()
         x = x.contiguous().float()
         B, M, T = x.shape
@@ -201,8 +201,8 @@ class HifiGanGenerator(nn.Module):
                     raise _lib.BsgError('this generator has the NSF source (use_pitch_embed): f0 is required')
                 NH = self.harmonic_num + 1
                 f0 = f0.to(x.device, torch.float32).contiguous()
-                if rand_ini is None:
-                    rand_ini = torch.rand(B, NH, device=x.device, generator=torch.Generator(device=x.device).manual_seed(seed))
+                if rand_ini is None:       # 9 initial phases per utterance: host draw, reproducible from the seed
+                    rand_ini = torch.from_numpy(np.random.RandomState(seed & 0x7FFFFFFF).uniform(size=(B, NH)).astype(np.float32))
                 if noise is None:
                     noise = torch.empty(B, T * hop, NH, device=x.device)
                     _lib.check(lib.bsg_philox_normal(_lib.ptr(noise), noise.numel(), seed, 0x4E5346, 0, _lib.stream_ptr()), 'bsg_philox_normal')

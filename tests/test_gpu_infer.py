@@ -92,3 +92,63 @@ def test_e2e_infer_once_and_batch(workdir, hifigan_sd, sd_spec):
         assert maxabs(w, want[i, 0, :n]) <= 2e-3
     with pytest.raises(NotImplementedError):
         infer.preprocess_input({'text': 'AP 你好 AP', 'notes': 'rest | C4 | rest', 'notes_duration': '0.1 | 0.2 | 0.1'}, 'word')
+
+
+def test_e2e_with_pitch_extractor_and_nsf_vocoder(workdir, sd_spec):
+    """pe_enable + use_nsf (the shipped M4Singer set-up, base.yaml:25,62): mel -> PitchExtractor f0 -> NSF-HiFiGAN."""
+    import json as _json
+    from collections import OrderedDict
+    from bisinger_amd.hparams import hparams, set_hparams
+    from bisinger_amd.infer import DiffSingerE2EInfer
+    from oracle import fs2 as ofs2, melgen as omg, nsf as onsf, pe as ope
+    os.makedirs('checkpoints/pe')
+    os.makedirs('checkpoints/nsf')
+    spec = OrderedDict((k, tuple(s)) for k, s in sd_spec['PitchExtractor'])
+    pw = synth.synth_state_dict(spec, seed=11)
+    for k in spec:
+        if k.endswith('running_var'):
+            pw[k] = (0.5 + np.abs(pw[k]) * 5).astype(np.float32)
+    pe_sd = {k: torch.from_numpy(v) for k, v in pw.items()}
+    for k, s_ in spec.items():
+        if k not in pe_sd:
+            pe_sd[k] = torch.zeros(s_, dtype=torch.long if k.endswith('num_batches_tracked') else torch.float32)
+    torch.save({'state_dict': {'model.' + k: v for k, v in pe_sd.items()}}, 'checkpoints/pe/model_ckpt_steps_10.ckpt')
+    nspec = OrderedDict((k, tuple(s)) for k, s in sd_spec['HifiGanGenerator_nsf_weight_norm'])
+    nsd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(nspec, seed=13).items()}
+    torch.save({'state_dict': {'model_gen': nsd}}, 'checkpoints/nsf/model_ckpt_steps_7.ckpt')
+    hcfg = yaml.safe_load(open(f'{ROOT}/bisinger_amd/configs/hifigan.yaml'))
+    hcfg['use_pitch_embed'] = True
+    yaml.safe_dump(hcfg, open('checkpoints/nsf/config.yaml', 'w'))
+    cfg = yaml.safe_load(open('exp.yaml'))
+    cfg.update(vocoder_ckpt='checkpoints/nsf', pe_enable=True, pe_ckpt='checkpoints/pe', use_nsf=True, pitch_type='frame',
+               use_uv=True, pitch_norm='log')
+    yaml.safe_dump(cfg, open('exp2.yaml', 'w'))
+    set_hparams('exp2.yaml', exp_name='exp_diff_e2e', print_hparams=False, hparams_str='seed=99')
+    infer = DiffSingerE2EInfer(hparams)
+    assert infer.vocoder.use_nsf and hasattr(infer, 'pe')
+    inp = _item(8, 5)
+    wav = infer.infer_once(inp)
+    wav2 = infer.infer_once(inp)
+    assert wav.ndim == 1 and np.isfinite(wav).all() and np.array_equal(wav, wav2)
+    # oracle pipeline with the same draws
+    item = infer.preprocess_input(inp, 'phoneme')
+    sample = infer.input_to_batch(item)
+    sd = {k: v.detach().cpu() for k, v in infer.model.state_dict().items()}
+    oin = {'txt_tokens': sample['txt_tokens'].cpu(), 'spk_embed': sample['spk_ids'].cpu(), 'pitch_midi': sample['pitch_midi'].cpu(),
+           'midi_dur': sample['midi_dur'].cpu(), 'is_slur': sample['is_slur'].cpu(), 'lang': sample['lang'].cpu(),
+           'speechsing': sample['speechsing'].cpu()}
+    f = ofs2.fs2_forward(sd, oin)
+    B, T = f['mel2ph'].shape
+    n = B * 80 * T
+    noise = np.stack([synth.philox_normal(99, 0, n)] + [synth.philox_normal(99, i + 1, n) for i in reversed(range(100))])
+    r = omg.mel_gen(sd, oin, torch.from_numpy(noise.reshape(101, B, 80, T)), fs2_out=f)
+    pe_cpu = {k: v.detach().cpu() for k, v in infer.pe.state_dict().items()}
+    f0 = ope.pitch_extractor_forward(pe_cpu, r['mel_out'])['f0_denorm_pred']
+    got_f0 = infer.pe(infer._generate(sample, None)['mel_out'])['f0_denorm_pred'].cpu()
+    # voiced/unvoiced decisions near 0 may flip with rounding: compare where both agree on voicing
+    agree = (f0 > 0) == (got_f0 > 0)
+    assert agree.float().mean() > 0.9
+    ri = torch.from_numpy(np.random.RandomState(99).uniform(size=(B, 9)).astype(np.float32))
+    nz = torch.from_numpy(synth.philox_normal(99, 0x4E5346, B * T * 256 * 9).reshape(B, T * 256, 9))
+    want = onsf.nsf_hifigan_forward(nsd, r['mel_out'].transpose(1, 2), got_f0, ri, nz, hcfg)
+    assert maxabs(wav, want.reshape(-1)) <= 5e-3
