@@ -57,6 +57,13 @@ _SIGS = {
     'bsg_ddpm_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_void_p, c_uint64, c_int32, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_void_p]),
     'bsg_plms_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_ddpm_step': (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(Schedule), c_int32, c_int64, c_uint64, c_uint64, c_void_p]),
+    'bsg_fftden_n_weights': (c_int32, [c_int32]),
+    'bsg_fftden_create': (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p), c_int32,
+                                    c_void_p, c_void_p, c_void_p]),
+    'bsg_fftden_destroy': (None, [c_void_p]),
+    'bsg_fftden_prepare': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'bsg_fftden_forward': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_philox_normal': (c_int32, [c_void_p, c_int64, c_uint64, c_uint32, c_uint64, c_void_p]),
     'bsg_mel_start': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_mel_finish': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -57,6 +57,7 @@ struct GemmArgs {
   long long sTapB;       // B offset per tap
   const float* bias_m;   // per output row
   const float* bias_n;   // per output column
+  long long sBiasN;      // batch stride of bias_n (0: shared)
   float alpha;           // v = (acc + bias) * alpha
   int alpha_ncols;       // 0: every column; n > 0: only columns < n are scaled (q part of a fused QKV projection)
   int act;

@@ -1072,6 +1072,18 @@ extern "C" int bsg_mel_start(const float* fs2_mel, const float* spec_min, const 
   return BSG_OK;
 }
 
+extern "C" int bsg_ddpm_step(float* x, const float* eps, const float* noise, const bsg_schedule* s, int32_t t, int64_t n,
+                             uint64_t seed, uint64_t offset, void* stream) {
+  TRY(check_schedule(s, "ddpm_step", false));
+  BSG_REQUIRE(x && eps && n > 0 && n % 4 == 0 && offset % 4 == 0 && t >= 0 && t < s->num_timesteps, "ddpm_step: bad argument");
+  StepCoef c{s->sqrt_recip_alphas_cumprod[t], s->sqrt_recipm1_alphas_cumprod[t], s->posterior_mean_coef1[t],
+             s->posterior_mean_coef2[t], s->sigma[t]};
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, noise, c, (long long)(n / 4),
+                     (unsigned long long)seed, (unsigned)(t + 1), (unsigned long long)(offset / 4));
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
 extern "C" int bsg_philox_normal(float* x, int64_t n, uint64_t seed, uint32_t stream_id, uint64_t offset, void* stream) {
   BSG_REQUIRE(x && n > 0 && n % 4 == 0 && offset % 4 == 0, "philox_normal: n=%lld offset=%llu must be multiples of 4", (long long)n, (unsigned long long)offset);
   hipLaunchKernelGGL(philox_fill_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)(n / 4),

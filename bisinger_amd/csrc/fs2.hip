@@ -647,3 +647,171 @@ extern "C" int bsg_fs2midi_decode(bsg_fs2midi* h, const float* enc_out, const in
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
+
+
+// ================================================================================================
+// the `FFT` candidate denoiser (DIFF_DECODERS['fft'], usr/diff/candidate_decoder.py:39-100):
+// input projection -> concat[x, cond, step embedding] -> Linear(3C -> H) -> FastspeechDecoder stack -> Linear(H -> M).
+// The concat-Linear is split by columns: the cond part is step-invariant (hoisted to prepare), the step part is one
+// vector per utterance, so per call only x * W_x^T runs over all frames.  Reuses fft_stack() of the FS2 decoder.
+// ================================================================================================
+namespace bsg {
+namespace {
+// in [B][R][Cc] -> out [B][Cc][R]
+__global__ void transpose_brc_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < Cc) ? in[((long long)b * R + r) * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < Cc && r < R) out[((long long)b * Cc + c) * R + r] = tile[tx][j];
+  }
+}
+__global__ void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx, float* __restrict__ out, int n,
+                                   int width, int n_rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * width) return;
+  long long r = idx[i / width];
+  r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+  out[i] = table[r * width + (i % width)];
+}
+}  // namespace
+}  // namespace bsg
+
+struct bsg_fftden {
+  bsg_fs2midi* core = nullptr;   // owns weights + the FFT-stack workspaces
+  int M = 0, S = 0, n_pos = 0, ksz = 9;
+  std::vector<FftLayerW> layers;
+  float *alpha, *lnw, *lnb, *in_w, *in_b, *mel_w, *mel_b, *gdi_w, *gdi_b, *dtab, *table;
+  size_t cap = 0;
+  int B = 0, T = 0;
+  float *condpart = nullptr, *xT = nullptr, *xp = nullptr, *te = nullptr, *tvec = nullptr, *mel = nullptr;
+};
+
+extern "C" void bsg_fftden_destroy(bsg_fftden* h) {
+  if (!h) return;
+  float* ws[] = {h->condpart, h->xT, h->xp, h->te, h->tvec, h->mel};
+  for (float* p : ws)
+    if (p) (void)hipFree(p);
+  bsg_fs2midi_destroy(h->core);
+  delete h;
+}
+
+extern "C" int bsg_fftden_n_weights(int32_t n_layers) { return 2 + 10 * n_layers + 2 + 2 + 4 + 2 + 2; }
+
+extern "C" int bsg_fftden_create(bsg_fftden** out, int32_t in_dims, int32_t n_layers, int32_t num_heads, int32_t ffn_kernel,
+                                 int32_t max_steps, int32_t n_pos, const void* const* w, int32_t n_weights, const float* step_table,
+                                 const float* pos_table, void* stream) {
+  BSG_REQUIRE(out && w && step_table && pos_table, "fftden_create: null argument");
+  BSG_REQUIRE(in_dims > 0 && in_dims % 4 == 0 && n_layers > 0 && num_heads > 0 && H % num_heads == 0 && (H / num_heads) % 4 == 0 &&
+                  ffn_kernel % 2 == 1 && max_steps > 0 && n_pos > 1, "fftden_create: bad config");
+  BSG_REQUIRE(n_weights == bsg_fftden_n_weights(n_layers), "fftden_create: expected %d weight tensors, got %d", bsg_fftden_n_weights(n_layers), n_weights);
+  for (int i = 0; i < n_weights; ++i) BSG_REQUIRE(w[i] != nullptr, "fftden_create: weight %d is null", i);
+  hipStream_t st = (hipStream_t)stream;
+  bsg_fftden* h = new bsg_fftden();
+  h->core = new bsg_fs2midi();
+  h->core->cfg = bsg_fs2midi_cfg{};
+  h->core->cfg.num_heads = num_heads;
+  h->M = in_dims; h->S = max_steps; h->n_pos = n_pos; h->ksz = ffn_kernel;
+  bsg_fs2midi* c = h->core;
+  auto fail = [&](int rc) { bsg_fftden_destroy(h); return rc; };
+  int rc, i = 0;
+  // FFT.state_dict(): pos_embed_alpha, embed_positions._float_tensor, layers.*, layer_norm.{w,b}, input_projection.{w,b},
+  // mlp.0.{w,b}, mlp.2.{w,b}, get_mel_out.{w,b}, get_decode_inp.{w,b}
+  if ((rc = fs2_copy(c, &h->alpha, w[i++], 1, st)) != BSG_OK) return fail(rc);
+  i++;
+  if ((rc = load_fft_layers(c, h->layers, w + i, n_layers, ffn_kernel, st)) != BSG_OK) return fail(rc);
+  i += 10 * n_layers;
+  if ((rc = fs2_copy(c, &h->lnw, w[i++], H, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->lnb, w[i++], H, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->in_w, w[i++], (size_t)H * in_dims, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->in_b, w[i++], H, st)) != BSG_OK) return fail(rc);
+  const float *m0w = (const float*)w[i], *m0b = (const float*)w[i + 1], *m2w = (const float*)w[i + 2], *m2b = (const float*)w[i + 3];
+  i += 4;
+  if ((rc = fs2_copy(c, &h->mel_w, w[i++], (size_t)in_dims * H, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->mel_b, w[i++], in_dims, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->gdi_w, w[i++], (size_t)H * 3 * H, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->gdi_b, w[i++], H, st)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_copy(c, &h->table, pos_table, (size_t)n_pos * H, st)) != BSG_OK) return fail(rc);
+  // step-embedding MLP tabulated for every timestep (candidate_decoder.py:60-62)
+  float* hid = nullptr;
+  if ((rc = fs2_alloc(c, &hid, (size_t)max_steps * 4 * H)) != BSG_OK) return fail(rc);
+  if ((rc = fs2_alloc(c, &h->dtab, (size_t)max_steps * H)) != BSG_OK) return fail(rc);
+  if ((rc = linear(step_table, m0w, m0b, hid, max_steps, 4 * H, H, ACT_MISH, nullptr, nullptr, st)) != BSG_OK) return fail(rc);
+  if ((rc = linear(hid, m2w, m2b, h->dtab, max_steps, H, 4 * H, ACT_NONE, nullptr, nullptr, st)) != BSG_OK) return fail(rc);
+  if (hipStreamSynchronize(st) != hipSuccess) { set_error("fftden_create: sync failed"); return fail(BSG_EHIP); }
+  *out = h;
+  return BSG_OK;
+}
+
+extern "C" int bsg_fftden_prepare(bsg_fftden* h, const float* cond, int32_t B, int32_t T, void* stream) {
+  BSG_REQUIRE(h && cond && B > 0 && T > 0 && T < h->n_pos, "fftden_prepare: bad argument (T=%d)", T);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t rows = (size_t)B * T;
+  if (rows > h->cap) {
+    BSG_HIP(hipStreamSynchronize(st));
+    float** bufs[] = {&h->condpart, &h->xT, &h->xp, &h->te, &h->tvec, &h->mel};
+    for (float** p : bufs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    h->cap = 0;
+    BSG_HIP(hipMalloc((void**)&h->condpart, rows * H * sizeof(float)));
+    BSG_HIP(hipMalloc((void**)&h->xT, rows * H * sizeof(float)));
+    BSG_HIP(hipMalloc((void**)&h->xp, rows * H * sizeof(float)));
+    BSG_HIP(hipMalloc((void**)&h->te, rows * H * sizeof(float)));      // [B][H] used; rows >= B for any later (B,T) that fits
+    BSG_HIP(hipMalloc((void**)&h->tvec, rows * H * sizeof(float)));
+    BSG_HIP(hipMalloc((void**)&h->mel, rows * h->M * sizeof(float)));
+    h->cap = rows;
+  }
+  TRY(ensure_ws(h->core, rows, (size_t)B * h->core->cfg.num_heads * T * T, st));
+  h->B = B; h->T = T;
+  // cond [B][H][T] -> [B*T][H]; condpart = cond_t * W[:, C:2C]^T                           (candidate_decoder.py:63-70)
+  hipLaunchKernelGGL(transpose_brc_kernel, dim3(cdiv(T, 32), cdiv(H, 32), B), dim3(256), 0, st, cond, h->xT, H, T);
+  BSG_LAUNCH_CHECK();
+  GemmArgs g{};
+  g.A = h->xT; g.B = h->gdi_w + H; g.C = h->condpart; g.M = (int)rows; g.N = H; g.K = H; g.lda = H; g.ldb = 3 * H; g.ldc = H;
+  g.trans_b = 1; g.taps = 1; g.alpha = 1.f; g.batch = 1;
+  return launch_gemm(g, st);
+}
+
+extern "C" int bsg_fftden_forward(bsg_fftden* h, const float* x, const int64_t* t, float* eps, int32_t B, int32_t T, void* stream) {
+  BSG_REQUIRE(h && x && t && eps, "fftden_forward: null argument");
+  BSG_REQUIRE(h->cap > 0 && h->B == B && h->T == T, "fftden_forward: (B=%d,T=%d) does not match bsg_fftden_prepare (B=%d,T=%d)", B, T, h->B, h->T);
+  hipStream_t st = (hipStream_t)stream;
+  const long long rows = (long long)B * T;
+  bsg_fs2midi* c = h->core;
+  // x [B][M][T] -> [B*T][M]; xp = input_projection                                        (:57-58)
+  hipLaunchKernelGGL(transpose_brc_kernel, dim3(cdiv(T, 32), cdiv(h->M, 32), B), dim3(256), 0, st, x, h->xT, h->M, T);
+  BSG_LAUNCH_CHECK();
+  TRY(linear(h->xT, h->in_w, h->in_b, h->xp, rows, H, h->M, ACT_NONE, nullptr, nullptr, st));
+  // step part: tvec[b] = mlp(emb(t_b)) * W[:, 2C:3C]^T + bias                               (:59-66)
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(B * H, 256)), dim3(256), 0, st, (const float*)h->dtab, (const long long*)t, h->te, B, H, h->S);
+  BSG_LAUNCH_CHECK();
+  {
+    GemmArgs g{};
+    g.A = h->te; g.B = h->gdi_w + 2 * H; g.C = h->tvec; g.M = B; g.N = H; g.K = H; g.lda = H; g.ldb = 3 * H; g.ldc = H; g.trans_b = 1;
+    g.taps = 1; g.bias_n = h->gdi_b; g.alpha = 1.f; g.batch = 1;
+    TRY(launch_gemm(g, st));
+  }
+  float* xs = c->w_x;
+  {
+    GemmArgs g{};   // decoder_inp = xp W_x^T + condpart + tvec[b]
+    g.A = h->xp; g.B = h->gdi_w; g.C = xs; g.M = T; g.N = H; g.K = H; g.lda = H; g.ldb = 3 * H; g.ldc = H; g.trans_b = 1; g.taps = 1;
+    g.bias_n = h->tvec; g.sBiasN = H; g.alpha = 1.f; g.R = h->condpart; g.ldr = H; g.sR = (long long)T * H; g.batch = B;
+    g.sA = (long long)T * H; g.sC = (long long)T * H;
+    TRY(launch_gemm(g, st));
+  }
+  const dim3 rg(cdiv(rows, 4)), rb(256);
+  hipLaunchKernelGGL(decoder_positions_kernel, dim3(B), dim3(64), 0, st, (const float*)xs, c->w_pos, c->w_keep, T);
+  BSG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(decoder_entry_kernel, rg, rb, 0, st, xs, (const int*)c->w_pos, h->table, h->alpha, c->w_keep, rows, h->n_pos);
+  BSG_LAUNCH_CHECK();
+  TRY(fft_stack(c, h->layers, h->lnw, h->lnb, h->ksz, xs, c->w_keep, B, T, st));
+  TRY(linear(xs, h->mel_w, h->mel_b, h->mel, rows, h->M, H, ACT_NONE, nullptr, nullptr, st));       // get_mel_out (:98)
+  hipLaunchKernelGGL(transpose_brc_kernel, dim3(cdiv(h->M, 32), cdiv(T, 32), B), dim3(256), 0, st, (const float*)h->mel, eps, T, h->M);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}

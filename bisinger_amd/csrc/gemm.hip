@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int col = bn + wn * 64 + ni * 32 + l31;
-      const float bn_v = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
+      const float bn_v = (g.bias_n && col < g.N) ? g.bias_n[(long long)zo * g.sBiasN + col] : 0.f;
       const float ps_v = (g.post_scale_n && col < g.N) ? g.post_scale_n[col] : 1.f;
       const float pb_v = (g.post_scale_n && col < g.N) ? g.post_shift_n[col] : 0.f;
 #pragma unroll

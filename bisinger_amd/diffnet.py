@@ -172,7 +172,13 @@ class DiffNet(nn.Module):
         return out
 
 
-# usr/diffsinger_task.py:24-29.  ('fft' = SURVEY.md §8 row f4, not built.)
+def _fft(hp):
+    from .candidate_decoder import FFT
+    return FFT(hp['hidden_size'], hp['dec_layers'], hp['dec_ffn_kernel_size'], hp['num_heads'])
+
+
+# usr/diffsinger_task.py:24-29
 DIFF_DECODERS = {
     'wavenet': lambda hp: DiffNet(hp['audio_num_mel_bins']),
+    'fft': _fft,
 }

@@ -113,6 +113,21 @@ class GaussianDiffusion(nn.Module):
         s, _keep = self._schedule()
         h = self.denoise_fn._h
         t = self.K_step
+        from .diffnet import DiffNet
+        if not isinstance(self.denoise_fn, DiffNet):
+            # any other denoise_fn (DIFF_DECODERS['fft']): the reference loop (:265-267) step by step
+            if hparams.get('pndm_speedup'):
+                raise NotImplementedError('PLMS is fused with the wavenet denoiser only')
+            n = t if n_steps is None else n_steps
+            Bt = B if B_total is None else B_total
+            with torch.cuda.device(x.device):
+                for k in range(n):
+                    i = t - 1 - k
+                    eps = self.denoise_fn(x, torch.full((B,), i, device=x.device, dtype=torch.long), cond)
+                    nz = None if noise is None else noise[k].contiguous()
+                    _lib.check(lib.bsg_ddpm_step(_lib.ptr(x), _lib.ptr(eps.contiguous()), _lib.ptr(nz), byref(s), i, x.numel(), seed,
+                                                 row0 * M * T, _lib.stream_ptr()), 'bsg_ddpm_step')
+            return x
         with torch.cuda.device(x.device):
             if hparams.get('pndm_speedup'):
                 _lib.check(lib.bsg_plms_sample(h, byref(s), _lib.ptr(x), t, int(hparams['pndm_speedup']), B, T,

@@ -110,6 +110,11 @@ int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float
                     int32_t t_start, int32_t n_steps, int32_t B, int32_t T, int32_t row0,
                     int32_t B_total, void* stream);
 
+/* One ancestral update given eps (p_sample :159-166 without the denoiser call), for denoisers that are not a
+ * bsg_diffnet (the FFT candidate below): x, eps, noise (or NULL = Philox stream of timestep t) are n floats. */
+int bsg_ddpm_step(float* x, const float* eps, const float* noise, const bsg_schedule* s, int32_t t, int64_t n,
+                  uint64_t seed, uint64_t offset, void* stream);
+
 /* x[0..n) <- N(0,1) from the same Philox4x32-10 stream family: element i = lane i%4 of counter
  * ((offset+i)/4, stream_id, 0, 0), key = seed (x_T under gaussian_start uses stream_id 0, the step with
  * timestep i uses stream_id i+1).  n and offset must be multiples of 4. */
@@ -199,6 +204,22 @@ int bsg_length_regulator(const int64_t* dur, const int64_t* txt, int64_t* mel2ph
 int bsg_fs2midi_decode(bsg_fs2midi* h, const float* enc_out, const int64_t* mel2ph, const int64_t* spk_id,
                        const int64_t* speechsing, int32_t B, int32_t T_txt, int32_t T, float* decoder_inp,
                        float* mel_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FFT candidate denoiser: DIFF_DECODERS['fft'] = FFT(hidden, dec_layers, dec_ffn_kernel_size,
+ * num_heads) (usr/diffsinger_task.py:26-28, usr/diff/candidate_decoder.py:39-100); same denoise_fn contract as DiffNet.
+ * dev_weights in FFT.state_dict() order: pos_embed_alpha, embed_positions._float_tensor, layers.i.op.* (10 per layer),
+ * layer_norm.{w,b}, input_projection.{w,b}, mlp.0.{w,b}, mlp.2.{w,b}, get_mel_out.{w,b}, get_decode_inp.{w,b}.
+ * step_table [max_steps,256] and pos_table [n_pos,256] as for bsg_diffnet_create / bsg_fs2midi_create.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bsg_fftden bsg_fftden;
+int bsg_fftden_n_weights(int32_t n_layers);
+int bsg_fftden_create(bsg_fftden** out, int32_t in_dims, int32_t n_layers, int32_t num_heads, int32_t ffn_kernel,
+                      int32_t max_steps, int32_t n_pos, const void* const* dev_weights, int32_t n_weights,
+                      const float* step_table, const float* pos_table, void* stream);
+void bsg_fftden_destroy(bsg_fftden* h);
+int bsg_fftden_prepare(bsg_fftden* h, const float* cond, int32_t B, int32_t T, void* stream);
+int bsg_fftden_forward(bsg_fftden* h, const float* x, const int64_t* t, float* eps, int32_t B, int32_t T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HiFi-GAN generator forward (mel -> waveform).
