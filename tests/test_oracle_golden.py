@@ -157,3 +157,58 @@ def test_philox_stream_known_answer():
     assert [hex(int(v)) for v in z] == ['0xd16cfe09', '0x94fdcceb', '0x5001e420', '0x24126ea1']
     n = synth.philox_normal(1, 5, 100000)
     assert abs(n.mean()) < 0.02 and abs(n.std() - 1) < 0.02
+
+
+def _bn_fix(w, spec):
+    for k in spec:
+        if k.endswith('running_var'):
+            w[k] = (0.5 + np.abs(w[k]) * 5).astype(np.float32)
+        if k.endswith('running_mean'):
+            w[k] = (w[k] * 3).astype(np.float32)
+    return w
+
+
+def test_f2_pitch_extractor_and_nsf(gold, sd_spec):
+    """SURVEY.md §8 row f2 goldens (tools/make_golden_f2.py)."""
+    from collections import OrderedDict
+    from oracle import nsf as onsf, pe as ope
+    g = gold('f2')
+    spec = OrderedDict((k, tuple(s)) for k, s in sd_spec['PitchExtractor'])
+    sd = {k: T(v) for k, v in _bn_fix(synth.synth_state_dict(spec, seed=11), spec).items()}
+    rs = np.random.RandomState(31)
+    for tag, (B, Tn) in {'B2T50': (2, 50), 'B1T133': (1, 133)}.items():
+        mel = (rs.standard_normal((B, Tn, 80)) * 1.5 - 3.0).astype(np.float32)
+        if B > 1:
+            mel[1, Tn - 7:] = 0
+        r = ope.pitch_extractor_forward(sd, T(mel))
+        assert np.abs(r['pitch_pred'].numpy() - g[f'pe.{tag}.pitch_pred']).max() <= 1e-5
+        assert np.abs(r['f0_denorm_pred'].numpy() - g[f'pe.{tag}.f0']).max() <= 1e-4
+    nspec = OrderedDict((k, tuple(s)) for k, s in sd_spec['HifiGanGenerator_nsf_weight_norm'])
+    nsd = {k: T(v) for k, v in synth.synth_state_dict(nspec, seed=13).items()}
+    cfg = dict(sd_spec['hifigan_cfg'], use_pitch_embed=True)
+    for tag, (B, Tn) in {'B1T12': (1, 12), 'B2T21': (2, 21)}.items():
+        mel = (rs.standard_normal((B, 80, Tn)) * 1.5 - 3.0).astype(np.float32)
+        f0 = (rs.uniform(90, 500, size=(B, Tn))).astype(np.float32)
+        f0[:, Tn // 3: Tn // 3 + 3] = 0
+        ri = rs.uniform(0, 1, size=(B, 9)).astype(np.float32)
+        nz = rs.standard_normal((B, Tn * 256, 9)).astype(np.float32)
+        har = onsf.sine_source(nsd, T(f0), T(ri), T(nz), cfg['audio_sample_rate'], 256)
+        assert np.abs(har.numpy() - g[f'nsf.{tag}.har']).max() <= 1e-5
+        y = onsf.nsf_hifigan_forward(nsd, T(mel), T(f0), T(ri), T(nz), cfg)
+        assert np.abs(y.numpy() - g[f'nsf.{tag}.wav']).max() <= 1e-5
+
+
+def test_f4_fft_candidate_denoiser(gold, sd_spec):
+    """SURVEY.md §8 row f4 golden (tools/make_golden_f4.py)."""
+    from collections import OrderedDict
+    from oracle import candidate_decoder as ocd
+    g = gold('f4')
+    spec = OrderedDict((k, tuple(s)) for k, s in sd_spec['FFT'])
+    sd = {k: T(v) for k, v in synth.synth_state_dict(spec, seed=17).items()}
+    rs = np.random.RandomState(41)
+    for tag, (B, Tn) in {'B2T40': (2, 40), 'B1T77': (1, 77)}.items():
+        x = rs.standard_normal((B, 1, 80, Tn)).astype(np.float32)
+        cond = rs.standard_normal((B, 256, Tn)).astype(np.float32)
+        t = rs.randint(0, 100, size=(B,)).astype(np.int64)
+        y = ocd.fft_denoiser_forward(sd, T(x), T(t), T(cond))
+        assert np.abs(y.numpy() - g[f'{tag}.eps']).max() <= 1e-5
