@@ -67,6 +67,8 @@ _SIGS = {
     'bsg_philox_normal': (c_int32, [c_void_p, c_int64, c_uint64, c_uint32, c_uint64, c_void_p]),
     'bsg_mel_start': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_mel_finish': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'bsg_diffnet_persist_clocks': (c_int32, [c_void_p, c_void_p, c_int32]),
+    'bsg_diffnet_status': (c_int32, [c_void_p, POINTER(c_int32)]),
     'bsg_diffnet_profile': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_profile_read': (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'bsg_fs2midi_n_weights': (c_int32, [POINTER(Fs2Cfg)]),

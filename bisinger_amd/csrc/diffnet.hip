@@ -86,7 +86,7 @@ struct ResArgs {
       __builtin_amdgcn_sched_barrier(0);                                                               \
       const unsigned long long _t = __builtin_amdgcn_s_memtime();                                      \
       __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
-      if (lane == 0) a.stamps[((long long)blockIdx.x * 8 + wave) * 10 + (i)] = _t;                      \
+      if (lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + (i)] = _t;                      \
       __builtin_amdgcn_sched_barrier(0);                                                               \
     }                                                                                                  \
   } while (0)
@@ -126,13 +126,41 @@ __device__ __forceinline__ constexpr int acc_row0(int r) { return (r & 3) + 8 * 
   ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0_[3], B_[3], ACC0, 0, 0, 0);                  \
   ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1_[3], B_[3], ACC1, 0, 0, 0);
 
+// Software-pipelined MFMA stream over two row tiles that share the B fragment.  Group q = 4 k-steps = 8 MFMAs.
+// A fragments live in a ring of NS register sets: set s holds group q+s and is refilled with group q+s+NS right
+// after its MFMAs have issued, i.e. NS-1 groups (>= 512 cycles each) before it is needed again; the B fragment of
+// the next group is read from LDS while the current group multiplies.  sched_barrier pins this order: left alone,
+// hipcc sinks the refills next to their consumers and every trip waits a full L2 latency.
+template <int NS, typename LDB>
+__device__ __forceinline__ void mfma_pipe(f32x16& acc0, f32x16& acc1, f32x4 (&A0)[NS], f32x4 (&A1)[NS], rsrc_t rs, int vfrag,
+                                          int sa0, int sa1, int q_begin, int q_end, int q_last, LDB ldb) {
+  f32x4 Bf[2];
+  Bf[0] = ldb(q_begin);
+#pragma unroll 1
+  for (int q = q_begin; q < q_end; q += NS) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int qn = q + s + 1 <= q_last ? q + s + 1 : q_last;
+      Bf[(s + 1) & 1] = ldb(qn);
+      __builtin_amdgcn_sched_barrier(0);
+      BSG_MFMA8(acc0, acc1, A0[s], A1[s], Bf[s & 1])
+      __builtin_amdgcn_sched_barrier(0);
+      const int qr = q + s + NS <= q_last ? q + s + NS : q_last;
+      A0[s] = ldf4(rs, vfrag, sa0 + qr * 1024);
+      A1[s] = ldf4(rs, vfrag, sa1 + qr * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // One workgroup = 8 waves = one 32-frame tile of one utterance; wave w owns gate rows [32w,32w+32) and filter
 // rows [256+32w, ...) in GEMM1 and residual rows [32w, ...) + skip rows [256+32w, ...) in GEMM2.
 // Both GEMM loops are software-pipelined by hand: A fragments (global, L2) are requested a full 8-MFMA group
 // before use and B fragments (LDS) one group before use; sched_barrier pins that order (left alone, hipcc
 // sinks the prefetch loads next to their consumers, which exposes the L2 latency on every trip).
-template <bool STAMP = false>
-__global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
+template <bool STAMP, bool WT, int NS>   // WT: x_out is stored write-through (sc1) for the in-launch hand-off of the persistent
+                                         // kernel; NS: depth of the A-fragment ring (2: <= 80 VGPRs, 4: <= 128)
+__device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_id) {
   constexpr int NT = 32;               // frames per workgroup
   constexpr int LDX = NT + 2 * HALO;   // xs row stride (48 floats = 12 x 16 B)
   constexpr int LDZ = NT;              // zs row stride
@@ -144,8 +172,8 @@ __global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.x / a.tiles_per_row;
-  const int t0 = (blockIdx.x - b * a.tiles_per_row) * NT;
+  const int b = tile_id / a.tiles_per_row;
+  const int t0 = (tile_id - b * a.tiles_per_row) * NT;
   const int T = a.T;
   const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
   const int col = t0 + l31;            // this lane's frame in every accumulator tile
@@ -166,14 +194,18 @@ __global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
   const int vfrag = lane * 16;                // per-lane byte offset inside a packed 1-KB A fragment group
 
   BSG_STAMP(0);
-  if (STAMP && lane == 0) a.stamps[((long long)blockIdx.x * 8 + wave) * 10 + 8] = __builtin_amdgcn_s_memrealtime();
+  if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 8] = __builtin_amdgcn_s_memrealtime();
   // ---- (1) the first A fragments fly while the x tile is staged ------------------------------------
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   const int sa_g = wave * 96 * 1024, sa_f = (8 + wave) * 96 * 1024;   // gate / filter tile of the packed dilated conv
-  f32x4 A0g = ldf4(rs_a1, vfrag, sa_g), A0f = ldf4(rs_a1, vfrag, sa_f);
-  f32x4 A1g = ldf4(rs_a1, vfrag, sa_g + 1024), A1f = ldf4(rs_a1, vfrag, sa_f + 1024);
+  f32x4 Ag[NS], Af[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    Ag[k] = ldf4(rs_a1, vfrag, sa_g + k * 1024);
+    Af[k] = ldf4(rs_a1, vfrag, sa_f + k * 1024);
+  }
 
   // ---- (2) stage xs = x + d (zero padded) ------------------------------------------------------
   if ((T & 3) == 0) {
@@ -203,34 +235,17 @@ __global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
   __syncthreads();
   BSG_STAMP(1);
 
-  // ---- (3) GEMM1: y = W_dil * im2col(xs); 8 k-steps (two groups of 8 MFMAs) per trip --------------
+  // ---- (3) GEMM1: y = W_dil * im2col(xs): 96 groups of 8 MFMAs ------------------------------------
   {
     const float* xrow = xs + lh * LDX + HALO + l31;
+    const int dil = a.dil;
     auto ldb = [&](int q) {
       const int tap = q >> 5, cg = q & 31;
-      const float* p = xrow + 8 * cg * LDX + (tap - 1) * a.dil;
+      const float* p = xrow + 8 * cg * LDX + (tap - 1) * dil;
       return f32x4{p[0], p[2 * LDX], p[4 * LDX], p[6 * LDX]};
     };
-    f32x4 B0 = ldb(0), B1;
     BSG_STAMP(2);
-#pragma unroll 1
-    for (int q = 0; q < 96; q += 2) {
-      B1 = ldb(q + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      BSG_MFMA8(acc0, acc1, A0g, A0f, B0)
-      __builtin_amdgcn_sched_barrier(0);
-      const int q2 = q + 2 < 96 ? q + 2 : 95;
-      A0g = ldf4(rs_a1, vfrag, sa_g + q2 * 1024);
-      A0f = ldf4(rs_a1, vfrag, sa_f + q2 * 1024);
-      B0 = ldb(q2);
-      __builtin_amdgcn_sched_barrier(0);
-      BSG_MFMA8(acc0, acc1, A1g, A1f, B1)
-      __builtin_amdgcn_sched_barrier(0);
-      const int q3 = q + 3 < 96 ? q + 3 : 95;
-      A1g = ldf4(rs_a1, vfrag, sa_g + q3 * 1024);
-      A1f = ldf4(rs_a1, vfrag, sa_f + q3 * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    mfma_pipe<NS>(acc0, acc1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 0, 96, 95, ldb);
   }
   BSG_STAMP(3);
 
@@ -254,8 +269,11 @@ __global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
   // loads GEMM2 needs first fly across the two barriers: its first A fragments and the residual input x,
   // which becomes the initial accumulator of the residual rows (x + b_out + W_out z, then / sqrt(2))
   const int sb_r = wave * 32 * 1024, sb_s = (8 + wave) * 32 * 1024;   // residual / skip tile of the packed output projection
-  A0g = ldf4(rs_a2, vfrag, sb_r); A0f = ldf4(rs_a2, vfrag, sb_s);
-  A1g = ldf4(rs_a2, vfrag, sb_r + 1024); A1f = ldf4(rs_a2, vfrag, sb_s + 1024);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    Ag[k] = ldf4(rs_a2, vfrag, sb_r + k * 1024);
+    Af[k] = ldf4(rs_a2, vfrag, sb_s + k * 1024);
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
   __syncthreads();  // every wave is done reading xs
@@ -277,33 +295,11 @@ __global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
       const float* p = zrow + 8 * q * LDZ;
       return f32x4{p[0], p[2 * LDZ], p[4 * LDZ], p[6 * LDZ]};
     };
-    f32x4 B0 = ldb(0), B1;
-#define BSG_G2_TRIP(q)                                                                        \
-    {                                                                                         \
-      B1 = ldb(q + 1);                                                                        \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-      BSG_MFMA8(acc0, acc1, A0g, A0f, B0)                                                     \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-      const int q2 = q + 2 < 32 ? q + 2 : 31;                                                 \
-      A0g = ldf4(rs_a2, vfrag, sb_r + q2 * 1024);                                             \
-      A0f = ldf4(rs_a2, vfrag, sb_s + q2 * 1024);                                             \
-      B0 = ldb(q2);                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-      BSG_MFMA8(acc0, acc1, A1g, A1f, B1)                                                     \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-      const int q3 = q + 3 < 32 ? q + 3 : 31;                                                 \
-      A1g = ldf4(rs_a2, vfrag, sb_r + q3 * 1024);                                             \
-      A1f = ldf4(rs_a2, vfrag, sb_s + q3 * 1024);                                             \
-      __builtin_amdgcn_sched_barrier(0);                                                      \
-    }
-#pragma unroll 1
-    for (int q = 0; q < 16; q += 2) BSG_G2_TRIP(q)
+    mfma_pipe<NS>(acc0, acc1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 0, 16, 31, ldb);
     // the running skip sum is added after the chain (keeps the small products out of a large accumulator)
 #pragma unroll
     for (int r = 0; r < 16; ++r) prevs[r] = ldf(rs_sk, vcol, (32 * wave + acc_row0(r)) * rowT);
-#pragma unroll 1
-    for (int q = 16; q < 32; q += 2) BSG_G2_TRIP(q)
-#undef BSG_G2_TRIP
+    mfma_pipe<NS>(acc0, acc1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, 32, 31, ldb);
   }
   BSG_STAMP(6);
   if (col_ok) {
@@ -311,14 +307,105 @@ __global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int so = (32 * wave + acc_row0(r)) * rowT;
-      stf(acc0[r] / 1.41421356237309504880f, rs_xo, vst, so);                      // (x + residual) / sqrt(2), net.py:78
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc0[r] / 1.41421356237309504880f), rs_xo, vst, so,
+                                            WT ? 16 : 0);                          // (x + residual) / sqrt(2), net.py:78
       stf(((a.first ? 0.f : prevs[r]) + acc1[r]) / a.skip_div, rs_sk, vst, so);    // running skip sum (/ sqrt(L) last, :126)
     }
   }
   BSG_STAMP(7);
-  if (STAMP && lane == 0) a.stamps[((long long)blockIdx.x * 8 + wave) * 10 + 9] = __builtin_amdgcn_s_memrealtime();
+  if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 9] = __builtin_amdgcn_s_memrealtime();
 }
 #undef BSG_MFMA8
+
+template <bool STAMP = false>
+__global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
+  residual_tile<STAMP, false, 2>(a, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// All L residual layers of one DiffNet evaluation in ONE launch.  Workgroup w owns tiles w, w+G, ... and walks the
+// layers in order; layer l of tile j needs layer l-1 of tiles j-1, j, j+1 (the dilation halo is <= 8 frames < 32),
+// so the only inter-workgroup traffic is the x tile of the two neighbours:
+//   producer: x_out stored write-through (sc1) -> every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed agent-scope
+//             flag store per (layer, tile);
+//   consumer: one lane polls the two neighbour flags (relaxed, s_sleep, bounded) -> ONE agent-scope acquire ->
+//             s_waitcnt vmcnt(0) -> barrier -> plain loads            (cdna_hip_programming.md Guideline 16, valid form).
+// Dependencies only point to the previous layer, so any set of co-resident workgroups makes progress; the host sizes
+// the grid to <= 2 workgroups per CU (3 fit) so every workgroup is resident.  The flags are zeroed by a memset node
+// before every launch.  Why: with one launch per layer all 512 workgroups stage their tile at the same moment (no
+// MFMA work for ~6 us) and the younger of the two co-resident workgroups finishes ~20 us after the older one; here
+// the phases of neighbouring workgroups drift apart and the load / epilogue phases hide under the other's MFMAs.
+// ------------------------------------------------------------------------------------------------
+struct PersistArgs {
+  ResArgs base;   // pointers of layer 0
+  float* xa;
+  float* xb;
+  long long ct_stride, a1_stride, a2_stride, bo_stride;   // per-layer strides (elements)
+  int n_tiles, cycle;
+  unsigned* flags;    // [L][n_tiles], zero before the launch
+  unsigned* status;   // [0] += 1 for every spin that gave up
+  unsigned long long* clk;   // optional [grid][4]: s_memtime / s_memrealtime at start and end (diagnostic)
+};
+
+__global__ __launch_bounds__(512, 4) void persistent_layers_kernel(PersistArgs p) {
+  const int L = p.base.L, n_tiles = p.n_tiles, tpr = p.base.tiles_per_row;
+  if (p.clk && threadIdx.x == 0) {
+    p.clk[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+    p.clk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+  // Tile assignment.  Workgroups i and i + G/2 are (in practice) the two that share a CU, and the older one wins the
+  // MFMA arbitration.  If the first G/2 workgroups owned the first G/2 tiles, they would only ever wait for each
+  // other and run up to 25 % ahead, leaving the second half to finish alone at half occupancy.  Interleaving makes
+  // every tile's neighbours belong to the other half, so neither half can get more than one layer ahead.
+  const int G = (int)gridDim.x, half = G >> 1;
+  const int slot = (G & 1) ? (int)blockIdx.x : ((int)blockIdx.x % half) * 2 + (int)blockIdx.x / half;
+  for (int l = 0; l < L; ++l) {
+    ResArgs a = p.base;
+    a.layer = l;
+    a.x_in = (l & 1) ? p.xb : p.xa;
+    a.x_out = (l & 1) ? p.xa : p.xb;
+    a.condterm = p.base.condterm + (long long)l * p.ct_stride;
+    a.apack1 = p.base.apack1 + (long long)l * p.a1_stride;
+    a.apack2 = p.base.apack2 + (long long)l * p.a2_stride;
+    a.bias_out = p.base.bias_out + (long long)l * p.bo_stride;
+    a.dil = 1 << (l % p.cycle);
+    a.first = l == 0;
+    a.skip_div = l == L - 1 ? sqrtf((float)L) : 1.0f;
+    for (int tile = slot; tile < n_tiles; tile += gridDim.x) {
+      if (l > 0) {
+        if (threadIdx.x == 0) {
+          const int j = tile % tpr;
+          const unsigned* f = p.flags + (long long)(l - 1) * n_tiles;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const int nb = side == 0 ? tile - 1 : tile + 1;
+            if (side == 0 ? j == 0 : j == tpr - 1) continue;
+            unsigned spins = 0;
+            while (__hip_atomic_load(f + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(4);
+              if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
+                atomicAdd(p.status, 1u);
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+      }
+      residual_tile<false, true, 4>(a, tile);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+      __syncthreads();
+      if (threadIdx.x == 0 && l + 1 < L)
+        __hip_atomic_store(p.flags + (long long)l * n_tiles + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (p.clk && threadIdx.x == 0) {
+    p.clk[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+    p.clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // sampler: one ancestral step, elementwise over [B][M][T]   (shallow_diffusion_tts.py:134-166)
@@ -683,6 +770,12 @@ struct bsg_diffnet {
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
+  size_t prof_launches = 0;   // kernel launches covered by the recorded pairs (L per pair, or 1 in persistent mode)
+  // persistent multi-layer launch: hand-off flags [L][tiles] + status word
+  unsigned* flags = nullptr;
+  size_t flags_cap = 0;
+  int num_cus = 0;
+  unsigned long long* clk = nullptr;   // [1024][4] diagnostic clock stamps of the last persistent launch
 };
 
 static int dev_alloc(float** p, size_t n) {
@@ -701,6 +794,8 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+  if (h->flags) (void)hipFree(h->flags);
+  if (h->clk) (void)hipFree(h->clk);
   delete h;
 }
 
@@ -860,6 +955,24 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   }
   h->B = B;
   h->T = T;
+  {
+    const size_t need = (size_t)h->L * B * cdiv(T, 32) + 64;
+    if (need > h->flags_cap) {
+      BSG_HIP(hipStreamSynchronize(st));
+      if (h->flags) (void)hipFree(h->flags);
+      h->flags = nullptr;
+      h->flags_cap = 0;
+      BSG_HIP(hipMalloc((void**)&h->flags, need * sizeof(unsigned)));
+      BSG_HIP(hipMemsetAsync(h->flags, 0, need * sizeof(unsigned), st));
+      h->flags_cap = need;
+    }
+    if (!h->clk) BSG_HIP(hipMalloc((void**)&h->clk, 1024 * 4 * sizeof(unsigned long long)));
+    if (!h->num_cus) {
+      int dev = 0;
+      BSG_HIP(hipGetDevice(&dev));
+      BSG_HIP(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+  }
   for (int l = 0; l < h->L; ++l)
     TRY(conv1x1(h->w_cond + (size_t)l * 2 * C * C, h->b_cond + (size_t)l * 2 * C, cond,
                 h->condterm + (size_t)l * 2 * C * bt, 2 * C, C, B, T, ACT_NONE, st));
@@ -898,6 +1011,45 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   return BSG_OK;
 }
 
+// all L layers in one launch (persistent_layers_kernel); x chain starts in h->xa
+static int launch_layers_persistent(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, hipStream_t st) {
+  PersistArgs p{};
+  ResArgs& a = p.base;
+  a.skip = h->skip; a.condterm = h->condterm; a.dproj = h->dproj; a.t_dev = t_dev; a.t_uniform = t_uniform;
+  a.apack1 = h->apack1; a.apack2 = h->apack2; a.bias_out = h->b_out;
+  a.B = B; a.T = T; a.L = h->L; a.tiles_per_row = cdiv(T, 32); a.stamps = nullptr;
+  p.xa = h->xa; p.xb = h->xb;
+  p.ct_stride = (long long)2 * C * (long long)B * T; p.a1_stride = (long long)2 * C * 3 * C; p.a2_stride = (long long)2 * C * C;
+  p.bo_stride = 2 * C;
+  p.n_tiles = B * a.tiles_per_row; p.cycle = h->cfg.dilation_cycle_length;
+  const size_t nflags = (size_t)h->L * p.n_tiles;
+  p.flags = h->flags; p.status = h->flags + h->flags_cap - 1; p.clk = h->clk;
+  BSG_HIP(hipMemsetAsync(h->flags, 0, ((nflags * sizeof(unsigned) + 15) / 16) * 16, st));
+  const size_t lds = (size_t)C * (32 + 2 * HALO) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    BSG_HIP(hipFuncSetAttribute((const void*)persistent_layers_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  // every workgroup must be resident: 2 per CU (the kernel is built for 4 waves/SIMD, 48 KB of LDS each)
+  static int occ = -1;
+  if (occ < 0) BSG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)persistent_layers_kernel, 512, lds));
+  BSG_REQUIRE(occ >= 2, "persistent launch needs 2 resident workgroups per CU, the runtime reports %d", occ);
+  const int grid = p.n_tiles < 2 * h->num_cus ? p.n_tiles : 2 * h->num_cus;
+  hipLaunchKernelGGL(persistent_layers_kernel, dim3(grid), dim3(512), lds, st, p);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// Opt-in (BSG_PERSIST=1).  Measured in round 1 at B=16, T=1000: bit-identical results, 2.63 ms per 20 layers vs
+// 20 x 136.9 us = 2.74 ms with one launch per layer (+2.4 % end to end, MFMA pipe 85 % busy).  Kept off by default: it
+// needs every workgroup resident (2 per CU on all CUs of the device), which a per-layer launch does not.
+static bool use_persistent() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BSG_PERSIST"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
+
 static int check_bound(bsg_diffnet* h, int B, int T, const char* who) {
   if (!h) { set_error("%s: null handle", who); return BSG_EINVAL; }
   if (h->cap_bt == 0 || h->B != B || h->T != T) {
@@ -922,6 +1074,7 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
   if (prof) {
     BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
     h->prof_used += 2;
+    h->prof_launches += h->L;
   }
   TRY(conv1x1(h->w_skip, h->b_skip, h->skip, h->hid, C, C, B, T, ACT_RELU, st));   // net.py:127-128
   TRY(conv1x1(h->w_fin, h->b_fin, h->hid, eps, h->M, C, B, T, ACT_NONE, st));      // net.py:129
@@ -998,13 +1151,18 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     float* nxt = h->xb;
     const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
     if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    for (int l = 0; l < h->L; ++l) {
-      TRY(launch_layer(h, l, cur, nullptr, i, nxt, h->skip, B, T, st));
-      float* tmp = cur; cur = nxt; nxt = tmp;
+    if (use_persistent()) {
+      TRY(launch_layers_persistent(h, nullptr, i, B, T, st));
+    } else {
+      for (int l = 0; l < h->L; ++l) {
+        TRY(launch_layer(h, l, cur, nullptr, i, nxt, h->skip, B, T, st));
+        float* tmp = cur; cur = nxt; nxt = tmp;
+      }
     }
     if (prof) {
       BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
       h->prof_used += 2;
+      h->prof_launches += use_persistent() ? 1 : h->L;
     }
     TailArgs a{};
     a.skip = h->skip; a.x = x; a.noise = noise ? noise + (long long)k * n : nullptr; a.xa_next = h->xa;
@@ -1029,6 +1187,23 @@ extern "C" int bsg_diffnet_debug_stamps(bsg_diffnet* h, int32_t layer, const flo
   return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream, (unsigned long long*)stamps);
 }
 
+extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
+  BSG_REQUIRE(h && handoff_timeouts, "diffnet_status: null argument");
+  *handoff_timeouts = 0;
+  if (h->flags) {
+    unsigned v = 0;
+    BSG_HIP(hipMemcpy(&v, h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *handoff_timeouts = (int32_t)v;
+  }
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg) {
+  BSG_REQUIRE(h && out && h->clk && n_wg > 0 && n_wg <= 1024, "diffnet_persist_clocks: bad argument");
+  BSG_HIP(hipMemcpy(out, h->clk, (size_t)n_wg * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return BSG_OK;
+}
+
 extern "C" int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable) {
   BSG_REQUIRE(h, "diffnet_profile: null handle");
   if (enable && h->prof_ev.empty()) {
@@ -1037,6 +1212,7 @@ extern "C" int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable) {
   }
   h->prof_on = enable != 0;
   h->prof_used = 0;
+  h->prof_launches = 0;
   return BSG_OK;
 }
 
@@ -1050,7 +1226,7 @@ extern "C" int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, 
     total += ms;
   }
   *layer_ms_total = total;
-  *n_layer_launches = (int64_t)(h->prof_used / 2) * h->L;
+  *n_layer_launches = (int64_t)h->prof_launches;
   return BSG_OK;
 }
 

@@ -153,6 +153,13 @@ class DiffNet(nn.Module):
         """Record hipEvent pairs around the residual-layer launches of every evaluation (bench.py roofline)."""
         _lib.check(_lib.load().bsg_diffnet_profile(self.handle(), int(enable)), 'bsg_diffnet_profile')
 
+    def handoff_timeouts(self):
+        """Persistent-launch health: spins that gave up (0 unless a workgroup was not resident). Synchronises."""
+        from ctypes import c_int32
+        n = c_int32()
+        _lib.check(_lib.load().bsg_diffnet_status(self._h, byref(n)), 'bsg_diffnet_status')
+        return n.value
+
     def profile_read(self):
         """-> (summed device ms of the recorded residual-layer chains, number of layer launches covered)."""
         from ctypes import c_double, c_int64

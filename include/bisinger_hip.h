@@ -131,9 +131,16 @@ int bsg_mel_finish(const float* x, const float* spec_min, const float* spec_max,
 
 /* Live timing of the dominant kernel (bench.py's roofline): while enabled, every DiffNet evaluation records
  * a hipEvent pair around its L fused residual-layer launches on the launch stream.  profile_read waits for the
- * recorded events and returns the summed device time and the number of layer launches they cover. */
+ * recorded events and returns the summed device time and the number of kernel launches they cover (L per evaluation,
+ * or 1 when the L layers run as one persistent launch). */
 int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable);
 int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_layer_launches);
+/* Synchronous health check of the persistent multi-layer launch (BSG_PERSIST=1): number of inter-workgroup
+ * hand-off spins that gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
+int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
+/* Diagnostic: {s_memtime, s_memrealtime} at the start and end of each workgroup of the LAST persistent launch,
+ * out [n_wg][4] uint64 (host).  Shader clock held = d(memtime)/d(memrealtime) x 100 MHz.  Synchronous. */
+int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg);
 
 /* Diagnostic build of the fused residual layer (separate kernel instantiation; the product kernel executes no
  * stamp): same computation, plus s_memtime stamps per wave at the phase boundaries

@@ -113,3 +113,49 @@ def test_fused_step_tail_matches_separate_kernels(model, monkeypatch):
     assert maxabs(fused, sep) <= 2e-5
     assert maxabs(fused_p, sep_p) <= 2e-5
     assert maxabs(fused_p, fused) > 1e-2
+
+
+@pytest.mark.parametrize('B,T', [(3, 77), (16, 1000), (40, 640)])
+def test_persistent_layers_bitwise_equal_to_per_layer_launches(B, T):
+    """BSG_PERSIST=1: the 20 layers as one launch with neighbour-tile hand-offs must give bit-identical results
+    (same arithmetic, only the synchronisation differs).  Checked in a child process per mode because the switch is
+    read once per process; (40,640) needs several tiles per workgroup (800 tiles > 512 resident workgroups)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, hashlib, torch, numpy as np
+sys.path.insert(0, %r)
+from tests.util import load_formula_weights, use_config
+from bisinger_amd import synth
+from bisinger_amd.hparams import hparams
+torch.set_grad_enabled(False)
+use_config()
+from bisinger_amd.diffnet import DIFF_DECODERS
+from bisinger_amd.diffusion import GaussianDiffusion
+class E:
+    def __len__(self): return 65
+    def pad(self): return 0
+m = GaussianDiffusion(E(), 80, DIFF_DECODERS['wavenet'](hparams), timesteps=100, K_step=100, spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+load_formula_weights(m, 0, synth.DIFFNET_GAIN); m = m.cuda()
+B, T = %d, %d
+g = torch.Generator().manual_seed(3)
+cond = torch.randn(B, 256, T, generator=g).cuda()
+hs = []
+for rep in range(3):
+    x = m.philox_normal((B, 1, 80, T), 'cuda', 5, 0, 0)
+    x = m.sample(cond, x, seed=5, n_steps=10)
+    torch.cuda.synchronize()
+    hs.append(hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest())
+print(json.dumps({'hashes': hs, 'timeouts': m.denoise_fn.handoff_timeouts(), 'finite': bool(torch.isfinite(x).all())}))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), B, T)
+    res = {}
+    for mode in ('0', '1'):
+        env = dict(os.environ, BSG_PERSIST=mode)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['1']['timeouts'] == 0 and res['1']['finite']
+    assert len(set(res['0']['hashes'])) == 1 and len(set(res['1']['hashes'])) == 1
+    assert res['0']['hashes'][0] == res['1']['hashes'][0]
