@@ -28,7 +28,10 @@ def init_distributed(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == 'nccl':
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
