@@ -55,6 +55,25 @@ __global__ void pack_a_frag_kernel(const float* __restrict__ src, float* __restr
   out[i] = src[(long long)m * sm + (long long)(k % Kc) * sc + (long long)(k / Kc) * st];
 }
 
+// Winograd F(2,3) weights of the k=3 dilated conv, in 16x16x4 A-fragment order:
+//   U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2;   out[comp][mt16][q][lane][jj] = U_comp(m, k),
+//   m = 16*mt16 + (lane&15), k = 16*q + 4*jj + (lane>>4)       (src [2C][C][3])
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * 2 * C * C) return;
+  const int jj = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+  const int q = rest & 15, mt = (rest >> 4) & 31, comp = rest >> 9;
+  const int m = 16 * mt + (lane & 15), k = 16 * q + 4 * jj + (lane >> 4);
+  const float* p = w + ((long long)m * C + k) * 3;
+  const float w0 = p[0], w1 = p[1], w2 = p[2];
+  float u;
+  if (comp == 0) u = w0;
+  else if (comp == 1) u = (w0 + w1 + w2) * 0.5f;
+  else if (comp == 2) u = (w0 - w1 + w2) * 0.5f;
+  else u = w2;
+  out[i] = u;
+}
+
 __global__ void vec_add_kernel(const float* a, const float* b, float* o, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = a[i] + b[i];
@@ -73,6 +92,7 @@ struct ResArgs {
   int t_uniform;
   const float* apack1;   // dilated conv, packed  [16][96][64][4]
   const float* apack2;   // output projection     [16][32][64][4]
+  const float* apackw;   // dilated conv in Winograd F(2,3) form, packed for 16x16x4 MFMAs [4][32][16][64][4]
   const float* bias_out; // [2C]
   int B, T, L, layer, dil, tiles_per_row;
   int first;             // layer 0: skip is stored, not accumulated
@@ -158,8 +178,9 @@ __device__ __forceinline__ void mfma_pipe(f32x16& acc0, f32x16& acc1, f32x4 (&A0
 // Both GEMM loops are software-pipelined by hand: A fragments (global, L2) are requested a full 8-MFMA group
 // before use and B fragments (LDS) one group before use; sched_barrier pins that order (left alone, hipcc
 // sinks the prefetch loads next to their consumers, which exposes the L2 latency on every trip).
-template <bool STAMP, bool WT, int NS>   // WT: x_out is stored write-through (sc1) for the in-launch hand-off of the persistent
-                                         // kernel; NS: depth of the A-fragment ring (2: <= 80 VGPRs, 4: <= 128)
+template <bool STAMP, bool WT, int NS, bool WINO>   // WT: x_out is stored write-through (sc1) for the in-launch hand-off of the
+                                         // persistent kernel; NS: depth of the A-fragment ring of GEMM2 (and of GEMM1 when
+                                         // !WINO); WINO: GEMM1 as Winograd F(2,3) over the dilated taps (2/3 of the MFMA work)
 __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_id) {
   constexpr int NT = 32;               // frames per workgroup
   constexpr int LDX = NT + 2 * HALO;   // xs row stride (48 floats = 12 x 16 B)
@@ -197,14 +218,27 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
   if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 8] = __builtin_amdgcn_s_memrealtime();
   // ---- (1) the first A fragments fly while the x tile is staged ------------------------------------
   f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-  const int sa_g = wave * 96 * 1024, sa_f = (8 + wave) * 96 * 1024;   // gate / filter tile of the packed dilated conv
   f32x4 Ag[NS], Af[NS];
+  const int sa_g = wave * 96 * 1024, sa_f = (8 + wave) * 96 * 1024;   // gate / filter tile of the packed dilated conv
+  // Winograd: 4 row tiles of 16 (gate 32w..+15, gate +16, filter 256+32w.., filter +16), ring of 2 groups
+  const rsrc_t rs_aw = mk_rsrc(a.apackw, 4 * 2 * C * C * 4);
+  f32x4 AW[2][4];
+  int sw[4];
+  if constexpr (WINO) {
+    sw[0] = (2 * wave) * 16 * 1024; sw[1] = (2 * wave + 1) * 16 * 1024;
+    sw[2] = (16 + 2 * wave) * 16 * 1024; sw[3] = (16 + 2 * wave + 1) * 16 * 1024;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    Ag[k] = ldf4(rs_a1, vfrag, sa_g + k * 1024);
-    Af[k] = ldf4(rs_a1, vfrag, sa_f + k * 1024);
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) AW[k][i] = ldf4(rs_aw, vfrag, sw[i] + k * 1024);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      Ag[k] = ldf4(rs_a1, vfrag, sa_g + k * 1024);
+      Af[k] = ldf4(rs_a1, vfrag, sa_f + k * 1024);
+    }
   }
 
   // ---- (2) stage xs = x + d (zero padded) ------------------------------------------------------
@@ -235,27 +269,27 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
   __syncthreads();
   BSG_STAMP(1);
 
-  // ---- (3) GEMM1: y = W_dil * im2col(xs): 96 groups of 8 MFMAs ------------------------------------
-  {
-    const float* xrow = xs + lh * LDX + HALO + l31;
-    const int dil = a.dil;
-    auto ldb = [&](int q) {
-      const int tap = q >> 5, cg = q & 31;
-      const float* p = xrow + 8 * cg * LDX + (tap - 1) * dil;
-      return f32x4{p[0], p[2 * LDX], p[4 * LDX], p[6 * LDX]};
-    };
-    BSG_STAMP(2);
-    mfma_pipe<NS>(acc0, acc1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 0, 96, 95, ldb);
-  }
-  BSG_STAMP(3);
-
-  // ---- (4) + hoisted conditioner term, gate: z = sigmoid(gate) * tanh(filter)   (net.py:71-74) ----------
-  // The 64 KB/workgroup conditioner tile is the largest HBM stream of the layer.  It is requested here, not at
-  // kernel start: all workgroups of a launch start together, and 32 MB requested at t=0 by an idle chip costs
-  // ~15k cycles with the MFMA pipe empty; by now the co-resident workgroups have drifted apart, so this
-  // latency hides under their MFMA work.
   float z[16];
-  {
+  int zoff[16];   // LDS element offsets of z[] (compile-time pattern + per-lane part; folded by the compiler)
+  if constexpr (!WINO) {
+    // ---- (3) GEMM1: y = W_dil * im2col(xs): 96 groups of 8 MFMAs ----------------------------------
+    {
+      const float* xrow = xs + lh * LDX + HALO + l31;
+      const int dil = a.dil;
+      auto ldb = [&](int q) {
+        const int tap = q >> 5, cg = q & 31;
+        const float* p = xrow + 8 * cg * LDX + (tap - 1) * dil;
+        return f32x4{p[0], p[2 * LDX], p[4 * LDX], p[6 * LDX]};
+      };
+      BSG_STAMP(2);
+      mfma_pipe<NS>(acc0, acc1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 0, 96, 95, ldb);
+    }
+    BSG_STAMP(3);
+    // ---- (4) + hoisted conditioner term, gate: z = sigmoid(gate) * tanh(filter)   (net.py:71-74) --------
+    // The 64 KB/workgroup conditioner tile is the largest HBM stream of the layer.  It is requested here, not at
+    // kernel start: all workgroups of a launch start together, and 32 MB requested at t=0 by an idle chip costs
+    // ~15k cycles with the MFMA pipe empty; by now the co-resident workgroups have drifted apart, so this
+    // latency hides under their MFMA work.
     float cg[16], cf[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -263,7 +297,86 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
       cf[r] = ldf(rs_ct, vcol, (C + 32 * wave + acc_row0(r)) * rowT);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = fast_sigmoid(acc0[r] + cg[r]) * fast_tanh(acc1[r] + cf[r]);
+    for (int r = 0; r < 16; ++r) {
+      z[r] = fast_sigmoid(acc0[r] + cg[r]) * fast_tanh(acc1[r] + cf[r]);
+      zoff[r] = (32 * wave + acc_row(r, lh)) * LDZ + l31;
+    }
+  } else {
+    // ---- (3w) GEMM1 as Winograd F(2,3) along the dilated taps -------------------------------------
+    // For the output pair (t, t+d):  y[t] = M0+M1+M2,  y[t+d] = M1-M2-M3,  M_j = sum_c U_j[.,c] * V_j[c], with
+    //   V0 = x[t-d]-x[t+d], V1 = x[t]+x[t+d], V2 = x[t+d]-x[t], V3 = x[t]-x[t+2d]   (x = the staged, zero-padded tile)
+    // 4 GEMMs of K = 256 over 16 pairs instead of one of K = 768 over 32 frames: 2/3 of the MFMA work.  16x16x4 MFMAs
+    // (N = 16 pairs); lane = (pair p = lane&15, k-row lq = lane>>4); pair p of dilation d sits at tp = (p/d)*2d + p%d.
+    const int p16 = lane & 15, lq = lane >> 4, dil = a.dil;
+    const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
+    const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
+    f32x4 y0[4], y1[4], M[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y0[i] = y1[i] = M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xb0 = xs + lq * LDX + HALO + tp;
+    auto ldbw = [&](int g) {
+      const int comp = g >> 4, q = g & 15;
+      const int oa = comp == 0 ? -dil : comp == 2 ? dil : 0;
+      const int ob = comp == 0 ? dil : comp == 1 ? dil : comp == 2 ? 0 : 2 * dil;
+      const float* pa = xb0 + 16 * q * LDX + oa;
+      const float* pb = xb0 + 16 * q * LDX + ob;
+      f32x4 v;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float xa = pa[4 * jj * LDX], xb_ = pb[4 * jj * LDX];
+        v[jj] = comp == 1 ? xa + xb_ : xa - xb_;
+      }
+      return v;
+    };
+    BSG_STAMP(2);
+    f32x4 Bw[2];
+    Bw[0] = ldbw(0);
+#pragma unroll 1
+    for (int g = 0; g < 64; g += 2) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int gn = g + s2 + 1 < 64 ? g + s2 + 1 : 63;
+        Bw[(s2 + 1) & 1] = ldbw(gn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[s2][i][jj], Bw[s2 & 1][jj], M[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int gr = g + s2 + 2 < 64 ? g + s2 + 2 : 63;
+        const int so = ((gr >> 4) * 512 + (gr & 15)) * 1024;   // comp * (32 tiles * 16 groups) + q
+#pragma unroll
+        for (int i = 0; i < 4; ++i) AW[s2][i] = ldf4(rs_aw, vfrag, sw[i] + so);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if ((g & 15) == 14) {   // a Winograd component is complete: fold it into the two outputs
+        const int comp = g >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (comp == 0) { y0[i] = M[i]; }
+          else if (comp == 1) { y0[i] += M[i]; y1[i] = M[i]; }
+          else if (comp == 2) { y0[i] += M[i]; y1[i] -= M[i]; }
+          else { y1[i] -= M[i]; }
+          M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    BSG_STAMP(3);
+    // ---- (4w) + hoisted conditioner term, gate ----------------------------------------------------
+    const int f0c = t0 + tp < T ? t0 + tp : T - 1, f1c = t0 + tp + dil < T ? t0 + tp + dil : T - 1;
+    const int vc0 = (lq * 4 * T + f0c) * 4, vc1 = (lq * 4 * T + f1c) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so_g = (32 * wave + 16 * i + r) * rowT, so_f = so_g + C * rowT;
+        const float cg0 = ldf(rs_ct, vc0, so_g), cf0 = ldf(rs_ct, vc0, so_f);
+        const float cg1 = ldf(rs_ct, vc1, so_g), cf1 = ldf(rs_ct, vc1, so_f);
+        z[i * 8 + r] = fast_sigmoid(y0[i][r] + cg0) * fast_tanh(y0[2 + i][r] + cf0);
+        z[i * 8 + 4 + r] = fast_sigmoid(y1[i][r] + cg1) * fast_tanh(y1[2 + i][r] + cf1);
+        zoff[i * 8 + r] = (32 * wave + 16 * i + 4 * lq + r) * LDZ + tp;
+        zoff[i * 8 + 4 + r] = (32 * wave + 16 * i + 4 * lq + r) * LDZ + tp + dil;
+      }
   }
   BSG_STAMP(4);
   // loads GEMM2 needs first fly across the two barriers: its first A fragments and the residual input x,
@@ -275,15 +388,15 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
     Af[k] = ldf4(rs_a2, vfrag, sb_s + k * 1024);
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
-  __syncthreads();  // every wave is done reading xs
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] = z[r];
-#pragma unroll
   for (int r = 0; r < 16; ++r) {
-    acc0[r] += ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
+    acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
     acc1[r] = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
   }
+  __syncthreads();  // every wave is done reading xs
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zs[zoff[r]] = z[r];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] += ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
   __syncthreads();
   BSG_STAMP(5);
 
@@ -317,9 +430,9 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
 }
 #undef BSG_MFMA8
 
-template <bool STAMP = false>
-__global__ __launch_bounds__(512, 6) void residual_layer_kernel(ResArgs a) {
-  residual_tile<STAMP, false, 2>(a, (int)blockIdx.x);
+template <bool STAMP, bool WINO>
+__global__ __launch_bounds__(512, WINO ? 4 : 6) void residual_layer_kernel(ResArgs a) {
+  residual_tile<STAMP, false, 2, WINO>(a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,13 +453,14 @@ struct PersistArgs {
   ResArgs base;   // pointers of layer 0
   float* xa;
   float* xb;
-  long long ct_stride, a1_stride, a2_stride, bo_stride;   // per-layer strides (elements)
+  long long ct_stride, a1_stride, a2_stride, aw_stride, bo_stride;   // per-layer strides (elements)
   int n_tiles, cycle;
   unsigned* flags;    // [L][n_tiles], zero before the launch
   unsigned* status;   // [0] += 1 for every spin that gave up
   unsigned long long* clk;   // optional [grid][4]: s_memtime / s_memrealtime at start and end (diagnostic)
 };
 
+template <bool WINO>
 __global__ __launch_bounds__(512, 4) void persistent_layers_kernel(PersistArgs p) {
   const int L = p.base.L, n_tiles = p.n_tiles, tpr = p.base.tiles_per_row;
   if (p.clk && threadIdx.x == 0) {
@@ -366,6 +480,7 @@ __global__ __launch_bounds__(512, 4) void persistent_layers_kernel(PersistArgs p
     a.x_out = (l & 1) ? p.xa : p.xb;
     a.condterm = p.base.condterm + (long long)l * p.ct_stride;
     a.apack1 = p.base.apack1 + (long long)l * p.a1_stride;
+    a.apackw = p.base.apackw + (long long)l * p.aw_stride;
     a.apack2 = p.base.apack2 + (long long)l * p.a2_stride;
     a.bias_out = p.base.bias_out + (long long)l * p.bo_stride;
     a.dil = 1 << (l % p.cycle);
@@ -394,7 +509,7 @@ __global__ __launch_bounds__(512, 4) void persistent_layers_kernel(PersistArgs p
         }
         __syncthreads();
       }
-      residual_tile<false, true, 4>(a, tile);
+      residual_tile<false, true, WINO ? 2 : 4, WINO>(a, tile);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
       __syncthreads();
       if (threadIdx.x == 0 && l + 1 < L)
@@ -741,6 +856,7 @@ struct bsg_diffnet {
   float* b_in = nullptr;    // [C]
   float* apack1 = nullptr;  // [L][2C*3C]
   float* apack2 = nullptr;  // [L][2C*C]
+  float* apackw = nullptr;  // [L][4*2C*C]  Winograd form of the dilated conv
   float* w_cond = nullptr;  // [L][2C][H]
   float* b_cond = nullptr;  // [L][2C]  (b_cond + b_dil)
   float* b_out = nullptr;   // [L][2C]
@@ -789,7 +905,7 @@ static void dev_free(float*& p) {
 
 extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (!h) return;
-  float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
+  float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->apackw, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
                    &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
@@ -834,6 +950,7 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&h->b_in, C));
   TRY(dev_alloc(&h->apack1, (size_t)L * 2 * C * 3 * C));
   TRY(dev_alloc(&h->apack2, (size_t)L * 2 * C * C));
+  TRY(dev_alloc(&h->apackw, (size_t)L * 4 * 2 * C * C));
   TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->b_cond, (size_t)L * 2 * C));
   TRY(dev_alloc(&h->b_out, (size_t)L * 2 * C));
@@ -858,6 +975,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
       hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)lw[0],
                          h->apack1 + (size_t)l * total, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL);
     }
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(cdiv(4LL * 2 * C * C, 256)), dim3(256), 0, st, (const float*)lw[0],
+                       h->apackw + (size_t)l * 4 * 2 * C * C);
     {
       const long long total = (long long)2 * C * C;
       hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)lw[6],
@@ -979,6 +1098,13 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   return BSG_OK;
 }
 
+// GEMM1 of the residual block as Winograd F(2,3) (BSG_WINO=0 selects the direct K=768 form)
+static bool use_wino() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BSG_WINO"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
 static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long long* t_dev, int t_uniform, float* x_out,
                         float* skip, int B, int T, hipStream_t st, unsigned long long* stamps = nullptr) {
   ResArgs a{};
@@ -987,6 +1113,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   a.dproj = h->dproj; a.t_dev = t_dev; a.t_uniform = t_uniform;
   a.apack1 = h->apack1 + (size_t)layer * 2 * C * 3 * C;
   a.apack2 = h->apack2 + (size_t)layer * 2 * C * C;
+  a.apackw = h->apackw + (size_t)layer * 4 * 2 * C * C;
   a.bias_out = h->b_out + (size_t)layer * 2 * C;
   a.B = B; a.T = T; a.L = h->L; a.layer = layer;
   a.dil = 1 << (layer % h->cfg.dilation_cycle_length);
@@ -1001,12 +1128,19 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   const size_t lds = (size_t)C * (32 + 2 * HALO) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  if (stamps) hipLaunchKernelGGL(residual_layer_kernel<true>, grid, block, lds, st, a);
-  else hipLaunchKernelGGL(residual_layer_kernel<false>, grid, block, lds, st, a);
+  if (use_wino()) {
+    if (stamps) hipLaunchKernelGGL((residual_layer_kernel<true, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((residual_layer_kernel<false, true>), grid, block, lds, st, a);
+  } else {
+    if (stamps) hipLaunchKernelGGL((residual_layer_kernel<true, false>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((residual_layer_kernel<false, false>), grid, block, lds, st, a);
+  }
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
@@ -1016,10 +1150,10 @@ static int launch_layers_persistent(bsg_diffnet* h, const long long* t_dev, int 
   PersistArgs p{};
   ResArgs& a = p.base;
   a.skip = h->skip; a.condterm = h->condterm; a.dproj = h->dproj; a.t_dev = t_dev; a.t_uniform = t_uniform;
-  a.apack1 = h->apack1; a.apack2 = h->apack2; a.bias_out = h->b_out;
+  a.apack1 = h->apack1; a.apack2 = h->apack2; a.apackw = h->apackw; a.bias_out = h->b_out;
   a.B = B; a.T = T; a.L = h->L; a.tiles_per_row = cdiv(T, 32); a.stamps = nullptr;
   p.xa = h->xa; p.xb = h->xb;
-  p.ct_stride = (long long)2 * C * (long long)B * T; p.a1_stride = (long long)2 * C * 3 * C; p.a2_stride = (long long)2 * C * C;
+  p.ct_stride = (long long)2 * C * (long long)B * T; p.a1_stride = (long long)2 * C * 3 * C; p.a2_stride = (long long)2 * C * C; p.aw_stride = (long long)4 * 2 * C * C;
   p.bo_stride = 2 * C;
   p.n_tiles = B * a.tiles_per_row; p.cycle = h->cfg.dilation_cycle_length;
   const size_t nflags = (size_t)h->L * p.n_tiles;
@@ -1028,15 +1162,22 @@ static int launch_layers_persistent(bsg_diffnet* h, const long long* t_dev, int 
   const size_t lds = (size_t)C * (32 + 2 * HALO) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    BSG_HIP(hipFuncSetAttribute((const void*)persistent_layers_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)persistent_layers_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)persistent_layers_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   // every workgroup must be resident: 2 per CU (the kernel is built for 4 waves/SIMD, 48 KB of LDS each)
   static int occ = -1;
-  if (occ < 0) BSG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)persistent_layers_kernel, 512, lds));
+  if (occ < 0) {
+    int o0 = 0, o1 = 0;
+    BSG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, (const void*)persistent_layers_kernel<false>, 512, lds));
+    BSG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, (const void*)persistent_layers_kernel<true>, 512, lds));
+    occ = o0 < o1 ? o0 : o1;
+  }
   BSG_REQUIRE(occ >= 2, "persistent launch needs 2 resident workgroups per CU, the runtime reports %d", occ);
   const int grid = p.n_tiles < 2 * h->num_cus ? p.n_tiles : 2 * h->num_cus;
-  hipLaunchKernelGGL(persistent_layers_kernel, dim3(grid), dim3(512), lds, st, p);
+  if (use_wino()) hipLaunchKernelGGL(persistent_layers_kernel<true>, dim3(grid), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL(persistent_layers_kernel<false>, dim3(grid), dim3(512), lds, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

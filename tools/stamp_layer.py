@@ -52,3 +52,14 @@ d = np.diff(s[:, :, :8], axis=2)
 for i in range(7):
     print(f'  phase {i}->{i + 1} {names[i + 1]:28s} mean {d[:, :, i].mean():10.0f}  p10 {np.percentile(d[:, :, i], 10):10.0f}  p90 {np.percentile(d[:, :, i], 90):10.0f}')
 print('  per-wave total mean', (s[:, :, 7] - s[:, :, 0]).mean())
+
+# intra-workgroup skew: how long the first wave to finish GEMM1 waits for the last one of its workgroup
+g1 = s[:, :, 3]
+skew = g1.max(axis=1) - g1.min(axis=1)
+early = wg_end < np.median(wg_end)
+for name, sel in (('older half (finishes first)', early), ('younger half', ~early)):
+    print(f'GEMM1-end skew inside a workgroup, {name}: mean {skew[sel].mean():.0f} p50 {np.percentile(skew[sel], 50):.0f} p90 {np.percentile(skew[sel], 90):.0f} cycles;'
+          f' GEMM1 duration mean {(s[sel][:, :, 3] - s[sel][:, :, 2]).mean():.0f}; barrier phase mean {(s[sel][:, :, 5] - s[sel][:, :, 4]).mean():.0f}')
+# per-wave-slot pattern: which waves finish GEMM1 last
+rank = np.argsort(np.argsort(g1, axis=1), axis=1).mean(axis=0)
+print('mean finishing rank of wave 0..7 (0 = first):', np.round(rank, 2))
