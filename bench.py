@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_FRAME_LAYER = 2 * (512 * 768 + 512 * 256)   # dilated conv + output projection
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0                                 # MI355X_MICROARCH.md, HBM3E spec (achievable ~6.3 TB/s)
+HBM_BYTES_PER_FRAME_LAYER = 6 * 256 * 4               # x in, x out, conditioner term 2C, skip read+write
 B_PER_GPU, T_FRAMES, T_TXT, N_MEL, N_DIFF_STEPS = 16, 1000, 100, 80, 100
 
 
@@ -102,7 +104,7 @@ def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps):
     x = model.sample(g['decoder_inp'].transpose(1, 2).contiguous(), x, noise=noise[1:].to(device), n_steps=n_sample_steps)
     torch.cuda.synchronize()
     parity = {
-        'what': f'GPU vs oracle after FS2 + the first {n_sample_steps} sampler steps, same supplied noise, full bench shape',
+        'what': f'GPU vs fp32 oracle after FS2 + the first {n_sample_steps} sampler steps, same supplied noise, full bench shape',
         'x_max_abs': float((x.cpu() - ret['x']).abs().max()),
         'cond_max_abs': float((g['decoder_inp'].cpu() - fs2_out['decoder_inp']).abs().max()),
         'fs2_mel_max_abs': float((g['mel_out'].cpu() - fs2_out['mel_out']).abs().max()),
@@ -118,11 +120,16 @@ def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps):
 
 
 def main():
+    global B_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--cpu-steps', type=int, default=24, help='sampler steps of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+                    help="arithmetic of the fused residual layers: f32 = BASELINE configs[1] (default, the parity configuration); "
+                         "bf16 = configs[2] (bf16 MFMA operands, fp32 accumulate; run with --batch 64)")
+    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='utterances per GPU')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the all-gather even with one rank (self-test)')
     args = ap.parse_args()
 
@@ -147,6 +154,8 @@ def main():
 
     torch.set_grad_enabled(False)
     model = build_model(device)
+    model.denoise_fn.set_compute('bf16' if args.dtype == 'bf16' else 'fp32')
+    B_PER_GPU = args.batch
     B_total = B_PER_GPU * world
     inp_np = synth.synth_inputs(B_total, T_TXT, T_FRAMES, seed=1)
     d = {k: torch.from_numpy(v).to(device) for k, v in inp_np.items()}     # inputs resident in HBM
@@ -191,26 +200,43 @@ def main():
         layers_per_launch = 20 if os.environ.get('BSG_PERSIST', '0') not in ('', '0') else 1
         avg_ms = layer_ms / max(n_layer, 1)
         achieved = FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch / (avg_ms * 1e-3) / 1e12 if n_layer else None
+        bf16 = args.dtype == 'bf16'
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_bf16.json' if bf16 else 'traffic.json')
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('residual_layer_kernel_hbm_bytes_per_launch')
+            tj = json.load(open(tpath))
+            if tj.get('frames_per_launch', 16000) == frames_per_launch:
+                traffic = tj.get('residual_layer_kernel_hbm_bytes_per_launch')
             if traffic is not None:
                 traffic *= layers_per_launch
+        if bf16:
+            # 16x the fp32 MFMA rate moves the layer under the HBM roof: AI = 1,048,576 FLOP / 6 KB = 171 FLOP/B against a
+            # ridge of 2,500 TFLOP/s / 8 TB/s = 312 FLOP/B
+            ach_gbs = HBM_BYTES_PER_FRAME_LAYER * frames_per_launch / (avg_ms * 1e-3) / 1e9 if n_layer else None
+            roof = {'kernel': 'residual_layer_bf16_kernel (fused DiffNet residual block, bf16 MFMA operands)', 'bound': 'hbm',
+                    'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS if ach_gbs else None,
+                    'traffic': traffic, 'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
+                    'bytes_per_launch': HBM_BYTES_PER_FRAME_LAYER * frames_per_launch,
+                    'mfma_tflops': achieved, 'mfma_frac_of_bf16_peak': achieved / 2516.0 if achieved else None}
+        else:
+            roof = {'kernel': ('persistent_layers_kernel (20 fused DiffNet residual blocks per launch)' if layers_per_launch > 1
+                               else 'residual_layer_kernel<false,true> (fused DiffNet residual block, Winograd GEMM1)'), 'bound': 'mfma',
+                    'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': traffic,
+                    'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
+                    'flop_per_launch': FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch}
+        cfg_name = 'configs[2]' if bf16 else 'configs[1]'
         rec = {
             'metric': 'mel_frames_per_sec', 'value': value, 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE.json configs[1]: B={B_PER_GPU}/GPU x T={T_FRAMES} x {N_MEL}-mel, FS2-MIDI enc+dec + '
-                                   f'{N_DIFF_STEPS}-step DDPM sampler (20-layer DiffNet, 256 ch), fp32, formula weights',
+            'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE.json {cfg_name}: B={B_PER_GPU}/GPU x T={T_FRAMES} x {N_MEL}-mel, FS2-MIDI enc+dec + '
+                                   f'{N_DIFF_STEPS}-step DDPM sampler (20-layer DiffNet, 256 ch), '
+                                   + ('bf16 MFMA operands / fp32 accumulate in the residual layers (FS2, projections, sampler fp32)'
+                                      if bf16 else 'fp32') + ', formula weights',
                        'global_batch': B_total, 'frames_per_utt': T_FRAMES, 'diffusion_steps': N_DIFF_STEPS,
                        'parallelism': f'utterance-sharded x{world}, RCCL all-gather of mels' if world > 1 else 'single GPU'},
-            'roofline': {'kernel': ('persistent_layers_kernel (20 fused DiffNet residual blocks per launch)' if layers_per_launch > 1
-                                    else 'residual_layer_kernel<false> (fused DiffNet residual block)'), 'bound': 'mfma',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': traffic,
-                         'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
-                         'flop_per_launch': FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch},
+            'roofline': roof,
         }
         if world == 1 and args.cpu_steps > 0:
             base, parity = cpu_baseline_and_parity(model, inp_np, device, args.cpu_steps)

@@ -27,13 +27,12 @@
 #include <vector>
 
 #include "bsg_common.h"
+#include "diffnet_res.h"
 
 namespace bsg {
 
 namespace {
 
-constexpr int C = 256;     // residual channels == encoder hidden (checked at create)
-constexpr int HALO = 8;    // max dilation 2^3
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: out[((mt*(K/8) + q)*64 + lane)*4 + j] = W(m = 32*mt + (lane&31), k = 8*q + 2*j + (lane>>5))
@@ -82,23 +81,6 @@ __global__ void vec_add_kernel(const float* a, const float* b, float* o, int n) 
 // ------------------------------------------------------------------------------------------------
 // fused residual block
 // ------------------------------------------------------------------------------------------------
-struct ResArgs {
-  const float* x_in;     // [B][C][T]
-  float* x_out;          // [B][C][T]
-  float* skip;           // [B][C][T]
-  const float* condterm; // this layer's [B][2C][T]: conditioner_projection(cond) + b_cond + b_dil
-  const float* dproj;    // [S][L][C] table: diffusion_projection_l(mlp(emb(step)))
-  const long long* t_dev;  // [B] or null
-  int t_uniform;
-  const float* apack1;   // dilated conv, packed  [16][96][64][4]
-  const float* apack2;   // output projection     [16][32][64][4]
-  const float* apackw;   // dilated conv in Winograd F(2,3) form, packed for 16x16x4 MFMAs [4][32][16][64][4]
-  const float* bias_out; // [2C]
-  int B, T, L, layer, dil, tiles_per_row;
-  int first;             // layer 0: skip is stored, not accumulated
-  float skip_div;        // last layer: skip_sum / sqrt(L) (net.py:126); 1 otherwise
-  unsigned long long* stamps;  // diagnostic build only (STAMP = true): [workgroup][wave][8] s_memtime values
-};
 
 #define BSG_STAMP(i)                                                                                   \
   do {                                                                                                 \
@@ -110,31 +92,6 @@ struct ResArgs {
       __builtin_amdgcn_sched_barrier(0);                                                               \
     }                                                                                                  \
   } while (0)
-
-// fast gate math: v_exp_f32 / v_rcp_f32 based (abs error ~2e-7, far inside the 1e-3 mel budget); the libm
-// versions cost ~60 VALU instructions per element and the gate phase runs with the MFMA pipe idle.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
-
-// Buffer (SRSRC) addressing: one wave-uniform 128-bit descriptor per tensor, a per-lane 32-bit byte offset that
-// is computed once, and a wave-uniform SGPR offset per access — the 32 row-strided loads of an accumulator tile
-// then need ONE address VGPR instead of 32 64-bit pairs (what keeps the kernel at <= 80 VGPRs = 3 workgroups/CU).
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float ldf(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ f32x4 ldf4(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void stf(float v, rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
-}
-// uniform part of acc_row(): register r of a 32x32 accumulator covers row (r&3) + 8*(r>>2) (+ 4 for lanes >= 32)
-__device__ __forceinline__ constexpr int acc_row0(int r) { return (r & 3) + 8 * (r >> 2); }
 
 #define BSG_MFMA8(ACC0, ACC1, A0_, A1_, B_)                                                  \
   ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0_[0], B_[0], ACC0, 0, 0, 0);                  \
@@ -592,6 +549,7 @@ __global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 struct TailArgs {
   const float* skip;    // [B][C][T]
+  const unsigned short* skip_h;  // bf16 mode: [B][C/4][T][4] instead of `skip`
   float* x;             // [B][M][T] in/out
   const float* noise;   // [B][M][T] or null (Philox)
   float* xa_next;       // [B][C][T]
@@ -673,7 +631,23 @@ __global__ __launch_bounds__(512, 4) void step_tail_kernel(TailArgs a) {
   const int vcol = (lh * 4 * T + colc) * 4;
 
   // ---- stage the skip tile ---------------------------------------------------------------------
-  if ((T & 3) == 0) {
+  if (a.skip_h) {
+    // channel-quad bf16: 64 quads x 32 frames, one 8-byte load per item
+    const rsrc_t rs_sh = mk_rsrc(a.skip_h + (long long)b * C * T, (unsigned)C * T * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 512 * k;
+      const int q = idx >> 5, f = idx & 31;
+      const int t = t0 + f;
+      using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+      u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_sh, t < T ? (q * T + t) * 8 : 0, 0, 0));
+      if (t >= T) v = u32x2{0u, 0u};
+      ss[(4 * q) * 32 + f] = bf16_lo(v[0]);
+      ss[(4 * q + 1) * 32 + f] = bf16_hi(v[0]);
+      ss[(4 * q + 2) * 32 + f] = bf16_lo(v[1]);
+      ss[(4 * q + 3) * 32 + f] = bf16_hi(v[1]);
+    }
+  } else if ((T & 3) == 0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = tid + 512 * k;
@@ -857,6 +831,13 @@ struct bsg_diffnet {
   float* apack1 = nullptr;  // [L][2C*3C]
   float* apack2 = nullptr;  // [L][2C*C]
   float* apackw = nullptr;  // [L][4*2C*C]  Winograd form of the dilated conv
+  unsigned short* apack1h = nullptr;  // [L][2C*3C] bf16 fragments (bf16-operand form, diffnet_bf16.hip)
+  unsigned short* apack2h = nullptr;  // [L][2C*C]
+  int compute = BSG_COMPUTE_F32;      // bsg_diffnet_set_compute
+  unsigned short* condterm_h = nullptr;  // [L][B][2C/4][T][4] bf16 (bf16 mode only)
+  unsigned short* skip_h = nullptr;      // [B][C/4][T][4] bf16
+  size_t cap_bt_h = 0;
+  int prepared_compute = BSG_COMPUTE_F32;   // mode the bound condition was prepared for
   float* w_cond = nullptr;  // [L][2C][H]
   float* b_cond = nullptr;  // [L][2C]  (b_cond + b_dil)
   float* b_out = nullptr;   // [L][2C]
@@ -912,6 +893,10 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->flags) (void)hipFree(h->flags);
   if (h->clk) (void)hipFree(h->clk);
+  if (h->apack1h) (void)hipFree(h->apack1h);
+  if (h->condterm_h) (void)hipFree(h->condterm_h);
+  if (h->skip_h) (void)hipFree(h->skip_h);
+  if (h->apack2h) (void)hipFree(h->apack2h);
   delete h;
 }
 
@@ -951,6 +936,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&h->apack1, (size_t)L * 2 * C * 3 * C));
   TRY(dev_alloc(&h->apack2, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->apackw, (size_t)L * 4 * 2 * C * C));
+  BSG_HIP(hipMalloc((void**)&h->apack1h, (size_t)L * 2 * C * 3 * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->apack2h, (size_t)L * 2 * C * C * sizeof(unsigned short)));
   TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->b_cond, (size_t)L * 2 * C));
   TRY(dev_alloc(&h->b_out, (size_t)L * 2 * C));
@@ -982,6 +969,9 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
       hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)lw[6],
                          h->apack2 + (size_t)l * total, 2 * C, C, C, (long long)C, 1LL, 0LL);
     }
+    rc = pack_a_frag_bf16((const float*)lw[0], h->apack1h + (size_t)l * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, st);
+    if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[6], h->apack2h + (size_t)l * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, st);
+    if (rc != BSG_OK) break;
     hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, (const float*)lw[5], (const float*)lw[1],
                        h->b_cond + (size_t)l * 2 * C, 2 * C);
     if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: pack kernels failed"); rc = BSG_EHIP; break; }
@@ -1092,9 +1082,23 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       BSG_HIP(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
     }
   }
-  for (int l = 0; l < h->L; ++l)
+  if (h->compute == BSG_COMPUTE_BF16 && bt > h->cap_bt_h) {
+    BSG_HIP(hipStreamSynchronize(st));
+    if (h->condterm_h) (void)hipFree(h->condterm_h);
+    if (h->skip_h) (void)hipFree(h->skip_h);
+    h->condterm_h = h->skip_h = nullptr;
+    h->cap_bt_h = 0;
+    BSG_HIP(hipMalloc((void**)&h->condterm_h, (size_t)h->L * 2 * C * bt * sizeof(unsigned short)));
+    BSG_HIP(hipMalloc((void**)&h->skip_h, (size_t)C * bt * sizeof(unsigned short)));
+    h->cap_bt_h = bt;
+  }
+  for (int l = 0; l < h->L; ++l) {
     TRY(conv1x1(h->w_cond + (size_t)l * 2 * C * C, h->b_cond + (size_t)l * 2 * C, cond,
                 h->condterm + (size_t)l * 2 * C * bt, 2 * C, C, B, T, ACT_NONE, st));
+    if (h->compute == BSG_COMPUTE_BF16)
+      TRY(f32_to_quad_bf16(h->condterm + (size_t)l * 2 * C * bt, h->condterm_h + (size_t)l * 2 * C * bt, B, 2 * C, T, st));
+  }
+  h->prepared_compute = h->compute;
   return BSG_OK;
 }
 
@@ -1114,12 +1118,25 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   a.apack1 = h->apack1 + (size_t)layer * 2 * C * 3 * C;
   a.apack2 = h->apack2 + (size_t)layer * 2 * C * C;
   a.apackw = h->apackw + (size_t)layer * 4 * 2 * C * C;
+  a.apack1h = h->apack1h + (size_t)layer * 2 * C * 3 * C;
+  a.apack2h = h->apack2h + (size_t)layer * 2 * C * C;
   a.bias_out = h->b_out + (size_t)layer * 2 * C;
   a.B = B; a.T = T; a.L = h->L; a.layer = layer;
   a.dil = 1 << (layer % h->cfg.dilation_cycle_length);
   a.first = layer == 0;
   a.skip_div = layer == h->L - 1 ? sqrtf((float)h->L) : 1.0f;
   a.stamps = stamps;
+  if (h->compute == BSG_COMPUTE_BF16) {
+    // the running skip sum lives in h->skip_h (bf16); a caller-supplied fp32 buffer (the unit-test hook) is converted
+    // in and out around the launch
+    a.condterm_h = h->condterm_h + (size_t)layer * 2 * C * (size_t)B * T;
+    a.skip_h = h->skip_h;
+    const bool ext = skip != h->skip;
+    if (ext && !a.first) TRY(f32_to_quad_bf16(skip, h->skip_h, B, C, T, st));
+    TRY(launch_residual_layer_bf16(a, st));
+    if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
+    return BSG_OK;
+  }
   // 32-frame tiles: 48 KB of LDS -> 3 workgroups per CU.  (Wider tiles of 64 / 128 frames were built and
   // measured in round 1: 0-50 % slower at every batch size, because fewer workgroups per CU hide less of the
   // L2 latency of the weight stream.)
@@ -1197,6 +1214,10 @@ static int check_bound(bsg_diffnet* h, int B, int T, const char* who) {
     set_error("%s: (B=%d,T=%d) does not match the condition bound by bsg_diffnet_prepare (B=%d,T=%d)", who, B, T, h->B, h->T);
     return BSG_ESTATE;
   }
+  if (h->compute == BSG_COMPUTE_BF16 && h->prepared_compute != BSG_COMPUTE_BF16) {
+    set_error("%s: the condition was bound before bsg_diffnet_set_compute(BF16); call bsg_diffnet_prepare again", who);
+    return BSG_ESTATE;
+  }
   return BSG_OK;
 }
 
@@ -1217,6 +1238,7 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
     h->prof_used += 2;
     h->prof_launches += h->L;
   }
+  if (h->compute == BSG_COMPUTE_BF16) TRY(quad_bf16_to_f32(h->skip_h, h->skip, B, C, T, st));
   TRY(conv1x1(h->w_skip, h->b_skip, h->skip, h->hid, C, C, B, T, ACT_RELU, st));   // net.py:127-128
   TRY(conv1x1(h->w_fin, h->b_fin, h->hid, eps, h->M, C, B, T, ACT_NONE, st));      // net.py:129
   return BSG_OK;
@@ -1292,7 +1314,8 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     float* nxt = h->xb;
     const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
     if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    if (use_persistent()) {
+    const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32;
+    if (persist) {
       TRY(launch_layers_persistent(h, nullptr, i, B, T, st));
     } else {
       for (int l = 0; l < h->L; ++l) {
@@ -1303,10 +1326,11 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     if (prof) {
       BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
       h->prof_used += 2;
-      h->prof_launches += use_persistent() ? 1 : h->L;
+      h->prof_launches += persist ? 1 : h->L;
     }
     TailArgs a{};
-    a.skip = h->skip; a.x = x; a.noise = noise ? noise + (long long)k * n : nullptr; a.xa_next = h->xa;
+    a.skip = h->skip; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h : nullptr;
+    a.x = x; a.noise = noise ? noise + (long long)k * n : nullptr; a.xa_next = h->xa;
     a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
     a.k = StepCoef{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
                    s->posterior_mean_coef2[i], s->sigma[i]};
@@ -1317,6 +1341,13 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     else hipLaunchKernelGGL(step_tail_kernel<96>, grid, block, tail_lds, st, a);
     BSG_LAUNCH_CHECK();
   }
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode) {
+  BSG_REQUIRE(h, "diffnet_set_compute: null handle");
+  BSG_REQUIRE(mode == BSG_COMPUTE_F32 || mode == BSG_COMPUTE_BF16, "diffnet_set_compute: unknown mode %d", mode);
+  h->compute = mode;
   return BSG_OK;
 }
 

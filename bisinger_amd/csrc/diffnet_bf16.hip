@@ -1,0 +1,358 @@
+// bf16-operand form of the fused DiffNet residual block (BASELINE config "B=64, T=1000, bf16").
+//
+// Same contract and the same HBM tensors as residual_layer_kernel (diffnet.hip; reference semantics
+// /root/reference/train_bisinger/usr/diff/net.py:66-78): x, the hoisted conditioner term and the running skip
+// residual stream x stays fp32 in HBM (it is the accumulator of the 20-layer chain); bf16 are every MFMA OPERAND — the
+// packed weights (rounded once at create), the staged x + d tile, the gated z tile — and the two largest HBM streams: the
+// hoisted conditioner term (rounded once per utterance) and the running skip sum, both in channel-quad order
+// [rows/4][T][4] so that a lane's 4 consecutive accumulator rows are one 8-byte access.  fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16), fp32 gate math, fp32 epilogue.  Measured (round 1, B=64): the layer runs at the fabric's
+// byte rate, not the matrix pipe's — every byte removed from HBM traffic is time.
+//
+// With 16x the fp32 MFMA rate the layer is no longer bound by the matrix pipe but by bytes: 6 KB / frame of HBM
+// tensors and the weight stream every workgroup pulls from L2 (1 MB of bf16 per workgroup).  Hence 64-frame
+// tiles (half the weight bytes per frame of the 32-frame fp32 tile) at 2 workgroups per CU:
+//
+//   stage  xs[f][c] = bf16(x[c][t0-8+f] + d[c])  (zero outside [0,T))  -> LDS, CHANNELS-LAST [80][256] bf16,
+//          528-B rows.  The MFMA B operand wants 8 consecutive k (channels) per lane, and a tap shift is then a
+//          row offset; lanes = consecutive frames, so global loads are 256-B coalesced dword rows and the
+//          16-B LDS stores are conflict-free (row stride = 4 banks mod 32).
+//   GEMM1  y[2C x 64] = W_dil * im2col(xs): 48 k-steps of 16 channels (3 taps x 16), per wave 2 row tiles
+//          (gate 32w.., filter 256+32w..) x 2 column tiles; A fragments stream from L2 in fragment order
+//          (16 B / lane), B fragments are one ds_read_b128 per column tile (conflict-free: consecutive frames
+//          are 4 banks apart, mod 64).
+//   gate   z = sigmoid(y_g + cond_g) * tanh(y_f + cond_f) in registers -> bf16 -> LDS [64][256] (own region)
+//   GEMM2  o = W_out * z, 16 k-steps; residual rows start from x + b_out, skip rows from b_out
+//   out    x_out = (x + res)/sqrt(2), skip += o_skip   (fp32, 128-B coalesced rows as in the fp32 kernel)
+#include "diffnet_res.h"
+
+namespace bsg {
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+constexpr int NT = 64;                    // frames per workgroup
+constexpr int ROWB = 2 * C + 16;          // LDS image row: 256 bf16 + 16 B pad = 528 B (132 dwords = 4 mod 64)
+constexpr int XROWS = NT + 2 * HALO;      // 80
+constexpr int XS_BYTES = XROWS * ROWB;    // 42,240
+constexpr int ZS_BYTES = NT * ROWB;       // 33,792
+constexpr int NS = 3;                     // A-fragment ring depth (k-steps)
+constexpr int KSB = 16 * 1024;            // bytes per k-step slab of a packed weight (16 row tiles x 1 KB)
+
+// out[((ks*(M/32) + rt)*64 + lane)*8 + j] = bf16( W(m = 32*rt + (lane&31), k = 16*ks + 8*(lane>>5) + j) )
+// k-step major: the 16 row tiles the 8 waves of a workgroup read in one k-step are one contiguous 16-KB slab, so the
+// requests of workgroups that run in step spread over every L2 channel (row-tile major put them 48 KB apart — the same
+// few channels for every wave — and ran at a quarter of the L2 rate)
+// with W(m,k) at src[m*sm + (k % Kc)*sc + (k / Kc)*st]   (dilated conv: k = tap*C + ci, src [2C][C][3])
+__global__ void pack_a_frag_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ out, int M, int K, int Kc,
+                                        long long sm, long long sc, long long st) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * K) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  const long long rest = i >> 9;
+  const int RT = M / 32;
+  const int rt = (int)(rest % RT), ks = (int)(rest / RT);
+  const int m = 32 * rt + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+  out[i] = (__bf16)src[(long long)m * sm + (long long)(k % Kc) * sc + (long long)(k / Kc) * st];
+}
+
+__device__ __forceinline__ bf16x8 lda8(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  return __builtin_bit_cast(unsigned, bf16x2{(__bf16)lo, (__bf16)hi});
+}
+
+#define BSG_MFMA_BF(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
+
+// k-step pipeline over two row tiles x two column tiles.  A fragments (global, L2) live in a ring of NS k-steps and are
+// refilled right after use, i.e. NS-1 k-steps (4 MFMAs = 128 matrix-pipe cycles each, x4 waves per SIMD) ahead; the B
+// fragments (LDS) of the next k-step are read while the current one multiplies.  sched_barrier pins that order.
+template <typename LDB>
+__device__ __forceinline__ void mfma_pipe_bf(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, bf16x8 (&A0)[NS], bf16x8 (&A1)[NS],
+                                             rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks, LDB ldb) {
+  bf16x8 B0[2], B1[2];
+  B0[0] = ldb(0, 0);
+  B1[0] = ldb(0, 1);
+  const int last = n_ks - 1;
+#pragma unroll 1
+  for (int ks = 0; ks < n_ks; ks += 2 * NS) {
+#pragma unroll
+    for (int s = 0; s < 2 * NS; ++s) {
+      if (ks + s < n_ks) {   // wave-uniform; n_ks is 48 or 16, the unrolled body covers 6 k-steps
+        const int kn = ks + s + 1 <= last ? ks + s + 1 : last;
+        B0[(s + 1) & 1] = ldb(kn, 0);
+        B1[(s + 1) & 1] = ldb(kn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        BSG_MFMA_BF(c00, A0[s % NS], B0[s & 1]);
+        BSG_MFMA_BF(c10, A1[s % NS], B0[s & 1]);
+        BSG_MFMA_BF(c01, A0[s % NS], B1[s & 1]);
+        BSG_MFMA_BF(c11, A1[s % NS], B1[s & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kr = ks + s + NS <= last ? ks + s + NS : last;
+        A0[s % NS] = lda8(rs, vfrag, sa0 + kr * KSB);
+        A1[s % NS] = lda8(rs, vfrag, sa1 + kr * KSB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+#define BSG_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (STAMP) {                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      const unsigned long long _t = __builtin_amdgcn_s_memtime();                                      \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
+      if (lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + (i)] = _t;                      \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
+  } while (0)
+
+template <bool STAMP>   // STAMP: diagnostic build with s_memtime stamps at the phase boundaries (tools/stamp_layer.py)
+__global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;
+  char* zs = lds_raw + XS_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tile_id = blockIdx.x;
+  const int b = tile_id / a.tiles_per_row;
+  const int t0 = (tile_id - b * a.tiles_per_row) * NT;
+  const int T = a.T;
+  const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(a.x_in + (long long)b * C * T, plane);
+  const rsrc_t rs_xo = mk_rsrc(a.x_out + (long long)b * C * T, plane);
+  const rsrc_t rs_sk = mk_rsrc(a.skip_h + (long long)b * C * T, plane / 2);
+  const rsrc_t rs_ct = mk_rsrc(a.condterm_h + (long long)b * 2 * C * T, plane);
+  const rsrc_t rs_a1 = mk_rsrc(a.apack1h, 2 * C * 3 * C * 2);
+  const rsrc_t rs_a2 = mk_rsrc(a.apack2h, 2 * C * C * 2);
+  const rsrc_t rs_bo = mk_rsrc(a.bias_out, 2 * C * 4);
+  const float* dp = a.dproj + ((long long)tb * a.L + a.layer) * C;
+  const rsrc_t rs_dp = mk_rsrc(dp, C * 4);
+  const int rowT = T * 4;
+  const int vfrag = lane * 16;
+
+  BSG_STAMP(0);
+  if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 8] = __builtin_amdgcn_s_memrealtime();
+  // ---- (1) the first A fragments fly while the x tile is staged ------------------------------------
+  bf16x8 Ag[NS], Af[NS];
+  const int sa_g = wave * 1024, sa_f = (8 + wave) * 1024;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    Ag[k] = lda8(rs_a1, vfrag, sa_g + k * KSB);
+    Af[k] = lda8(rs_a1, vfrag, sa_f + k * KSB);
+  }
+
+  // ---- (2) stage xs[f][c] = bf16(x + d), zero outside [0,T) ---------------------------------------
+  {
+    // core 64 frames: lane = frame, the wave walks its 4 chunks of 8 channels (wave-uniform rows -> SGPR offsets)
+    const int t = t0 + lane;
+    const bool ok = t < T;
+    const int vt = (ok ? t : 0) * 4;
+    float v[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = ldf(rs_x, vt, (8 * (4 * wave + i) + j) * rowT);
+    // halo 2 x 8 frames: 16 lanes = 16 halo frames of one 8-channel chunk
+    const int hf = tid & 15, hc = tid >> 4;
+    const int th = hf < 8 ? t0 - HALO + hf : t0 + NT - 8 + hf;
+    const int hrow = hf < 8 ? hf : NT + hf;
+    const bool hok = th >= 0 && th < T;
+    float hv[8], hd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      hv[j] = ldf(rs_x, hok ? ((8 * hc + j) * T + th) * 4 : 0, 0);
+      hd[j] = ldf(rs_dp, (8 * hc + j) * 4, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c8 = 4 * wave + i;
+      u32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = v[i][2 * j] + dp[8 * c8 + 2 * j], hi = v[i][2 * j + 1] + dp[8 * c8 + 2 * j + 1];
+        w[j] = ok ? pack2(lo, hi) : 0u;
+      }
+      *reinterpret_cast<u32x4*>(xs + (HALO + lane) * ROWB + c8 * 16) = w;
+    }
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = hok ? pack2(hv[2 * j] + hd[2 * j], hv[2 * j + 1] + hd[2 * j + 1]) : 0u;
+    *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = w;
+  }
+  __syncthreads();
+  BSG_STAMP(1);
+  BSG_STAMP(2);
+
+  // accumulator columns of this lane: frame t0 + 32*ct + l31
+  int vcol[2], vst[2], vq[2], vqs[2];   // vq: byte offset in a channel-quad bf16 plane ((quad lh)*T + frame)*8
+  bool col_ok[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = t0 + 32 * ct + l31;
+    col_ok[ct] = col < T;
+    vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
+    vst[ct] = (lh * 4 * T + col) * 4;
+    vq[ct] = (lh * T + (col_ok[ct] ? col : T - 1)) * 8;
+    vqs[ct] = (lh * T + col) * 8;
+  }
+
+  // ---- (3) GEMM1: 48 k-steps (tap-major) ----------------------------------------------------------
+  f32x16 yg0, yf0, yg1, yf1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) yg0[r] = yf0[r] = yg1[r] = yf1[r] = 0.f;
+  {
+    const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
+    const int dil = a.dil;
+    auto ldb = [&](int ks, int ct) {
+      const int tap = ks >> 4, kc = ks & 15;
+      return *reinterpret_cast<const bf16x8*>(xb + ((tap - 1) * dil + 32 * ct) * ROWB + kc * 32);
+    };
+    mfma_pipe_bf(yg0, yf0, yg1, yf1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 48, ldb);
+  }
+  BSG_STAMP(3);
+
+  // ---- (4) + hoisted conditioner term, gate -> zs (requested after GEMM1, see diffnet.hip) ----------
+  const int sb_r = wave * 1024, sb_s = (8 + wave) * 1024;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    Ag[k] = lda8(rs_a2, vfrag, sb_r + k * KSB);
+    Af[k] = lda8(rs_a2, vfrag, sb_s + k * KSB);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    // registers 4g..4g+3 = channels 32w + 8g + 4*lh + (0..3) = quad 8w + 2g + lh of the conditioner term
+    float cg[16], cf[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 qg = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[ct], (8 * wave + 2 * g) * T * 8, 0));
+      const u32x2 qf = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[ct], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+      cg[4 * g] = bf16_lo(qg[0]); cg[4 * g + 1] = bf16_hi(qg[0]); cg[4 * g + 2] = bf16_lo(qg[1]); cg[4 * g + 3] = bf16_hi(qg[1]);
+      cf[4 * g] = bf16_lo(qf[0]); cf[4 * g + 1] = bf16_hi(qf[0]); cf[4 * g + 2] = bf16_lo(qf[1]); cf[4 * g + 3] = bf16_hi(qf[1]);
+    }
+    const f32x16& yg = ct ? yg1 : yg0;
+    const f32x16& yf = ct ? yf1 : yf0;
+    float z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = fast_sigmoid(yg[r] + cg[r]) * fast_tanh(yf[r] + cf[r]);
+    // registers 4g..4g+3 are channels 32w + 8g + 4*lh + (0..3) of frame 32*ct + l31
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<u32x2*>(zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) =
+          u32x2{pack2(z[4 * g], z[4 * g + 1]), pack2(z[4 * g + 2], z[4 * g + 3])};
+    }
+  }
+  BSG_STAMP(4);
+  // residual rows start from x + b_out, skip rows from b_out
+  f32x16 or0, os0, or1, os1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float br = ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
+    const float bs = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
+    or0[r] = ldf(rs_x, vcol[0], (32 * wave + acc_row0(r)) * rowT) + br;
+    or1[r] = ldf(rs_x, vcol[1], (32 * wave + acc_row0(r)) * rowT) + br;
+    os0[r] = bs;
+    os1[r] = bs;
+  }
+  __syncthreads();
+  BSG_STAMP(5);
+
+  // ---- (5) GEMM2: 16 k-steps ------------------------------------------------------------------------
+  {
+    const char* zb = zs + l31 * ROWB + lh * 16;
+    auto ldb = [&](int ks, int ct) { return *reinterpret_cast<const bf16x8*>(zb + 32 * ct * ROWB + ks * 32); };
+    mfma_pipe_bf(or0, os0, or1, os1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, ldb);
+  }
+  BSG_STAMP(6);
+
+  // ---- (6) epilogue ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const f32x16& orr = ct ? or1 : or0;
+    const f32x16& oss = ct ? os1 : os0;
+    u32x2 pq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      pq[g] = a.first ? u32x2{0u, 0u}
+                      : __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_sk, vq[ct], (8 * wave + 2 * g) * T * 8, 0));
+    if (col_ok[ct]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stf(orr[r] / 1.41421356237309504880f, rs_xo, vst[ct], (32 * wave + acc_row0(r)) * rowT);   // (x + residual) / sqrt(2), net.py:78
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {   // running skip sum (/ sqrt(L) last, :126), stored as bf16
+        const float s0 = (bf16_lo(pq[g][0]) + oss[4 * g]) / a.skip_div, s1 = (bf16_hi(pq[g][0]) + oss[4 * g + 1]) / a.skip_div;
+        const float s2 = (bf16_lo(pq[g][1]) + oss[4 * g + 2]) / a.skip_div, s3 = (bf16_hi(pq[g][1]) + oss[4 * g + 3]) / a.skip_div;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(s0, s1), pack2(s2, s3)},
+                                              rs_sk, vqs[ct], (8 * wave + 2 * g) * T * 8, 0);
+      }
+    }
+  }
+  BSG_STAMP(7);
+  if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 9] = __builtin_amdgcn_s_memrealtime();
+}
+#undef BSG_STAMP
+
+__global__ void f32_to_quad_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float* s = src + ((long long)b * rows + 4 * q) * T + t;
+  *reinterpret_cast<u32x2*>(dst + (((long long)b * (rows / 4) + q) * T + t) * 4) = u32x2{pack2(s[0], s[T]), pack2(s[2 * (long long)T], s[3 * (long long)T])};
+}
+__global__ void quad_bf16_to_f32_kernel(const unsigned short* __restrict__ src, float* __restrict__ dst, int rows, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const u32x2 v = *reinterpret_cast<const u32x2*>(src + (((long long)b * (rows / 4) + q) * T + t) * 4);
+  float* d = dst + ((long long)b * rows + 4 * q) * T + t;
+  d[0] = bf16_lo(v[0]); d[T] = bf16_hi(v[0]); d[2 * (long long)T] = bf16_lo(v[1]); d[3 * (long long)T] = bf16_hi(v[1]);
+}
+
+}  // namespace
+
+int f32_to_quad_bf16(const float* src, unsigned short* dst, int B, int rows, int T, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_quad_bf16_kernel, dim3(cdiv(T, 256), rows / 4, B), dim3(256), 0, st, src, dst, rows, T);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+int quad_bf16_to_f32(const unsigned short* src, float* dst, int B, int rows, int T, hipStream_t st) {
+  hipLaunchKernelGGL(quad_bf16_to_f32_kernel, dim3(cdiv(T, 256), rows / 4, B), dim3(256), 0, st, src, dst, rows, T);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+int pack_a_frag_bf16(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp,
+                     hipStream_t st) {
+  const long long total = (long long)M * K;
+  hipLaunchKernelGGL(pack_a_frag_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, reinterpret_cast<__bf16*>(out), M, K,
+                     Kc, sm, sc, stp);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// `a.tiles_per_row` is set here: this form tiles an utterance in 64-frame pieces
+int launch_residual_layer_bf16(const ResArgs& a_in, hipStream_t st) {
+  ResArgs a = a_in;
+  a.tiles_per_row = cdiv(a.T, NT);
+  const size_t lds = XS_BYTES + ZS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (a.stamps) hipLaunchKernelGGL(residual_layer_bf16_kernel<true>, dim3(a.B * a.tiles_per_row), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(residual_layer_bf16_kernel<false>, dim3(a.B * a.tiles_per_row), dim3(512), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+}  // namespace bsg

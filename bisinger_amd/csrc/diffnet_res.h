@@ -1,0 +1,73 @@
+// Shared by the fp32 (diffnet.hip) and bf16-operand (diffnet_bf16.hip) forms of the fused residual block.
+#pragma once
+#include "bsg_common.h"
+
+namespace bsg {
+
+constexpr int C = 256;     // residual channels == encoder hidden (checked at create)
+constexpr int HALO = 8;    // max dilation 2^3
+
+struct ResArgs {
+  const float* x_in;     // [B][C][T]
+  float* x_out;          // [B][C][T]
+  float* skip;           // [B][C][T]
+  const float* condterm; // this layer's [B][2C][T]: conditioner_projection(cond) + b_cond + b_dil
+  const float* dproj;    // [S][L][C] table: diffusion_projection_l(mlp(emb(step)))
+  const long long* t_dev;  // [B] or null
+  int t_uniform;
+  const float* apack1;   // dilated conv, packed  [16][96][64][4]
+  const float* apack2;   // output projection     [16][32][64][4]
+  const float* apackw;   // dilated conv in Winograd F(2,3) form, packed for 16x16x4 MFMAs [4][32][16][64][4]
+  const unsigned short* apack1h;  // bf16 operand path: dilated conv packed for 32x32x16 bf16 MFMAs [16][48][64][8]
+  const unsigned short* apack2h;  // bf16 operand path: output projection                           [16][16][64][8]
+  // bf16-operand path: conditioner term and running skip sum are STORED as bf16 in channel-quad order
+  // [B][rows/4][T][4] (one 8-byte access per lane = 4 consecutive channels of one frame, 256-B coalesced)
+  const unsigned short* condterm_h;  // this layer's [B][2C/4][T][4]
+  unsigned short* skip_h;            // [B][C/4][T][4]
+  const float* bias_out; // [2C]
+  int B, T, L, layer, dil, tiles_per_row;
+  int first;             // layer 0: skip is stored, not accumulated
+  float skip_div;        // last layer: skip_sum / sqrt(L) (net.py:126); 1 otherwise
+  unsigned long long* stamps;  // diagnostic build only (STAMP = true): [workgroup][wave][8] s_memtime values
+};
+
+// bf16-operand form of the residual layer (diffnet_bf16.hip); same tensors, 64-frame tiles
+int launch_residual_layer_bf16(const ResArgs& a, hipStream_t st);
+// fp32 [M][K] weights -> bf16 A fragments of v_mfma_f32_32x32x16_bf16 (see diffnet_bf16.hip)
+int pack_a_frag_bf16(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp,
+                     hipStream_t st);
+
+// fp32 [B][rows][T] <-> bf16 channel-quad order [B][rows/4][T][4] (rows % 4 == 0)
+int f32_to_quad_bf16(const float* src, unsigned short* dst, int B, int rows, int T, hipStream_t st);
+int quad_bf16_to_f32(const unsigned short* src, float* dst, int B, int rows, int T, hipStream_t st);
+
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+
+// fast gate math: v_exp_f32 / v_rcp_f32 based (abs error ~2e-7, far inside the 1e-3 mel budget); the libm
+// versions cost ~60 VALU instructions per element and the gate phase runs with the MFMA pipe idle.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+
+// Buffer (SRSRC) addressing: one wave-uniform 128-bit descriptor per tensor, a per-lane 32-bit byte offset that
+// is computed once, and a wave-uniform SGPR offset per access — the 32 row-strided loads of an accumulator tile
+// then need ONE address VGPR instead of 32 64-bit pairs (what keeps the kernel at <= 80 VGPRs = 3 workgroups/CU).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldf(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 ldf4(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void stf(float v, rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+// uniform part of acc_row(): register r of a 32x32 accumulator covers row (r&3) + 8*(r>>2) (+ 4 for lanes >= 32)
+__device__ __forceinline__ constexpr int acc_row0(int r) { return (r & 3) + 8 * (r >> 2); }
+
+
+}  // namespace bsg

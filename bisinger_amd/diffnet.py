@@ -71,6 +71,9 @@ class DiffNet(nn.Module):
         self.skip_projection = _conv1d(C, C, 1)
         self.output_projection = _conv1d(C, in_dims, 1)
         nn.init.zeros_(self.output_projection.weight)
+        # extension (not in the reference): arithmetic of the fused residual layers, 'fp32' (parity) or 'bf16'
+        # (bf16 MFMA operands, fp32 accumulation; BASELINE config 3) — include/bisinger_hip.h bsg_diffnet_set_compute
+        self.compute_dtype = str(hparams.get('diff_compute_dtype', 'fp32'))
         self._h = None
         self._h_key = None
         self._bound = None
@@ -104,7 +107,25 @@ class DiffNet(nn.Module):
             _lib.check(lib.bsg_diffnet_create(byref(h), byref(cfg), cast(arr, POINTER(c_void_p)), len(ws),
                                               _lib.ptr(table), _lib.stream_ptr()), 'bsg_diffnet_create')
         self._h, self._h_key, self._bound = h, key, None
+        self._apply_compute()
         return h
+
+    _COMPUTE = {'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+
+    def _apply_compute(self):
+        if self.compute_dtype not in self._COMPUTE:
+            raise _lib.BsgError(f"diff_compute_dtype={self.compute_dtype!r}: expected 'fp32' or 'bf16'")
+        _lib.check(_lib.load().bsg_diffnet_set_compute(self._h, self._COMPUTE[self.compute_dtype]), 'bsg_diffnet_set_compute')
+
+    def set_compute(self, dtype):
+        """'fp32' (default, the <=1e-3 parity configuration) or 'bf16' (bf16 MFMA operands, fp32 accumulation)."""
+        if str(dtype) != self.compute_dtype:
+            self._bound = None          # the bf16 form keeps its own copy of the hoisted conditioner term: bind again
+        self.compute_dtype = str(dtype)
+        if self._h is not None:
+            self._apply_compute()
+        elif self.compute_dtype not in self._COMPUTE:
+            raise _lib.BsgError(f"diff_compute_dtype={self.compute_dtype!r}: expected 'fp32' or 'bf16'")
 
     def release(self):
         if self._h is not None:

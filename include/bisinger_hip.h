@@ -135,6 +135,15 @@ int bsg_mel_finish(const float* x, const float* spec_min, const float* spec_max,
  * or 1 when the L layers run as one persistent launch). */
 int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable);
 int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_layer_launches);
+/* Arithmetic of the fused residual layers (BASELINE config "bf16 diffusion mel-gen"):
+ *   BSG_COMPUTE_F32  (default) fp32 operands, fp32 MFMA — the parity configuration (<= 1e-3 on the mel);
+ *   BSG_COMPUTE_BF16 MFMA operands (weights, staged x + d, gated z) rounded to bf16 (RNE), fp32 accumulation, fp32
+ *                    gate/epilogue, and x / conditioner term / skip kept fp32 in HBM — a throughput configuration
+ *                    whose deviation from the fp32 path is reported by tests/test_gpu_bf16.py and bench.py.
+ * Takes effect on the next forward / sample call on the handle. */
+#define BSG_COMPUTE_F32 0
+#define BSG_COMPUTE_BF16 1
+int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode);
 /* Synchronous health check of the persistent multi-layer launch (BSG_PERSIST=1): number of inter-workgroup
  * hand-off spins that gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
 int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);

@@ -31,10 +31,27 @@ def step_embedding(sd, t, C, prefix='', dtype=torch.float32):
     return F.linear(h, g('mlp.2.weight'), g('mlp.2.bias'))
 
 
-def residual_block(sd, p, x, cond, d, dilation, dtype=torch.float32):
+def _bf16(x):
+    """round-to-nearest-even to bfloat16, kept in the working dtype (emulates a bf16 MFMA operand)"""
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def residual_block(sd, p, x, cond, d, dilation, dtype=torch.float32, operand_bf16=False):
     """net.py:66-78.  gate = first C channels -> sigmoid, filter = last C -> tanh;
-    residual = first C of the output projection, skip = last C."""
+    residual = first C of the output projection, skip = last C.
+    operand_bf16: emulate the build's bf16 configuration (BASELINE config 3) — the two conv weights, the conv input x + d,
+    the hoisted conditioner term and the gated activation are rounded to bf16, everything else (accumulation, gate,
+    residual stream) as above.  (The build also STORES the running skip sum as bf16; the caller of this function sums.)"""
     g = lambda k: sd[p + k].to(dtype)
+    if operand_bf16:
+        dp = F.linear(d, g('diffusion_projection.weight'), g('diffusion_projection.bias')).unsqueeze(-1)
+        c = _bf16(F.conv1d(cond, g('conditioner_projection.weight'), g('conditioner_projection.bias')) + g('dilated_conv.bias')[None, :, None])
+        y = F.conv1d(_bf16(x + dp), _bf16(g('dilated_conv.weight')), None, padding=dilation, dilation=dilation) + c
+        gate, filt = torch.chunk(y, 2, dim=1)
+        y = _bf16(torch.sigmoid(gate) * torch.tanh(filt))
+        y = F.conv1d(y, _bf16(g('output_projection.weight')), g('output_projection.bias'))
+        res, skip = torch.chunk(y, 2, dim=1)
+        return (x + res) / math.sqrt(2.0), skip
     dp = F.linear(d, g('diffusion_projection.weight'), g('diffusion_projection.bias')).unsqueeze(-1)
     c = F.conv1d(cond, g('conditioner_projection.weight'), g('conditioner_projection.bias'))
     y = F.conv1d(x + dp, g('dilated_conv.weight'), g('dilated_conv.bias'),
@@ -46,7 +63,7 @@ def residual_block(sd, p, x, cond, d, dilation, dtype=torch.float32):
     return (x + res) / math.sqrt(2.0), skip
 
 
-def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=torch.float32):
+def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=torch.float32, operand_bf16=False):
     """spec [B,1,M,T], t [B] int64, cond [B,H,T] -> eps [B,1,M,T]   (net.py:107-130)."""
     g = lambda k: sd[prefix + k].to(dtype)
     spec = spec.to(dtype)
@@ -56,7 +73,7 @@ def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=to
     d = step_embedding(sd, t, x.shape[1], prefix, dtype)
     skips = []
     for i in range(n_layers):
-        x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype)
+        x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype, operand_bf16)
         skips.append(s)
     x = torch.sum(torch.stack(skips), dim=0) / math.sqrt(n_layers)
     x = F.relu(F.conv1d(x, g('skip_projection.weight'), g('skip_projection.bias')))

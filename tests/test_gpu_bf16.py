@@ -1,0 +1,117 @@
+"""GPU: the bf16-operand configuration of the fused residual layers (BASELINE configs[2]; bsg_diffnet_set_compute).
+
+Not a parity configuration: the <= 1e-3 mel bar belongs to fp32 (test_gpu_*.py).  Two checks pin what it computes:
+  (1) against the oracle with the SAME rounding emulated (oracle.diffnet.residual_block(operand_bf16=True)):
+      weights, x + d, the hoisted conditioner term, the gated z and the stored skip sum rounded to bf16 (RNE), fp32 accumulation — the kernel must agree up to fp32
+      summation order and the rare 1-ulp bf16 flips that a 1e-7 difference before a rounding causes;
+  (2) its deviation from the fp32 configuration over a full 100-step sampler run is bounded and printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from bisinger_amd import synth
+from oracle import diffnet as odn
+from tests.util import cpu_sd, load_formula_weights, maxabs, use_config
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+T_ = torch.from_numpy
+
+
+@pytest.fixture(scope='module')
+def net():
+    use_config()
+    from bisinger_amd.diffnet import DiffNet
+    m = DiffNet(80)
+    load_formula_weights(m, 0, synth.DIFFNET_GAIN, prefix='denoise_fn.')
+    m = m.cuda()
+    yield m
+    m.set_compute('fp32')
+
+
+@pytest.mark.parametrize('B,T', [(2, 64), (3, 77), (1, 31), (5, 333), (2, 1000)])
+@pytest.mark.parametrize('layer', [0, 1, 2, 3, 19])
+def test_residual_layer_bf16(net, B, T, layer):
+    """every dilation, partial last 64-frame tile, T < one tile, first-layer store / last-layer scaling of the skip sum"""
+    sd = cpu_sd(net, 'denoise_fn.')
+    rs = np.random.RandomState(100 * B + T + layer)
+    x = rs.standard_normal((B, 256, T)).astype(np.float32)
+    cond = rs.standard_normal((B, 256, T)).astype(np.float32)
+    skip0 = rs.standard_normal((B, 256, T)).astype(np.float32)
+    t = rs.randint(0, 100, size=(B,)).astype(np.int64)
+    d = odn.step_embedding(sd, T_(t), 256, 'denoise_fn.')
+    p = f'denoise_fn.residual_layers.{layer}.'
+    rx, rskip = odn.residual_block(sd, p, T_(x), T_(cond), d, 2 ** (layer % 4), operand_bf16=True)
+    fx, fskip = odn.residual_block(sd, p, T_(x), T_(cond), d, 2 ** (layer % 4))
+    scale = 1 / 20 ** 0.5 if layer == 19 else 1.0
+    bf = lambda v: v.to(torch.bfloat16).float()
+    want_skip = bf((rskip if layer == 0 else bf(T_(skip0)) + rskip) * scale)     # the skip sum is stored as bf16
+    net.set_compute('bf16')
+    net.prepare(T_(cond).cuda())
+    skip = T_(skip0).cuda()
+    if layer == 0:
+        skip.fill_(float('nan'))
+    out = net.residual_layer(layer, T_(x).cuda(), T_(t).cuda(), skip)
+    torch.cuda.synchronize()
+    net.set_compute('fp32')
+    e_x, e_s = maxabs(out, rx), maxabs(skip, want_skip)
+    q_x, q_s = maxabs(rx, fx), maxabs(rskip, fskip)          # what the operand rounding itself costs
+    print(f'bf16 layer {layer} B={B} T={T}: kernel vs bf16-emulating oracle {e_x:.2e}/{e_s:.2e}; '
+          f'rounding cost vs fp32 oracle {q_x:.2e}/{q_s:.2e}')
+    assert e_x <= 5e-3 and e_s <= 6.3e-2      # skip: a 1-ulp bf16 flip of a stored value of magnitude < 16
+    assert e_x < 0.5 * q_x + 1e-4 or e_x <= 2e-4      # far closer to the emulation than the emulation is to fp32
+
+
+def test_bf16_does_not_change_fp32_results(net):
+    """switching the mode back restores the bit-identical fp32 path"""
+    rs = np.random.RandomState(5)
+    x = T_(rs.standard_normal((2, 1, 80, 96)).astype(np.float32)).cuda()
+    cond = T_(rs.standard_normal((2, 256, 96)).astype(np.float32)).cuda()
+    t = torch.tensor([3, 77], device='cuda')
+    a = net(x, t, cond).clone()
+    net.set_compute('bf16')
+    b = net(x, t, cond).clone()
+    net.set_compute('fp32')
+    c = net(x, t, cond).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)
+    assert not torch.equal(a, b)
+    dev = maxabs(a, b)
+    print(f'DiffNet eps, bf16 operands vs fp32: max abs {dev:.3e} (eps rms {float(a.pow(2).mean().sqrt()):.3f})')
+    assert dev <= 5e-2
+
+
+def test_sampler_bf16_deviation():
+    """full 100-step DDPM run, same supplied noise: bf16-operand mel vs fp32 mel (normalised units, range [-1, 1])"""
+    use_config()
+    from bisinger_amd.diffnet import DiffNet
+    from bisinger_amd.diffusion import GaussianDiffusion
+    from bisinger_amd.hparams import hparams
+
+    class Enc:
+        def __len__(self):
+            return 65
+
+        def pad(self):
+            return 0
+
+    m = GaussianDiffusion(Enc(), 80, DiffNet(80), timesteps=100, K_step=100, spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+    load_formula_weights(m, 0, synth.DIFFNET_GAIN)
+    m = m.cuda().eval()
+    B, T = 2, 128
+    rs = np.random.RandomState(3)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    noise = T_(synth.synth_noise(100, B, 80, T, seed=7)).cuda()
+    res = {}
+    for mode in ('fp32', 'bf16'):
+        m.denoise_fn.set_compute(mode)
+        x = noise[0][:, None].contiguous().clone()
+        res[mode] = m.sample(cond, x, noise=noise[1:], n_steps=100).clone()
+    torch.cuda.synchronize()
+    m.denoise_fn.set_compute('fp32')
+    dev = maxabs(res['fp32'], res['bf16'])
+    rms = float((res['fp32'] - res['bf16']).pow(2).mean().sqrt())
+    print(f'100-step sampler, bf16 operands vs fp32: max abs {dev:.3e}, rms {rms:.3e} (normalised mel in [-1, 1])')
+    assert torch.isfinite(res['bf16']).all()
+    assert dev <= 0.1 and rms <= 0.02

@@ -17,6 +17,8 @@ use_config()
 from bisinger_amd.diffnet import DiffNet  # noqa: E402
 
 net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else 'fp32'   # fp32 | bf16
+net.set_compute(DTYPE)
 FLOP_LAYER = 1048576.0
 FLOP_NET = 21184512.0
 for B, T in [(16, 1000), (64, 1000), (8, 1000), (1, 500)]:
@@ -37,7 +39,7 @@ for B, T in [(16, 1000), (64, 1000), (8, 1000), (1, 500)]:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        print(f'layer B={B} T={T}: {ms * 1e3:.1f} us  {FLOP_LAYER * B * T / ms / 1e9:.1f} TFLOP/s', flush=True)
+        print(f'{DTYPE} layer B={B} T={T}: {ms * 1e3:.1f} us  {FLOP_LAYER * B * T / ms / 1e9:.1f} TFLOP/s  {6144.0 * B * T / ms / 1e6:.0f} GB/s (algorithmic)', flush=True)
     spec = torch.randn(B, 1, 80, T, device='cuda')
     for _ in range(2):
         net(spec, t, cond)

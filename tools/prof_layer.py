@@ -19,6 +19,7 @@ B = int(os.environ.get('PB', 16))
 T = int(os.environ.get('PT', 1000))
 N = int(os.environ.get('PN', 20))
 net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+net.set_compute(os.environ.get('PD', 'fp32'))   # fp32 | bf16
 cond = torch.randn(B, 256, T, device='cuda')
 x = torch.randn(B, 256, T, device='cuda')
 skip = torch.zeros(B, 256, T, device='cuda')

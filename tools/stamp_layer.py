@@ -17,13 +17,16 @@ from bisinger_amd.diffnet import DiffNet  # noqa: E402
 
 B, T = int(os.environ.get('PB', 16)), int(os.environ.get('PT', 1000))
 net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+DT = os.environ.get('PD', 'fp32')
+net.set_compute(DT)
 cond = torch.randn(B, 256, T, device='cuda')
 x = torch.randn(B, 256, T, device='cuda')
 out = torch.empty_like(x)
 skip = torch.zeros(B, 256, T, device='cuda')
 t = torch.full((B,), 50, dtype=torch.long, device='cuda')
 net.prepare(cond)
-nwg = B * ((T + 31) // 32)
+NTILE = 64 if DT == 'bf16' else 32
+nwg = B * ((T + NTILE - 1) // NTILE)
 st = torch.zeros(nwg, 8, 10, dtype=torch.int64, device='cuda')
 lib = _lib.load()
 for it in range(3):
