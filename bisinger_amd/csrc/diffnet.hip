@@ -389,7 +389,12 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
 
 template <bool STAMP, bool WINO>
 __global__ __launch_bounds__(512, WINO ? 4 : 6) void residual_layer_kernel(ResArgs a) {
-  residual_tile<STAMP, false, 2, WINO>(a, (int)blockIdx.x);
+  // XCD-aware tile order: workgroup i runs on XCD i % 8; a contiguous run of tiles per XCD lets neighbouring tiles share
+  // their halo lines in one L2 (the halo of a tile is its neighbours' core)
+  const int n_tiles = a.B * a.tiles_per_row, per_xcd = (n_tiles + 7) >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile_id >= n_tiles) return;
+  residual_tile<STAMP, false, 2, WINO>(a, tile_id);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1141,7 +1146,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   // measured in round 1: 0-50 % slower at every batch size, because fewer workgroups per CU hide less of the
   // L2 latency of the weight stream.)
   a.tiles_per_row = cdiv(T, 32);
-  const dim3 grid(B * a.tiles_per_row), block(512);
+  const dim3 grid(8 * cdiv(B * a.tiles_per_row, 8)), block(512);   // see the tile order in residual_layer_kernel
   const size_t lds = (size_t)C * (32 + 2 * HALO) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {

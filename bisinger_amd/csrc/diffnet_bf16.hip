@@ -121,7 +121,11 @@ __global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int tile_id = blockIdx.x;
+  // XCD-aware tile order: workgroup i runs on XCD i % 8, so give the workgroups of one XCD a contiguous run of tiles —
+  // the two halo lines of a tile are its neighbours' core lines, and neighbours that share an L2 fetch them once
+  const int per_xcd = (a.B * a.tiles_per_row + 7) >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile_id >= a.B * a.tiles_per_row) return;
   const int b = tile_id / a.tiles_per_row;
   const int t0 = (tile_id - b * a.tiles_per_row) * NT;
   const int T = a.T;
@@ -343,14 +347,15 @@ int launch_residual_layer_bf16(const ResArgs& a_in, hipStream_t st) {
   ResArgs a = a_in;
   a.tiles_per_row = cdiv(a.T, NT);
   const size_t lds = XS_BYTES + ZS_BYTES;
+  const int grid = 8 * cdiv(a.B * a.tiles_per_row, 8);   // see the tile order in the kernel
   static bool attr_set = false;
   if (!attr_set) {
     BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  if (a.stamps) hipLaunchKernelGGL(residual_layer_bf16_kernel<true>, dim3(a.B * a.tiles_per_row), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(residual_layer_bf16_kernel<false>, dim3(a.B * a.tiles_per_row), dim3(512), lds, st, a);
+  if (a.stamps) hipLaunchKernelGGL(residual_layer_bf16_kernel<true>, dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL(residual_layer_bf16_kernel<false>, dim3(grid), dim3(512), lds, st, a);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

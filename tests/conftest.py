@@ -15,6 +15,9 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle is the slow side of every parity test; PyTorch's default of one thread per hardware thread is far
+    # from the fastest setting on a many-core host (bench.py calibrates the same way)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 def pytest_collection_modifyitems(config, items):
