@@ -23,13 +23,13 @@
 namespace bsg {
 namespace {
 
-constexpr int TT = 4;           // samples per lane (stride 64)
-constexpr int TILE = 256 * TT;  // samples per workgroup
+// samples per lane TT (stride 256) is a template parameter: 4 when the launch fills the chip anyway, 2 or 1 for short
+// inputs (B = 1), where 1024-sample tiles leave most CUs without a workgroup
 constexpr int CI_CHUNK = 8;
 
 struct ConvArgs {
   const float* x;      // [B][Cin][L]
-  const float* w;      // [Cout][Cin][K]
+  const float* w;      // packed [ceil(Cout/CO_BLK)][Cin][K][CO_BLK] (zero padded): the CO_BLK weights of one (ci, k) are one wide scalar load
   const float* bias;   // [Cout]
   float* y;            // [B][Cout][L]
   const float* res;    // optional [B][Cout][L]: y = conv + res
@@ -40,8 +40,9 @@ struct ConvArgs {
   int Cin, Cout, L, dil, pad;
 };
 
-template <int K, int CO_BLK>
+template <int K, int CO_BLK, int TT>
 __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
+  constexpr int TILE = 256 * TT;  // samples per workgroup
   extern __shared__ float xs[];   // [CI_CHUNK][TILE + (K-1)*dil]
   const int tid = threadIdx.x;
   const int t0 = blockIdx.x * TILE;
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
     const int nci = (a.Cin - ci0) < CI_CHUNK ? (a.Cin - ci0) : CI_CHUNK;
 #pragma unroll 1
     for (int ci = 0; ci < nci; ++ci) {
-      const float* __restrict__ wp = a.w + ((long long)co0 * a.Cin + (ci0 + ci)) * K;   // wave-uniform -> scalar loads
+      // wave-uniform -> scalar loads, CO_BLK consecutive floats per tap
+      const float* __restrict__ wp = a.w + ((long long)blockIdx.y * a.Cin + (ci0 + ci)) * (K * CO_BLK);
       const float* __restrict__ xr = xs + ci * span + tid;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
         for (int j = 0; j < TT; ++j) xv[j] = xr[k * a.dil + 256 * j];
 #pragma unroll
         for (int c = 0; c < CO_BLK; ++c) {
-          const float wv = (co0 + c < a.Cout) ? wp[(long long)c * a.Cin * K + k] : 0.f;
+          const float wv = wp[k * CO_BLK + c];
 #pragma unroll
           for (int j = 0; j < TT; ++j) acc[c][j] = fmaf(wv, xv[j], acc[c][j]);
         }
@@ -165,18 +167,38 @@ __global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float
   for (int i = lane; i < inner; i += 64) w[(long long)row * inner + i] = v[(long long)row * inner + i] * scale;
 }
 
-template <int K>
-int launch_conv_k(const ConvArgs& a, int B, hipStream_t st) {
+// [Cout][Cin][K] -> [ceil(Cout/CO)][Cin][K][CO], zero padded
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int K, int CO) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nblk = (Cout + CO - 1) / CO;
+  if (i >= nblk * Cin * K * CO) return;
+  const int c = i % CO, k = (i / CO) % K, ci = (i / (CO * K)) % Cin, blk = i / (CO * K * Cin);
+  const int co = blk * CO + c;
+  out[i] = co < Cout ? w[((long long)co * Cin + ci) * K + k] : 0.f;
+}
+
+template <int K, int TT>
+int launch_conv_kt(const ConvArgs& a, int B, hipStream_t st) {
+  constexpr int TILE = 256 * TT;
   const size_t lds = (size_t)CI_CHUNK * (TILE + (K - 1) * a.dil) * sizeof(float);
   if (a.Cout >= 16) {
     dim3 grid(cdiv(a.L, TILE), cdiv(a.Cout, 16), B);
-    hipLaunchKernelGGL((conv1d_kernel<K, 16>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv1d_kernel<K, 16, TT>), grid, dim3(256), lds, st, a);
   } else {
     dim3 grid(cdiv(a.L, TILE), cdiv(a.Cout, 8), B);
-    hipLaunchKernelGGL((conv1d_kernel<K, 8>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv1d_kernel<K, 8, TT>), grid, dim3(256), lds, st, a);
   }
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+
+template <int K>
+int launch_conv_k(const ConvArgs& a, int B, hipStream_t st) {
+  // workgroups at 1024 samples per workgroup; below ~2 per CU (256 CUs) use shorter tiles
+  const long long wgs4 = (long long)cdiv(a.L, 1024) * cdiv(a.Cout, a.Cout >= 16 ? 16 : 8) * B;
+  if (wgs4 >= 512) return launch_conv_kt<K, 4>(a, B, st);
+  if (wgs4 >= 256) return launch_conv_kt<K, 2>(a, B, st);
+  return launch_conv_kt<K, 1>(a, B, st);
 }
 
 int launch_conv(const ConvArgs& a, int K, int B, hipStream_t st) {
@@ -207,6 +229,7 @@ using namespace bsg;
 
 struct ConvW {
   float* w = nullptr;
+  float* wpk = nullptr;   // Conv1d only: repacked for conv1d_kernel (CO_BLK = 16 if cout >= 16 else 8)
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
 };
@@ -257,6 +280,15 @@ static int take_conv(bsg_hifigan* h, ConvW& c, const void* const*& w, int dim0, 
   }
   TRY(hg_alloc(h, &c.b, c.cout));
   BSG_HIP(hipMemcpyAsync(c.b, bias, c.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return BSG_OK;
+}
+
+static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st) {
+  const int CO = c.cout >= 16 ? 16 : 8;
+  const int n = cdiv(c.cout, CO) * c.cin * c.k * CO;
+  TRY(hg_alloc(h, &c.wpk, n));
+  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, c.wpk, c.cout, c.cin, c.k, CO);
+  BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
 
@@ -322,6 +354,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   }
   h->pre.cout = C0; h->pre.cin = cfg->n_mel; h->pre.k = 7;
   if ((rc = take_conv(h, h->pre, w, C0, cfg->n_mel * 7, st)) != BSG_OK) return fail(rc);
+  if ((rc = pack_conv(h, h->pre, st)) != BSG_OK) return fail(rc);
   h->ups.resize(cfg->n_ups);
   for (int i = 0; i < cfg->n_ups; ++i) {
     ConvW& c = h->ups[i];
@@ -339,10 +372,12 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
         ConvW& c = (pass == 0 ? h->rb1 : h->rb2)[(size_t)r * cfg->n_dil + m];
         c.cin = c.cout = ch; c.k = k;
         if ((rc = take_conv(h, c, w, ch, ch * k, st)) != BSG_OK) return fail(rc);
+        if ((rc = pack_conv(h, c, st)) != BSG_OK) return fail(rc);
       }
   }
   h->post.cout = 1; h->post.cin = C0 >> cfg->n_ups; h->post.k = 7;
   if ((rc = take_conv(h, h->post, w, 1, h->post.cin * 7, st)) != BSG_OK) return fail(rc);
+  if ((rc = pack_conv(h, h->post, st)) != BSG_OK) return fail(rc);
   if (hipStreamSynchronize(st) != hipSuccess) { set_error("hifigan_create: stream sync failed"); return fail(BSG_EHIP); }
   *out = h;
   return BSG_OK;
@@ -351,7 +386,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
 static int run_conv(const ConvW& c, const float* x, float* y, int B, int L, int dil, float in_slope, const float* res,
                     const float* acc_in, float out_div, int out_tanh, hipStream_t st) {
   ConvArgs a{};
-  a.x = x; a.w = c.w; a.bias = c.b; a.y = y; a.res = res; a.acc_in = acc_in; a.out_div = out_div; a.in_slope = in_slope;
+  a.x = x; a.w = c.wpk; a.bias = c.b; a.y = y; a.res = res; a.acc_in = acc_in; a.out_div = out_div; a.in_slope = in_slope;
   a.out_tanh = out_tanh; a.Cin = c.cin; a.Cout = c.cout; a.L = L; a.dil = dil; a.pad = (c.k * dil - dil) / 2;
   return launch_conv(a, c.k, B, st);
 }
