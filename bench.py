@@ -13,7 +13,10 @@ fp32).  Weak scaling: every rank generates 16 utterances of the 16*N batch.
 
 The JSON line also carries
   roofline     : the dominant kernel (fused residual layer), timed live with HIP events on the launch
-                 stream during the timed steps, against the fp32 MFMA peak;
+                 stream during the timed steps, against the fp32 MFMA peak (algorithmic FLOPs of the reference's
+                 direct convolution; the kernel's Winograd form executes 3/4 of them); `traffic` = the kernel's
+                 measured HBM-side bytes per launch (profiles/traffic*.json, PMC);
+  --dtype bf16 --batch 64 : BASELINE configs[2] (bf16 MFMA operands / fp32 accumulate), priced against the HBM roof;
   cpu_baseline : the oracle (PyTorch-CPU restatement of the reference, oracle/) timed on this host on a
                  bounded sample of the same workload (rank 0, N = 1 only), extrapolated to 100 steps;
                  the same sample is also replayed on the GPU with the same supplied noise -> `parity`.
@@ -33,7 +36,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_FRAME_LAYER = 2 * (512 * 768 + 512 * 256)   # dilated conv + output projection
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0                                 # MI355X_MICROARCH.md, HBM3E spec (achievable ~6.3 TB/s)
-HBM_BYTES_PER_FRAME_LAYER = 6 * 256 * 4               # x in, x out, conditioner term 2C, skip read+write
+HBM_BYTES_PER_FRAME_LAYER_BF16 = 4 * 256 * 4          # bf16 config: x in + x out fp32 (2 KB), conditioner term bf16 (1 KB), skip sum bf16 r+w (1 KB)
 B_PER_GPU, T_FRAMES, T_TXT, N_MEL, N_DIFF_STEPS = 16, 1000, 100, 80, 100
 
 
@@ -210,13 +213,13 @@ def main():
             if traffic is not None:
                 traffic *= layers_per_launch
         if bf16:
-            # 16x the fp32 MFMA rate moves the layer under the HBM roof: AI = 1,048,576 FLOP / 6 KB = 171 FLOP/B against a
-            # ridge of 2,500 TFLOP/s / 8 TB/s = 312 FLOP/B
-            ach_gbs = HBM_BYTES_PER_FRAME_LAYER * frames_per_launch / (avg_ms * 1e-3) / 1e9 if n_layer else None
+            # 16x the fp32 MFMA rate moves the layer under the HBM roof: AI = 1,048,576 FLOP / 4 KB = 256 FLOP/B against a
+            # ridge of 2,500 TFLOP/s / 8 TB/s = 312 FLOP/B (and the measured fabric traffic is 1.4x the algorithmic bytes)
+            ach_gbs = HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch / (avg_ms * 1e-3) / 1e9 if n_layer else None
             roof = {'kernel': 'residual_layer_bf16_kernel (fused DiffNet residual block, bf16 MFMA operands)', 'bound': 'hbm',
                     'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS if ach_gbs else None,
                     'traffic': traffic, 'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
-                    'bytes_per_launch': HBM_BYTES_PER_FRAME_LAYER * frames_per_launch,
+                    'bytes_per_launch': HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch,
                     'mfma_tflops': achieved, 'mfma_frac_of_bf16_peak': achieved / 2516.0 if achieved else None}
         else:
             roof = {'kernel': ('persistent_layers_kernel (20 fused DiffNet residual blocks per launch)' if layers_per_launch > 1
