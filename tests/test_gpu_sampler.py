@@ -159,3 +159,27 @@ print(json.dumps({'hashes': hs, 'timeouts': m.denoise_fn.handoff_timeouts(), 'fi
     assert res['1']['timeouts'] == 0 and res['1']['finite']
     assert len(set(res['0']['hashes'])) == 1 and len(set(res['1']['hashes'])) == 1
     assert res['0']['hashes'][0] == res['1']['hashes'][0]
+
+
+def test_sampler_loop_is_graph_capturable(model):
+    """The whole K-step loop is enqueued by one ABI call without host synchronisation (coefficients and Philox keys are
+    kernel arguments), so a caller can capture it into a hipGraph and replay it: same bits as the eager call."""
+    B, T, n = 2, 96, 12
+    rs = np.random.RandomState(17)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    x0 = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
+    eager = model.sample(cond, x0.clone(), seed=11, n_steps=n).clone()      # also warms up (workspaces, function attributes)
+    torch.cuda.synchronize()
+    xg = x0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            model.sample(cond, xg, seed=11, n_steps=n)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(2):
+        xg.copy_(x0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(xg, eager)
