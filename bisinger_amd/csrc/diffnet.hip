@@ -398,6 +398,282 @@ __global__ __launch_bounds__(512, WINO ? 4 : 6) void residual_layer_kernel(ResAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small launches (B * ceil(T/32) <= the number of CUs): one tile per workgroup leaves most of the chip idle and the layer
+// is bound by ONE CU's matrix rate (393 k MFMA cycles per tile over 4 SIMDs = 42 us).  Here a tile is computed by a PAIR
+// of workgroups (2*tile, 2*tile + 1), each owning half of the channels:
+//   part p: gate rows [128p, 128p+128) + filter rows [256+128p, ...)  ->  z channels [128p, 128p+128)   (Winograd GEMM1)
+//   exchange: each part stores its z half to a global scratch tile write-through (sc1), every wave drains (vmcnt(0)),
+//             barrier, one relaxed agent-scope flag store (value = launch epoch); one lane polls the partner's flag (bounded),
+//             ONE agent-scope acquire, barrier, plain loads of the partner half   (same protocol as the persistent launch)
+//   part p: residual rows [128p, ...) + skip rows [256+128p, ...) of GEMM2 over all 256 z channels
+// Wave w owns ONE 16-row tile (gate/filter, then residual/skip): 16x16x4 MFMAs throughout.  The host only takes this
+// path when every workgroup of the launch is resident (2 * tiles <= 2 per CU), so the partner is always running.
+// ------------------------------------------------------------------------------------------------
+struct SplitArgs {
+  ResArgs base;
+  const float* apack2w;   // output projection packed for 16x16x4 MFMAs [32 row tiles][16 k-groups][64][4]
+  float* zbuf;            // [tiles][C][32] scratch for the z exchange
+  unsigned* flags;        // [tiles][2]
+  unsigned* status;       // += 1 for a poll that gave up
+  unsigned epoch;         // launch counter (never 0): the value a flag takes in this launch
+};
+
+// out[((mt*(K/16) + q)*64 + lane)*4 + jj] = W(m = 16*mt + (lane&15), k = 16*q + 4*jj + (lane>>4)),  W row-major [M][K]
+__global__ void pack_a16_kernel(const float* __restrict__ w, float* __restrict__ out, int M, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * K) return;
+  const int jj = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+  const int KQ = K / 16;
+  const int q = rest % KQ, mt = rest / KQ;
+  out[i] = w[(long long)(16 * mt + (lane & 15)) * K + 16 * q + 4 * jj + (lane >> 4)];
+}
+
+__global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
+  const ResArgs& a = s.base;
+  constexpr int NT = 32, LDX = NT + 2 * HALO, LDZ = 48, NR = 4;   // NR: depth of the A-fragment rings (k-groups)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;
+  float* zs = lds;   // [C][LDZ], aliases xs after the barrier that ends GEMM1
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, lq = lane >> 4;
+  const int tile_id = (int)blockIdx.x >> 1, part = (int)blockIdx.x & 1;
+  const int b = tile_id / a.tiles_per_row;
+  const int t0 = (tile_id - b * a.tiles_per_row) * NT;
+  const int T = a.T;
+  const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(a.x_in + (long long)b * C * T, plane);
+  const rsrc_t rs_xo = mk_rsrc(a.x_out + (long long)b * C * T, plane);
+  const rsrc_t rs_sk = mk_rsrc(a.skip + (long long)b * C * T, plane);
+  const rsrc_t rs_ct = mk_rsrc(a.condterm + (long long)b * 2 * C * T, 2 * plane);
+  const rsrc_t rs_aw = mk_rsrc(a.apackw, 4 * 2 * C * C * 4);
+  const rsrc_t rs_a2 = mk_rsrc(s.apack2w, 2 * C * C * 4);
+  const rsrc_t rs_bo = mk_rsrc(a.bias_out, 2 * C * 4);
+  const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * a.L + a.layer) * C, C * 4);
+  const rsrc_t rs_zb = mk_rsrc(s.zbuf + (long long)tile_id * C * NT, C * NT * 4);
+  const int rowT = T * 4, vfrag = lane * 16;
+  const int gt = 8 * part + wave;   // this wave's 16-row tile: gate 16gt.., filter C+16gt..; later residual 16gt.., skip C+16gt..
+
+  // ---- (1) first A fragments fly while the x tile is staged ---------------------------------------
+  const int sw[2] = {gt * 16 * 1024, (16 + gt) * 16 * 1024};
+  f32x4 AW[NR][2];
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) AW[k][i] = ldf4(rs_aw, vfrag, sw[i] + k * 1024);
+
+  // ---- (2) stage xs = x + d (zero padded), as residual_tile ---------------------------------------
+  if ((T & 3) == 0) {
+#pragma unroll 3
+    for (int k = 0; k < 6; ++k) {
+      const int idx = tid + 512 * k;
+      const int c = idx / 12, j4 = idx - c * 12;
+      const int t = t0 - HALO + 4 * j4;
+      const bool ok = t >= 0 && t < T;
+      f32x4 v = ldf4(rs_x, ok ? (c * T + t) * 4 : 0, 0);
+      const float d = ldf(rs_dp, c * 4, 0);
+      v += d;
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(xs + c * LDX + 4 * j4) = v;
+    }
+  } else {
+#pragma unroll 4
+    for (int idx = tid; idx < C * LDX; idx += 512) {
+      const int c = idx / LDX, j = idx - c * LDX;
+      const int t = t0 - HALO + j;
+      const bool ok = t >= 0 && t < T;
+      const float v = ldf(rs_x, ok ? (c * T + t) * 4 : 0, 0) + ldf(rs_dp, c * 4, 0);
+      xs[idx] = ok ? v : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- (3) GEMM1, Winograd F(2,3) over the dilated taps (see residual_tile), one gate + one filter tile of 16 rows ----
+  const int dil = a.dil;
+  const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
+  const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
+  f32x4 y0[2], y1[2], M[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) y0[i] = y1[i] = M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* xb0 = xs + lq * LDX + HALO + tp;
+    auto ldbw = [&](int g) {
+      const int comp = g >> 4, q = g & 15;
+      const int oa = comp == 0 ? -dil : comp == 2 ? dil : 0;
+      const int ob = comp == 0 ? dil : comp == 1 ? dil : comp == 2 ? 0 : 2 * dil;
+      const float* pa = xb0 + 16 * q * LDX + oa;
+      const float* pb = xb0 + 16 * q * LDX + ob;
+      f32x4 v;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float xa = pa[4 * jj * LDX], xb_ = pb[4 * jj * LDX];
+        v[jj] = comp == 1 ? xa + xb_ : xa - xb_;
+      }
+      return v;
+    };
+    f32x4 Bw[2];
+    Bw[0] = ldbw(0);
+#pragma unroll 1
+    for (int g = 0; g < 64; g += NR) {
+#pragma unroll
+      for (int s2 = 0; s2 < NR; ++s2) {
+        const int gn = g + s2 + 1 < 64 ? g + s2 + 1 : 63;
+        Bw[(s2 + 1) & 1] = ldbw(gn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[s2][i][jj], Bw[s2 & 1][jj], M[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int gr = g + s2 + NR < 64 ? g + s2 + NR : 63;
+        const int so = ((gr >> 4) * 512 + (gr & 15)) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) AW[s2][i] = ldf4(rs_aw, vfrag, sw[i] + so);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if ((g & 15) == 16 - NR) {   // a Winograd component is complete
+        const int comp = g >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (comp == 0) { y0[i] = M[i]; }
+          else if (comp == 1) { y0[i] += M[i]; y1[i] = M[i]; }
+          else if (comp == 2) { y0[i] += M[i]; y1[i] -= M[i]; }
+          else { y1[i] -= M[i]; }
+          M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+  // ---- (4) + conditioner term, gate --------------------------------------------------------------------
+  float z0[4], z1[4];
+  {
+    const int f0c = t0 + tp < T ? t0 + tp : T - 1, f1c = t0 + tp + dil < T ? t0 + tp + dil : T - 1;
+    const int vc0 = (lq * 4 * T + f0c) * 4, vc1 = (lq * 4 * T + f1c) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int so_g = (16 * gt + r) * rowT, so_f = so_g + C * rowT;
+      const float cg0 = ldf(rs_ct, vc0, so_g), cf0 = ldf(rs_ct, vc0, so_f);
+      const float cg1 = ldf(rs_ct, vc1, so_g), cf1 = ldf(rs_ct, vc1, so_f);
+      z0[r] = fast_sigmoid(y0[0][r] + cg0) * fast_tanh(y0[1][r] + cf0);
+      z1[r] = fast_sigmoid(y1[0][r] + cg1) * fast_tanh(y1[1][r] + cf1);
+    }
+  }
+  // loads GEMM2 needs first: its A fragments, the residual input (initial accumulator) and the biases
+  const int sr = gt * 16 * 1024, ss = (16 + gt) * 16 * 1024;
+  f32x4 AR[NR], AS[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    AR[k] = ldf4(rs_a2, vfrag, sr + k * 1024);
+    AS[k] = ldf4(rs_a2, vfrag, ss + k * 1024);
+  }
+  int vcol[2];
+  bool col_ok[2];
+  f32x4 accR[2], accS[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = t0 + 16 * ct + p16;
+    col_ok[ct] = col < T;
+    vcol[ct] = (lq * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      accR[ct][r] = ldf(rs_x, vcol[ct], (16 * gt + r) * rowT) + ldf(rs_bo, lq * 16, (16 * gt + r) * 4);
+      accS[ct][r] = ldf(rs_bo, lq * 16, (C + 16 * gt + r) * 4);
+    }
+  }
+  __syncthreads();   // every wave is done reading xs
+  // ---- (5) z: own half -> LDS and (write-through) -> the exchange tile; partner half <- exchange tile ------
+  {
+    const int vz = ((4 * lq) * NT + tp) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * gt + 4 * lq + r;
+      zs[row * LDZ + tp] = z0[r];
+      zs[row * LDZ + tp + dil] = z1[r];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z0[r]), rs_zb, vz, (16 * gt + r) * NT * 4, 16);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z1[r]), rs_zb, vz + dil * 4, (16 * gt + r) * NT * 4, 16);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(s.flags + 2 * tile_id + part, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(s.flags + 2 * tile_id + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22)) {   // ~ seconds: never reached unless the partner is not resident
+        atomicAdd(s.status, 1u);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  {
+    const int c0 = (C / 2) * (1 - part);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + 512 * k;
+      const int c = c0 + (idx >> 3), j4 = idx & 7;
+      *reinterpret_cast<f32x4*>(zs + c * LDZ + 4 * j4) = ldf4(rs_zb, (c * NT + 4 * j4) * 4, 0);
+    }
+  }
+  __syncthreads();
+  // ---- (6) GEMM2: residual tile + skip tile of 16 rows x 2 column tiles of 16 frames -------------------------
+  {
+    const float* zb = zs + lq * LDZ + p16;
+    auto ldbz = [&](int q, int ct) {
+      const float* p = zb + 16 * q * LDZ + 16 * ct;
+      return f32x4{p[0], p[4 * LDZ], p[8 * LDZ], p[12 * LDZ]};
+    };
+    f32x4 Bz[2][2];
+    Bz[0][0] = ldbz(0, 0);
+    Bz[0][1] = ldbz(0, 1);
+#pragma unroll 1
+    for (int q = 0; q < 16; q += NR) {
+#pragma unroll
+      for (int s2 = 0; s2 < NR; ++s2) {
+        const int qn = q + s2 + 1 < 16 ? q + s2 + 1 : 15;
+        Bz[(s2 + 1) & 1][0] = ldbz(qn, 0);
+        Bz[(s2 + 1) & 1][1] = ldbz(qn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          accR[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AR[s2][jj], Bz[s2 & 1][0][jj], accR[0], 0, 0, 0);
+          accS[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AS[s2][jj], Bz[s2 & 1][0][jj], accS[0], 0, 0, 0);
+          accR[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AR[s2][jj], Bz[s2 & 1][1][jj], accR[1], 0, 0, 0);
+          accS[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AS[s2][jj], Bz[s2 & 1][1][jj], accS[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int qr = q + s2 + NR < 16 ? q + s2 + NR : 15;
+        AR[s2] = ldf4(rs_a2, vfrag, sr + qr * 1024);
+        AS[s2] = ldf4(rs_a2, vfrag, ss + qr * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // ---- (7) epilogue --------------------------------------------------------------------------------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float prevs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prevs[r] = a.first ? 0.f : ldf(rs_sk, vcol[ct], (16 * gt + r) * rowT);
+    if (col_ok[ct]) {
+      const int vst = (lq * 4 * T + t0 + 16 * ct + p16) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = (16 * gt + r) * rowT;
+        stf(accR[ct][r] / 1.41421356237309504880f, rs_xo, vst, so);   // (x + residual) / sqrt(2), net.py:78
+        stf((prevs[r] + accS[ct][r]) / a.skip_div, rs_sk, vst, so);   // running skip sum (/ sqrt(L) last, :126)
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // All L residual layers of one DiffNet evaluation in ONE launch.  Workgroup w owns tiles w, w+G, ... and walks the
 // layers in order; layer l of tile j needs layer l-1 of tiles j-1, j, j+1 (the dilation halo is <= 8 frames < 32),
 // so the only inter-workgroup traffic is the x tile of the two neighbours:
@@ -878,6 +1154,12 @@ struct bsg_diffnet {
   size_t flags_cap = 0;
   int num_cus = 0;
   unsigned long long* clk = nullptr;   // [1024][4] diagnostic clock stamps of the last persistent launch
+  // channel-split launch for small batches (residual_split_kernel)
+  float* apack2w = nullptr;            // [L][2C*C] output projection packed for 16x16x4 MFMAs
+  float* zbuf = nullptr;               // [tiles][C][32] z exchange scratch
+  unsigned* split_flags = nullptr;     // [tiles][2] + status word
+  size_t split_cap = 0;                // tiles the scratch is sized for
+  unsigned split_epoch = 0;
 };
 
 static int dev_alloc(float** p, size_t n) {
@@ -892,12 +1174,13 @@ static void dev_free(float*& p) {
 extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (!h) return;
   float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->apackw, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
-                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
+                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->apack2w, &h->zbuf, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->flags) (void)hipFree(h->flags);
   if (h->clk) (void)hipFree(h->clk);
+  if (h->split_flags) (void)hipFree(h->split_flags);
   if (h->apack1h) (void)hipFree(h->apack1h);
   if (h->condterm_h) (void)hipFree(h->condterm_h);
   if (h->skip_h) (void)hipFree(h->skip_h);
@@ -941,6 +1224,7 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&h->apack1, (size_t)L * 2 * C * 3 * C));
   TRY(dev_alloc(&h->apack2, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->apackw, (size_t)L * 4 * 2 * C * C));
+  TRY(dev_alloc(&h->apack2w, (size_t)L * 2 * C * C));
   BSG_HIP(hipMalloc((void**)&h->apack1h, (size_t)L * 2 * C * 3 * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->apack2h, (size_t)L * 2 * C * C * sizeof(unsigned short)));
   TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
@@ -977,6 +1261,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
     rc = pack_a_frag_bf16((const float*)lw[0], h->apack1h + (size_t)l * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, st);
     if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[6], h->apack2h + (size_t)l * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, st);
     if (rc != BSG_OK) break;
+    hipLaunchKernelGGL(pack_a16_kernel, dim3(cdiv(2 * C * C, 256)), dim3(256), 0, st, (const float*)lw[6], h->apack2w + (size_t)l * 2 * C * C,
+                       2 * C, C);
     hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, (const float*)lw[5], (const float*)lw[1],
                        h->b_cond + (size_t)l * 2 * C, 2 * C);
     if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: pack kernels failed"); rc = BSG_EHIP; break; }
@@ -1081,6 +1367,18 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       h->flags_cap = need;
     }
     if (!h->clk) BSG_HIP(hipMalloc((void**)&h->clk, 1024 * 4 * sizeof(unsigned long long)));
+    const size_t tiles = (size_t)B * cdiv(T, 32);
+    if (tiles > h->split_cap) {
+      BSG_HIP(hipStreamSynchronize(st));
+      dev_free(h->zbuf);
+      if (h->split_flags) (void)hipFree(h->split_flags);
+      h->split_flags = nullptr;
+      h->split_cap = 0;
+      TRY(dev_alloc(&h->zbuf, tiles * C * 32));
+      BSG_HIP(hipMalloc((void**)&h->split_flags, (2 * tiles + 4) * sizeof(unsigned)));
+      BSG_HIP(hipMemsetAsync(h->split_flags, 0, (2 * tiles + 4) * sizeof(unsigned), st));
+      h->split_cap = tiles;
+    }
     if (!h->num_cus) {
       int dev = 0;
       BSG_HIP(hipGetDevice(&dev));
@@ -1114,6 +1412,24 @@ static bool use_wino() {
   return v != 0;
 }
 
+// A pair of workgroups per tile pays (a z exchange through L2) only when single workgroups would leave CUs idle: measured on
+// MI355X at T=1000, B = 1 / 2 / 4 (32 / 64 / 128 tiles): 63 -> 41, 64 -> 42, 65 -> 47 us per layer; B = 6 (192 tiles): 68 -> 70.
+// So: at most one workgroup per CU after the split, which also keeps every workgroup of the launch resident (the partner
+// of a polling workgroup is always running).  BSG_SPLIT=0 disables it.
+static bool use_split(bsg_diffnet* h, int B, int T) {
+  static int env = -1, occ = -1;
+  if (env < 0) { const char* e = getenv("BSG_SPLIT"); env = e ? atoi(e) : 1; }
+  if (!env || !h->num_cus || !h->zbuf) return false;
+  const long long tiles = (long long)B * cdiv(T, 32);
+  if (2 * tiles > h->num_cus || (size_t)tiles > h->split_cap) return false;
+  if (occ < 0) {
+    if (hipFuncSetAttribute((const void*)residual_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C * 48 * (int)sizeof(float)) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)residual_split_kernel, 512, (size_t)C * 48 * sizeof(float)) != hipSuccess)
+      occ = 0;
+  }
+  return occ >= 2;
+}
+
 static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long long* t_dev, int t_uniform, float* x_out,
                         float* skip, int B, int T, hipStream_t st, unsigned long long* stamps = nullptr) {
   ResArgs a{};
@@ -1131,6 +1447,21 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   a.first = layer == 0;
   a.skip_div = layer == h->L - 1 ? sqrtf((float)h->L) : 1.0f;
   a.stamps = stamps;
+  if (h->compute == BSG_COMPUTE_F32 && !stamps && use_wino() && use_split(h, B, T)) {
+    // small launch: a pair of workgroups per tile, each half of the channels (residual_split_kernel)
+    SplitArgs s{};
+    a.tiles_per_row = cdiv(T, 32);
+    s.base = a;
+    s.apack2w = h->apack2w + (size_t)layer * 2 * C * C;
+    s.zbuf = h->zbuf;
+    s.flags = h->split_flags;
+    s.status = h->split_flags + 2 * h->split_cap;
+    if (++h->split_epoch == 0) h->split_epoch = 1;
+    s.epoch = h->split_epoch;
+    hipLaunchKernelGGL(residual_split_kernel, dim3(2 * B * a.tiles_per_row), dim3(512), (size_t)C * 48 * sizeof(float), st, s);
+    BSG_LAUNCH_CHECK();
+    return BSG_OK;
+  }
   if (h->compute == BSG_COMPUTE_BF16) {
     // the running skip sum lives in h->skip_h (bf16); a caller-supplied fp32 buffer (the unit-test hook) is converted
     // in and out around the launch
@@ -1371,6 +1702,11 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
     unsigned v = 0;
     BSG_HIP(hipMemcpy(&v, h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
     *handoff_timeouts = (int32_t)v;
+  }
+  if (h->split_flags) {
+    unsigned v = 0;
+    BSG_HIP(hipMemcpy(&v, h->split_flags + 2 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *handoff_timeouts += (int32_t)v;
   }
   return BSG_OK;
 }

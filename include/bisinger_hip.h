@@ -144,8 +144,9 @@ int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_
 #define BSG_COMPUTE_F32 0
 #define BSG_COMPUTE_BF16 1
 int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode);
-/* Synchronous health check of the persistent multi-layer launch (BSG_PERSIST=1): number of inter-workgroup
- * hand-off spins that gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
+/* Synchronous health check of the launches that hand data between workgroups (the persistent multi-layer launch,
+ * BSG_PERSIST=1, and the channel-split launch used for small batches): number of inter-workgroup hand-off spins that
+ * gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
 int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
 /* Diagnostic: {s_memtime, s_memrealtime} at the start and end of each workgroup of the LAST persistent launch,
  * out [n_wg][4] uint64 (host).  Shader clock held = d(memtime)/d(memrealtime) x 100 MHz.  Synchronous. */

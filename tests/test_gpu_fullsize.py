@@ -136,3 +136,15 @@ def test_bf16_config_full_size():
     dev = maxabs(a, ref)
     print(f'B=64 T=1000 eps, bf16 vs fp32: max abs {dev:.3e}')
     assert dev <= 2e-2
+
+
+def test_split_launch_equals_regular_launch(model, data):
+    """Small launches (<= 128 tiles) run a tile as a PAIR of workgroups with a z hand-off (residual_split_kernel); the
+    arithmetic per output element is the same k-ordered chain, so row 3 alone (B=1: split) must equal row 3 inside the
+    B=16 batch (512 tiles: one workgroup per tile) bit for bit, and no hand-off may have timed out."""
+    x, cond, t = data
+    net = model.denoise_fn
+    full = net(x, t, cond).clone()
+    one = net(x[3:4].contiguous(), t[3:4].contiguous(), cond[3:4].contiguous()).clone()
+    assert torch.equal(one[0], full[3])
+    assert net.handoff_timeouts() == 0

@@ -21,7 +21,10 @@ DTYPE = sys.argv[1] if len(sys.argv) > 1 else 'fp32'   # fp32 | bf16
 net.set_compute(DTYPE)
 FLOP_LAYER = 1048576.0
 FLOP_NET = 21184512.0
-for B, T in [(16, 1000), (64, 1000), (8, 1000), (1, 500)]:
+SHAPES = [(16, 1000), (64, 1000), (8, 1000), (1, 500)]
+if len(sys.argv) > 2:   # e.g. 1x1000,2x1000,4x1000
+    SHAPES = [tuple(int(v) for v in p.split('x')) for p in sys.argv[2].split(',')]
+for B, T in SHAPES:
     cond = torch.randn(B, 256, T, device='cuda')
     x = torch.randn(B, 256, T, device='cuda')
     skip = torch.zeros(B, 256, T, device='cuda')
