@@ -608,6 +608,9 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
         break;
       }
     }
+    // consumed: clear the partner's flag, so that a replay of this very launch (a captured graph holding a single layer
+    // launch replays the same epoch) cannot match a stale value; the partner sets it again only in a later launch
+    __hip_atomic_store(s.flags + 2 * tile_id + (1 - part), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1650,7 +1653,11 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     float* nxt = h->xb;
     const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
     if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32;
+    // the persistent launch zeroes its hand-off flags with a memset before every launch; inside a stream capture that pair did
+    // not replay correctly (measured), so a capturing stream gets the per-layer launches
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32 && cap == hipStreamCaptureStatusNone;
     if (persist) {
       TRY(launch_layers_persistent(h, nullptr, i, B, T, st));
     } else {

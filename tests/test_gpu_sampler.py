@@ -183,3 +183,37 @@ def test_sampler_loop_is_graph_capturable(model):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(xg, eager)
+
+
+def test_single_layer_graph_replays(model):
+    """A graph holding ONE small-batch layer launch (the channel-split kernel: a pair of workgroups per tile with a flag
+    hand-off whose value is the launch epoch) replays the same epoch every time; the consumed flag is cleared in-kernel,
+    so every replay must wait for its partner again and reproduce the eager result on fresh inputs."""
+    net = model.denoise_fn
+    B, T = 2, 128
+    rs = np.random.RandomState(23)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    t = torch.tensor([5, 60], device='cuda')
+    net.prepare(cond)
+    xs = [T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda() for _ in range(3)]
+    skip = torch.zeros(B, 256, T, device='cuda')
+    want = []
+    for x in xs:
+        skip.zero_()
+        want.append((net.residual_layer(7, x, t, skip).clone(), skip.clone()))
+    torch.cuda.synchronize()
+    xg, sg = xs[0].clone(), torch.zeros_like(skip)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            og = net.residual_layer(7, xg, t, sg)
+    torch.cuda.current_stream().wait_stream(side)
+    for x, (wo, ws) in zip(xs, want):
+        xg.copy_(x)
+        sg.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(og, wo) and torch.equal(sg, ws)
+    assert net.handoff_timeouts() == 0
