@@ -5,9 +5,9 @@
 
 Per configuration (f32 = BASELINE configs[1], bf16 = configs[2]): the kernel-stats CSV as rocprofv3 wrote it, and a
 PMC summary (per-kernel means over all launches) with the HBM-side traffic of the dominant kernel per launch:
-  fabric bytes = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B  +  64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)   (L2 <-> fabric requests)
-  FETCH_SIZE / WRITE_SIZE (KB) are reported raw; on gfx950 FETCH_SIZE counts 16-B/lane coalesced reads at 1/2
-  (MI355X_MICROARCH.md "HBM"), so the request counters are the figure used for `traffic`.
+  traffic = 2 * FETCH_SIZE + WRITE_SIZE  (KB -> bytes): MI355X_MICROARCH.md "HBM" - on gfx950 FETCH_SIZE tallies the L2's 128-B
+  fabric read requests at 64 B, so it is doubled; WRITE_SIZE is exact.  Cross-check kept beside it from the request counters:
+  128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B  +  64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)  (agrees within 0.5 % here).
 """
 import collections
 import csv
@@ -52,9 +52,15 @@ for cfg in ('f32', 'bf16'):
         wr = 64 * g('TCC_EA0_WRREQ_64B_sum') + 32 * (g('TCC_EA0_WRREQ_sum') - g('TCC_EA0_WRREQ_64B_sum'))
         frames = 64000 if cfg == 'bf16' else 16000
         t = {'kernel': dom, 'frames_per_launch': frames, 'fabric_read_bytes': rd, 'fabric_write_bytes': wr,
-             'residual_layer_kernel_hbm_bytes_per_launch': rd + wr, 'algorithmic_bytes_per_launch': 6 * 256 * 4 * frames,
+             'algorithmic_bytes_per_launch': 6 * 256 * 4 * frames,
              'FETCH_SIZE_KB_raw': g('FETCH_SIZE'), 'WRITE_SIZE_KB': g('WRITE_SIZE'),
              'l2_hit_requests': g('TCC_HIT_sum'), 'l2_miss_requests': g('TCC_MISS_sum')}
+        if g('FETCH_SIZE') is not None and g('WRITE_SIZE') is not None:
+            t['fetch_bytes_corrected'] = 2 * 1024 * g('FETCH_SIZE')
+            t['write_bytes'] = 1024 * g('WRITE_SIZE')
+            t['residual_layer_kernel_hbm_bytes_per_launch'] = t['fetch_bytes_corrected'] + t['write_bytes']
+        else:
+            t['residual_layer_kernel_hbm_bytes_per_launch'] = rd + wr
         if g('SQ_VALU_MFMA_BUSY_CYCLES') and g('GRBM_GUI_ACTIVE'):
             t['mfma_busy_cycles_per_simd'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024
             t['kernel_cycles_grbm_gui_active_div8'] = g('GRBM_GUI_ACTIVE') / 8
