@@ -212,3 +212,25 @@ def test_f4_fft_candidate_denoiser(gold, sd_spec):
         t = rs.randint(0, 100, size=(B,)).astype(np.int64)
         y = ocd.fft_denoiser_forward(sd, T(x), T(t), T(cond))
         assert np.abs(y.numpy() - g[f'{tag}.eps']).max() <= 1e-5
+
+
+def test_oracle_bf16_operand_emulation_is_a_small_perturbation():
+    """oracle.diffnet.residual_block(operand_bf16=True) is the checker of the build's bf16-operand configuration
+    (tests/test_gpu_bf16.py): deterministic, and within the bf16 rounding budget of the fp32 restatement."""
+    import torch
+    from oracle import diffnet as odn
+    g = torch.Generator().manual_seed(3)
+    C = 256
+    sd = {'dilated_conv.weight': torch.randn(2 * C, C, 3, generator=g) * 0.03, 'dilated_conv.bias': torch.randn(2 * C, generator=g) * 0.1,
+          'diffusion_projection.weight': torch.randn(C, C, generator=g) * 0.05, 'diffusion_projection.bias': torch.zeros(C),
+          'conditioner_projection.weight': torch.randn(2 * C, C, 1, generator=g) * 0.05, 'conditioner_projection.bias': torch.zeros(2 * C),
+          'output_projection.weight': torch.randn(2 * C, C, 1, generator=g) * 0.05, 'output_projection.bias': torch.zeros(2 * C)}
+    x, cond, d = torch.randn(2, C, 50, generator=g), torch.randn(2, C, 50, generator=g), torch.randn(2, C, generator=g)
+    with torch.no_grad():
+        a = odn.residual_block(sd, '', x, cond, d, 4, operand_bf16=True)
+        b = odn.residual_block(sd, '', x, cond, d, 4, operand_bf16=True)
+        f = odn.residual_block(sd, '', x, cond, d, 4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for u, v in zip(a, f):
+        dev = float((u - v).abs().max())
+        assert 1e-5 < dev < 3e-2, dev
