@@ -246,6 +246,10 @@ def main():
             rec['cpu_baseline'] = base
             rec['parity'] = parity
             rec['gpu_over_cpu'] = value / base['value']
+        # native libraries (RCCL prints its load path) write through C stdio, which is block-buffered when stdout is a pipe:
+        # flush it first so that the JSON record is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(rec), flush=True)
     if world > 1 or args.force_dist:
         dist.barrier()
