@@ -196,6 +196,13 @@ def main():
         dt = float(t.item())
     assert mel.shape == (B_total, T_FRAMES, N_MEL) and bool(torch.isfinite(mel).all())
 
+    # every rank flushes what native libraries buffered on stdout (RCCL prints its load path) before rank 0 prints the record,
+    # so that the record is the last line of the job's merged stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if world > 1 or args.force_dist:
+        dist.barrier()
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = B_total * T_FRAMES * args.steps / dt
