@@ -831,6 +831,31 @@ __global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict_
 // Replaces three GEMM launches + the sampler launch per step (~150 us -> ~20 us at B=16, T=1000): the three
 // projections are too small (0.04-0.13 MFLOP/frame) to fill the chip as separate 128x128-tile GEMMs.
 // ------------------------------------------------------------------------------------------------
+struct PlmsCoef {
+  float a_t, a_prev;
+  float w0, w1, w2, w3, inv;  // eps' = (w0*e0 + w1*e1 + w2*e2 + w3*e3) / inv
+};
+
+// p_sample_plms update of one element, shared by plms_step_kernel and the fused tail (same rounding sequence in both)
+__device__ __forceinline__ float plms_update(float x, float e0, float e1, float e2, float e3, int n_hist, const PlmsCoef& k, float* ep_out) {
+  float ep = e0;
+  if (n_hist > 0) {   // multistep blends, evaluated left to right like the reference expressions
+    if (n_hist >= 3) ep = __fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0), __fmul_rn(-k.w1, e1)), __fmul_rn(k.w2, e2)), __fmul_rn(-k.w3, e3));
+    else if (n_hist == 2) ep = __fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0), __fmul_rn(-k.w1, e1)), __fmul_rn(k.w2, e2));
+    else if (k.w0 == 1.0f) ep = __fadd_rn(e0, e1);                       // (eps + eps_prev) / 2
+    else ep = __fsub_rn(__fmul_rn(k.w0, e0), e1);                        // (3*eps - h[-1]) / 2
+    ep = ep / k.inv;
+  }
+  const float a_t = k.a_t, a_prev = k.a_prev;
+  const float a_t_sq = sqrtf(a_t), a_prev_sq = sqrtf(a_prev);
+  const float cx = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(a_t_sq, a_prev_sq));
+  const float ce = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(sqrtf(__fmul_rn(__fsub_rn(1.0f, a_prev), a_t)),
+                                                       sqrtf(__fmul_rn(__fsub_rn(1.0f, a_t), a_prev))));
+  const float xd = __fmul_rn(__fsub_rn(a_prev, a_t), __fsub_rn(__fmul_rn(cx, x), __fmul_rn(ce, ep)));
+  if (ep_out) *ep_out = ep;
+  return __fadd_rn(x, xd);
+}
+
 struct TailArgs {
   const float* skip;    // [B][C][T]
   const unsigned short* skip_h;  // bf16 mode: [B][C/4][T][4] instead of `skip`
@@ -847,6 +872,13 @@ struct TailArgs {
   unsigned long long seed, quad_row0;   // Philox: key, and the flat element index of this shard's row 0
   unsigned stream;
   int B, T, M, tiles_per_row, do_head;
+  // PLMS form (plms_hist > 0): eps is stored to e_new and x <- p_sample_plms(x, eps, history)   (shallow_diffusion_tts.py:168-201)
+  int plms_hist;          // 0: DDPM ancestral update; 1..3: number of history entries blended
+  PlmsCoef pk;
+  float* e_new;           // [B][M][T]
+  const float* h1;        // newest history entry, then older
+  const float* h2;
+  const float* h3;
 };
 
 __device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigned stream, unsigned long long idx) {
@@ -972,20 +1004,40 @@ __global__ __launch_bounds__(512, 4) void step_tail_kernel(TailArgs a) {
       xv[r] = ldf(rs_x, vcol, m0 * rowT);
       nv[r] = a.noise ? ldf(rs_n, vcol, m0 * rowT) : 0.f;
     }
+    float h1v[16], h2v[16], h3v[16];
+    if (a.plms_hist) {
+      const unsigned hb = (unsigned)M * T * 4;
+      const rsrc_t rs_h1 = mk_rsrc(a.h1 + (long long)b * M * T, hb);
+      const rsrc_t rs_h2 = mk_rsrc(a.plms_hist > 1 ? a.h2 + (long long)b * M * T : a.x, a.plms_hist > 1 ? hb : 0u);
+      const rsrc_t rs_h3 = mk_rsrc(a.plms_hist > 2 ? a.h3 + (long long)b * M * T : a.x, a.plms_hist > 2 ? hb : 0u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int so = (32 * wave + acc_row0(r)) * rowT;
+        h1v[r] = ldf(rs_h1, vcol, so);
+        h2v[r] = ldf(rs_h2, vcol, so);   // zero-size descriptors read as 0
+        h3v[r] = ldf(rs_h3, vcol, so);
+      }
+    }
     tile_gemm<32>(acc, rs_wo, vfrag, wave * 32 * 1024, ss + lh * 32 + l31);
     const int vst = (lh * 4 * T + col) * 4;
+    const rsrc_t rs_en = mk_rsrc(a.plms_hist ? a.e_new + (long long)b * M * T : a.x, a.plms_hist ? (unsigned)M * T * 4 : 0u);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * wave + acc_row(r, lh);
       float o = 0.f;
       if (m < M) {
-        float nz = nv[r];
-        if (!a.noise && a.k.sigma != 0.f)
-          nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + colc);
-        float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, acc[r]));
-        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-        const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
-        o = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
+        if (a.plms_hist) {
+          o = plms_update(xv[r], acc[r], h1v[r], h2v[r], h3v[r], a.plms_hist, a.pk, nullptr);
+          if (col_ok) stf(acc[r], rs_en, vst, (32 * wave + acc_row0(r)) * rowT);
+        } else {
+          float nz = nv[r];
+          if (!a.noise && a.k.sigma != 0.f)
+            nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + colc);
+          float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, acc[r]));
+          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
+          o = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
+        }
         if (col_ok) stf(o, rs_x, vst, (32 * wave + acc_row0(r)) * rowT);
       }
       xin[m * 32 + l31] = o;
@@ -1071,30 +1123,13 @@ __global__ __launch_bounds__(256) void mel_start_kernel(const float* __restrict_
 }
 
 // PLMS transfer x_pred = x + x_delta  (shallow_diffusion_tts.py:174-182); eps' = blend of eps history (:191-198)
-struct PlmsCoef {
-  float a_t, a_prev;
-  float w0, w1, w2, w3, inv;  // eps' = (w0*e0 + w1*e1 + w2*e2 + w3*e3) / inv
-};
 __global__ void plms_step_kernel(const float* __restrict__ x, float* __restrict__ xo, const float* __restrict__ e0,
                                  const float* __restrict__ e1, const float* __restrict__ e2,
                                  const float* __restrict__ e3, PlmsCoef k, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float ep = e0[i];
-  if (e1) {   // multistep blends, evaluated left to right like the reference expressions
-    if (e3) ep = __fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0[i]), __fmul_rn(-k.w1, e1[i])), __fmul_rn(k.w2, e2[i])), __fmul_rn(-k.w3, e3[i]));
-    else if (e2) ep = __fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0[i]), __fmul_rn(-k.w1, e1[i])), __fmul_rn(k.w2, e2[i]));
-    else if (k.w0 == 1.0f) ep = __fadd_rn(e0[i], e1[i]);                       // (eps + eps_prev) / 2
-    else ep = __fsub_rn(__fmul_rn(k.w0, e0[i]), e1[i]);                        // (3*eps - h[-1]) / 2
-    ep = ep / k.inv;
-  }
-  const float a_t = k.a_t, a_prev = k.a_prev;
-  const float a_t_sq = sqrtf(a_t), a_prev_sq = sqrtf(a_prev);
-  const float cx = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(a_t_sq, a_prev_sq));
-  const float ce = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(sqrtf(__fmul_rn(__fsub_rn(1.0f, a_prev), a_t)),
-                                                       sqrtf(__fmul_rn(__fsub_rn(1.0f, a_t), a_prev))));
-  const float xd = __fmul_rn(__fsub_rn(a_prev, a_t), __fsub_rn(__fmul_rn(cx, x[i]), __fmul_rn(ce, ep)));
-  xo[i] = __fadd_rn(x[i], xd);
+  const int n_hist = e3 ? 3 : e2 ? 2 : e1 ? 1 : 0;
+  xo[i] = plms_update(x[i], e0[i], e1 ? e1[i] : 0.f, e2 ? e2[i] : 0.f, e3 ? e3[i] : 0.f, n_hist, k, nullptr);
 }
 
 }  // namespace
@@ -1609,6 +1644,58 @@ static int check_schedule(const bsg_schedule* s, const char* who, bool plms) {
   return BSG_OK;
 }
 
+// the 20 residual layers of one evaluation, input h->xa (the in-projection of x), output = the skip sum in h->skip(_h)
+static int layers_from_xa(bsg_diffnet* h, int t_uniform, int B, int T, hipStream_t st) {
+  float* cur = h->xa;
+  float* nxt = h->xb;
+  const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+  if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+  // the persistent launch zeroes its hand-off flags with a memset before every launch; inside a stream capture that pair did
+  // not replay correctly (measured), so a capturing stream gets the per-layer launches
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32 && cap == hipStreamCaptureStatusNone;
+  if (persist) {
+    TRY(launch_layers_persistent(h, nullptr, t_uniform, B, T, st));
+  } else {
+    for (int l = 0; l < h->L; ++l) {
+      TRY(launch_layer(h, l, cur, nullptr, t_uniform, nxt, h->skip, B, T, st));
+      float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+  }
+  if (prof) {
+    BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+    h->prof_used += 2;
+    h->prof_launches += persist ? 1 : h->L;
+  }
+  return BSG_OK;
+}
+
+static bool fused_tail_ok(const bsg_diffnet* h) {
+  return h->ws_pack != nullptr && (h->MP == 80 || h->MP == 96) && !getenv("BSG_NO_FUSED_TAIL");
+}
+
+// step_tail_kernel: skip projection, output projection, sampler update of x (DDPM, or PLMS when a.plms_hist > 0) and the next
+// evaluation's in-projection into h->xa; the caller fills the sampler-specific fields of `a`
+static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipStream_t st) {
+  static bool tail_attr = false;
+  const size_t tail_lds = (size_t)(C * 32 + 96 * 32) * sizeof(float);
+  if (!tail_attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    tail_attr = true;
+  }
+  a.skip = h->skip; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h : nullptr;
+  a.x = x; a.xa_next = h->xa;
+  a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
+  a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32);
+  const dim3 grid(B * a.tiles_per_row), block(512);
+  if (h->MP == 80) hipLaunchKernelGGL(step_tail_kernel<80>, grid, block, tail_lds, st, a);
+  else hipLaunchKernelGGL(step_tail_kernel<96>, grid, block, tail_lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
 extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float* noise, uint64_t seed,
                                int32_t t_start, int32_t n_steps, int32_t B, int32_t T, int32_t row0, int32_t B_total,
                                void* stream) {
@@ -1624,7 +1711,7 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   BSG_REQUIRE(n % 4 == 0, "ddpm_sample: B*M*T must be a multiple of 4");
   const long long n4 = n / 4;
   const unsigned long long quad0 = (unsigned long long)row0 * h->M * T / 4;
-  const bool fused = h->ws_pack != nullptr && (h->MP == 80 || h->MP == 96) && !getenv("BSG_NO_FUSED_TAIL");
+  const bool fused = fused_tail_ok(h);
   if (!fused) {
     for (int k = 0; k < n_steps; ++k) {
       const int i = t_start - k;
@@ -1639,50 +1726,17 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   }
   // fused loop: [in-projection once] -> per step: 20 residual layers -> step_tail_kernel (skip projection, output
   // projection, sampler update, next step's in-projection)
-  static bool tail_attr = false;
-  const size_t tail_lds = (size_t)(C * 32 + 96 * 32) * sizeof(float);
-  if (!tail_attr) {
-    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
-    tail_attr = true;
-  }
   if (n_steps > 0) TRY(conv1x1(h->w_in, h->b_in, x, h->xa, C, h->M, B, T, ACT_RELU, st));
   for (int k = 0; k < n_steps; ++k) {
     const int i = t_start - k;
-    float* cur = h->xa;
-    float* nxt = h->xb;
-    const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
-    if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    // the persistent launch zeroes its hand-off flags with a memset before every launch; inside a stream capture that pair did
-    // not replay correctly (measured), so a capturing stream gets the per-layer launches
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(st, &cap);
-    const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32 && cap == hipStreamCaptureStatusNone;
-    if (persist) {
-      TRY(launch_layers_persistent(h, nullptr, i, B, T, st));
-    } else {
-      for (int l = 0; l < h->L; ++l) {
-        TRY(launch_layer(h, l, cur, nullptr, i, nxt, h->skip, B, T, st));
-        float* tmp = cur; cur = nxt; nxt = tmp;
-      }
-    }
-    if (prof) {
-      BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-      h->prof_used += 2;
-      h->prof_launches += persist ? 1 : h->L;
-    }
+    TRY(layers_from_xa(h, i, B, T, st));
     TailArgs a{};
-    a.skip = h->skip; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h : nullptr;
-    a.x = x; a.noise = noise ? noise + (long long)k * n : nullptr; a.xa_next = h->xa;
-    a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
+    a.noise = noise ? noise + (long long)k * n : nullptr;
     a.k = StepCoef{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
                    s->posterior_mean_coef2[i], s->sigma[i]};
     a.seed = seed; a.quad_row0 = (unsigned long long)row0 * h->M * T; a.stream = (unsigned)(i + 1);
-    a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32); a.do_head = k + 1 < n_steps;
-    const dim3 grid(B * a.tiles_per_row), block(512);
-    if (h->MP == 80) hipLaunchKernelGGL(step_tail_kernel<80>, grid, block, tail_lds, st, a);
-    else hipLaunchKernelGGL(step_tail_kernel<96>, grid, block, tail_lds, st, a);
-    BSG_LAUNCH_CHECK();
+    a.do_head = k + 1 < n_steps;
+    TRY(launch_tail(h, a, x, B, T, st));
   }
   return BSG_OK;
 }
@@ -1802,6 +1856,7 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     TRY(dev_alloc(&h->xpred, (size_t)h->M * h->cap_bt));
   }
   const dim3 grid(cdiv((long long)n, 256)), block(256);
+  const bool fused = fused_tail_ok(h);
   // history ring: hist[0] = newest
   float* hist[4] = {h->eps_hist[0], h->eps_hist[1], h->eps_hist[2], h->eps_hist[3]};
   int n_hist = 0;
@@ -1812,6 +1867,21 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     c.a_t = s->alphas_cumprod[i];
     c.a_prev = s->alphas_cumprod[ip];
     float* e_new = hist[3];  // slot about to be recycled
+    if (n_hist > 0 && fused) {
+      // fused iteration: h->xa already holds the in-projection of x (left by the previous iteration); the tail projects the skip
+      // sum to eps, stores it to the history slot, applies the multistep update to x and projects the new x for the next one
+      TRY(layers_from_xa(h, i, B, T, st));
+      TailArgs a{};
+      a.plms_hist = n_hist; a.pk = c; a.e_new = e_new; a.h1 = hist[0]; a.h2 = hist[1]; a.h3 = hist[2];
+      if (n_hist == 1) { a.pk.w0 = 3.f; a.pk.inv = 2.f; }
+      else if (n_hist == 2) { a.pk.w0 = 23.f; a.pk.w1 = -16.f; a.pk.w2 = 5.f; a.pk.inv = 12.f; }
+      else { a.pk.w0 = 55.f; a.pk.w1 = -59.f; a.pk.w2 = 37.f; a.pk.w3 = -9.f; a.pk.inv = 24.f; }
+      a.do_head = i - interval >= 0;
+      TRY(launch_tail(h, a, x, B, T, st));
+      hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = e_new;
+      if (n_hist < 3) ++n_hist;
+      continue;
+    }
     TRY(forward_impl(h, x, nullptr, i, e_new, B, T, st));
     if (n_hist == 0) {
       c.inv = 1.f;
@@ -1835,6 +1905,7 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
                          (const float*)hist[1], (const float*)hist[2], c, (long long)n);
     }
     BSG_LAUNCH_CHECK();
+    if (fused && i - interval >= 0) TRY(conv1x1(h->w_in, h->b_in, x, h->xa, C, h->M, B, T, ACT_RELU, st));   // for the fused iterations
     hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = e_new;
     if (n_hist < 3) ++n_hist;
   }

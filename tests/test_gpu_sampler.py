@@ -115,6 +115,23 @@ def test_fused_step_tail_matches_separate_kernels(model, monkeypatch):
     assert maxabs(fused_p, fused) > 1e-2
 
 
+def test_fused_plms_tail_matches_separate_kernels(model, monkeypatch):
+    """PLMS loop: from the second iteration on the tail is fused (skip-proj -> out-proj -> eps stored to the history ->
+    multistep update -> next in-proj); against the separate GEMM launches + plms_step_kernel.  Partial tile, B > 1."""
+    B, T = 3, 77
+    cond = torch.randn(B, 256, T, generator=torch.Generator().manual_seed(6)).cuda()
+    x0 = T_(synth.synth_noise(1, B, 80, T, seed=4))[0][:, None].contiguous().cuda()
+    hparams['pndm_speedup'] = 5
+    try:
+        fused = model.sample(cond, x0.clone()).clone()
+        monkeypatch.setenv('BSG_NO_FUSED_TAIL', '1')
+        sep = model.sample(cond, x0.clone()).clone()
+    finally:
+        hparams['pndm_speedup'] = 0
+    assert bool(torch.isfinite(fused).all())
+    assert maxabs(fused, sep) <= 2e-5
+
+
 @pytest.mark.parametrize('B,T', [(3, 77), (16, 1000), (40, 640)])
 def test_persistent_layers_bitwise_equal_to_per_layer_launches(B, T):
     """BSG_PERSIST=1: the 20 layers as one launch with neighbour-tile hand-offs must give bit-identical results
