@@ -121,3 +121,28 @@ def test_drop_in_state_dicts_match_reference_lists(sd_spec):
     from bisinger_amd import _lib
     with pytest.raises(_lib.BsgError):
         gd.denoise_fn(torch.zeros(1, 1, 80, 8), torch.zeros(1, dtype=torch.long), torch.zeros(1, 256, 8))
+
+
+def test_diffnet_compute_dtype_option():
+    """`diff_compute_dtype` (extension, not in the reference): default fp32, read from hparams, validated on the host
+    before any library call; the state_dict is unaffected by it."""
+    import pytest
+    from bisinger_amd import _lib
+    from bisinger_amd.hparams import hparams, set_hparams
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    set_hparams(os.path.join(root, 'bisinger_amd', 'configs', 'bisinger_diff100.yaml'), print_hparams=False)
+    from bisinger_amd.diffnet import DiffNet
+    a = DiffNet(80)
+    assert a.compute_dtype == 'fp32'
+    hparams['diff_compute_dtype'] = 'bf16'
+    try:
+        b = DiffNet(80)
+    finally:
+        hparams.pop('diff_compute_dtype')
+    assert b.compute_dtype == 'bf16'
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    a.set_compute('bf16')
+    assert a.compute_dtype == 'bf16'
+    with pytest.raises(_lib.BsgError):
+        a.set_compute('int8')
