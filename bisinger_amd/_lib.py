@@ -8,6 +8,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
+if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
+    LIB_PATH = os.environ['BSG_LIB']
 ABI_VERSION = 1
 
 
