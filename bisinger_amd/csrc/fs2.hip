@@ -86,6 +86,107 @@ __global__ void masked_softmax_kernel(float* __restrict__ S, const float* __rest
   for (int k = tid; k < Tk; k += 256) s[k] = s[k] / sum;
 }
 
+// ---- fused self-attention (EncSALayer's MultiheadAttention, common_layers.py:282-370, head dim 128) -------------------
+// softmax(Q K^T + key-padding mask) V without materialising the [T,T] scores, fp32 MFMA throughout.  One wave = 32 queries;
+// a workgroup of NW waves shares the K / V tiles of a 32-key block in LDS.  Per block:
+//   S^T[key, q] = K[32 x 128] Q^T           A = K rows from LDS (stride 129: conflict-free), B = Q from registers (64 per lane)
+//   online softmax over keys: a lane owns ONE query (its accumulator column), its keys sit in its 16 registers and in the
+//   partner lane (lane ^ 32): max / sum are 16 in-register steps + one cross-half shuffle; the running output is rescaled
+//   in registers (exp(m_old - m_new) is per lane)
+//   O^T[d, q] += V^T[d, key] P[key, q]      the S accumulator IS the B operand: MFMA step j takes key row (j&3)+8(j>>2) (+4 for
+//   the upper lane half) = register j of the lane, the A operand V[key][d] is read from LDS with that same key order.
+// q is pre-scaled by head_dim^-1/2 (fused into the QKV projection); masked keys (keep == 0, or beyond T) get -inf as in the
+// reference's masked_fill; rows are [b*T + t][3H] with Q | K | V column blocks.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ keep,
+                                                                float* __restrict__ out, int T, int heads, int ld, int ldo) {
+  constexpr int D = 128, BK = 32, LDK = D + 1;
+  __shared__ float Ks[BK * LDK];
+  __shared__ __attribute__((aligned(16))) float Vs[BK * D];
+  __shared__ float kp[BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / heads, hh = blockIdx.y - b * heads;
+  const int q_row = (blockIdx.x * NW + wave) * 32 + l31;
+  const bool q_ok = q_row < T;
+  const float* __restrict__ base = qkv + (long long)b * T * ld + hh * D;
+  float qreg[64];
+  {
+    const float* __restrict__ qp = base + (long long)(q_ok ? q_row : T - 1) * ld;
+#pragma unroll
+    for (int s = 0; s < 64; ++s) qreg[s] = qp[2 * s + lh];
+  }
+  f32x16 O[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int H3 = ld / 3;
+  for (int k0 = 0; k0 < T; k0 += BK) {
+    __syncthreads();   // the previous block's tiles are consumed
+#pragma unroll
+    for (int j = 0; j < 1024 / (64 * NW); ++j) {
+      const int idx = tid + 64 * NW * j;
+      const int key = idx >> 5, c4 = (idx & 31) << 2;
+      const int kt = k0 + key;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (kt < T) {
+        const float* __restrict__ rp = base + (long long)kt * ld + c4;
+        kv = *reinterpret_cast<const f32x4*>(rp + H3);
+        vv = *reinterpret_cast<const f32x4*>(rp + 2 * H3);
+      }
+      Ks[key * LDK + c4] = kv[0]; Ks[key * LDK + c4 + 1] = kv[1]; Ks[key * LDK + c4 + 2] = kv[2]; Ks[key * LDK + c4 + 3] = kv[3];
+      *reinterpret_cast<f32x4*>(&Vs[key * D + c4]) = vv;
+    }
+    if (tid < BK) kp[tid] = (k0 + tid < T) ? keep[(long long)b * T + k0 + tid] : 0.f;
+    __syncthreads();
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    {
+      const float* __restrict__ kr = Ks + l31 * LDK + lh;
+#pragma unroll
+      for (int s = 0; s < 64; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * s], qreg[s], S, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (kp[acc_row(r, lh)] == 0.f) S[r] = -INFINITY;
+      mx = fmaxf(mx, S[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float ms = m_new == -INFINITY ? 0.f : m_new;     // a block of masked keys only must not produce inf - inf
+    const float scale = expf(m - ms);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = expf(S[r] - ms);
+      ps += S[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    l = l * scale + ps;
+    m = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[dt][r] *= scale;
+      const float* __restrict__ vr = Vs + 4 * lh * D + 32 * dt + l31;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[((j & 3) + 8 * (j >> 2)) * D], S[j], O[dt], 0, 0, 0);
+    }
+  }
+  if (q_ok) {
+    const float inv = 1.0f / l;
+    float* __restrict__ op = out + ((long long)b * T + q_row) * ldo + hh * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[32 * dt + acc_row(r, lh)] = O[dt][r] * inv;
+  }
+}
+
 // ---- token embeddings ----------------------------------------------------------------------------
 // x0 = sqrt(H) * E_tok[txt]; lang_e = E_lang[lang]                      (diffsinger_midi/fs2.py:28,122)
 __global__ void embed_tokens_kernel(const long long* __restrict__ txt, const long long* __restrict__ lang,
@@ -474,6 +575,12 @@ static int ensure_ws(bsg_fs2midi* h, size_t rows, size_t scores, hipStream_t st)
     BSG_HIP(hipMalloc((void**)&h->w_pos, rows * sizeof(int)));
     h->cap_rows = rows;
   }
+  (void)scores;   // the score tensor of the unfused attention is allocated on demand (ensure_scores)
+  return BSG_OK;
+}
+
+// [B*heads, T, T] scores: only the unfused attention path (BSG_NO_FLASH_ATTN=1, or a head dim other than 128) needs them
+static int ensure_scores(bsg_fs2midi* h, size_t scores, hipStream_t st) {
   if (scores > h->cap_scores) {
     BSG_HIP(hipStreamSynchronize(st));
     if (h->w_scores) (void)hipFree(h->w_scores);
@@ -509,23 +616,32 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
     // --- self attention ---
     TRY(ln(x, L.ln1w, L.ln1b, h->w_a, nullptr, rows, 1e-5f, st));
     TRY(linear(h->w_a, L.in_proj, nullptr, h->w_qkv, rows, 3 * H, H, ACT_NONE, nullptr, nullptr, st, qscale, H));
-    {
+    if (hd == 128 && !getenv("BSG_NO_FLASH_ATTN")) {
+      // fused attention: no [B*heads, T, T] score tensor (flash_attn_kernel); 2 waves per workgroup when 4 would leave CUs idle
+      const long long wg4 = (long long)cdiv(T, 128) * B * heads;
+      if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
+      else hipLaunchKernelGGL(flash_attn_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
+      BSG_LAUNCH_CHECK();
+    } else {
+      TRY(ensure_scores(h, (size_t)B * heads * T * T, st));
+      {
       GemmArgs g{};   // S[b,h] = Q K^T
       g.A = h->w_qkv; g.B = h->w_qkv + H; g.C = h->w_scores; g.M = T; g.N = T; g.K = hd; g.lda = 3 * H; g.ldb = 3 * H; g.ldc = T;
       g.trans_b = 1; g.taps = 1; g.alpha = 1.f; g.batch = B * heads; g.batch2 = heads;
       g.sA = (long long)T * 3 * H; g.sA2 = hd; g.sB = (long long)T * 3 * H; g.sB2 = hd;
       g.sC = (long long)heads * T * T; g.sC2 = (long long)T * T;
       TRY(launch_gemm(g, st));
-    }
-    hipLaunchKernelGGL(masked_softmax_kernel, dim3((unsigned)((long long)B * heads * T)), dim3(256), 0, st, h->w_scores, keep, T, T, heads);
-    BSG_LAUNCH_CHECK();
-    {
+      }
+      hipLaunchKernelGGL(masked_softmax_kernel, dim3((unsigned)((long long)B * heads * T)), dim3(256), 0, st, h->w_scores, keep, T, T, heads);
+      BSG_LAUNCH_CHECK();
+      {
       GemmArgs g{};   // O[b,:,h] = P V
       g.A = h->w_scores; g.B = h->w_qkv + 2 * H; g.C = h->w_a; g.M = T; g.N = hd; g.K = T; g.lda = T; g.ldb = 3 * H; g.ldc = H;
       g.trans_b = 0; g.taps = 1; g.alpha = 1.f; g.batch = B * heads; g.batch2 = heads;
       g.sA = (long long)heads * T * T; g.sA2 = (long long)T * T; g.sB = (long long)T * 3 * H; g.sB2 = hd;
       g.sC = (long long)T * H; g.sC2 = hd;
       TRY(launch_gemm(g, st));
+      }
     }
     TRY(linear(h->w_a, L.out_proj, nullptr, h->w_b, rows, H, H, ACT_NONE, x, keep, st));   // x1 = (x + attn) * keep
     // --- conv FFN ---
