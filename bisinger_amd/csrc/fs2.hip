@@ -168,10 +168,13 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(const float* __r
     ps += __shfl_xor(ps, 32);
     l = l * scale + ps;
     m = m_new;
+    const bool rescale = __any(scale != 1.0f);   // wave-uniform: once the running maxima have settled nothing is rescaled
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
+      if (rescale) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) O[dt][r] *= scale;
+        for (int r = 0; r < 16; ++r) O[dt][r] *= scale;
+      }
       const float* __restrict__ vr = Vs + 4 * lh * D + 32 * dt + l31;
 #pragma unroll
       for (int j = 0; j < 16; ++j) O[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[((j & 3) + 8 * (j >> 2)) * D], S[j], O[dt], 0, 0, 0);
