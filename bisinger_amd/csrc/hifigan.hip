@@ -38,6 +38,10 @@ struct ConvArgs {
   float in_slope;      // LeakyReLU slope applied to the input (1 = identity)
   int out_tanh;
   int Cin, Cout, L, dil, pad;
+  // polyphase ConvTranspose1d (n_phase = stride u > 0): blockIdx.z = b*u + phase; position q of phase r is output sample
+  // q*u + r + ph_off of a row of Lout samples; the phase's 2-tap weights start at w + r*w_phase_stride
+  int n_phase, ph_off, Lq, Lout;
+  long long w_phase_stride;
 };
 
 template <int K, int CO_BLK, int TT>
@@ -47,9 +51,11 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int t0 = blockIdx.x * TILE;
   const int co0 = blockIdx.y * CO_BLK;
-  const int b = blockIdx.z;
+  const int ph = a.n_phase > 0 ? (int)blockIdx.z % a.n_phase : 0;
+  const int b = a.n_phase > 0 ? (int)blockIdx.z / a.n_phase : (int)blockIdx.z;
   const int span = TILE + (K - 1) * a.dil;
   const float* __restrict__ xb = a.x + (long long)b * a.Cin * a.L;
+  const float* __restrict__ wbase = a.w + (long long)ph * a.w_phase_stride;
 
   float acc[CO_BLK][TT];
 #pragma unroll
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 #pragma unroll 1
     for (int ci = 0; ci < nci; ++ci) {
       // wave-uniform -> scalar loads, CO_BLK consecutive floats per tap
-      const float* __restrict__ wp = a.w + ((long long)blockIdx.y * a.Cin + (ci0 + ci)) * (K * CO_BLK);
+      const float* __restrict__ wp = wbase + ((long long)blockIdx.y * a.Cin + (ci0 + ci)) * (K * CO_BLK);
       const float* __restrict__ xr = xs + ci * span + tid;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -93,6 +99,19 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
     }
   }
 
+  if (a.n_phase > 0) {   // polyphase transposed conv: strided store of this phase's samples
+#pragma unroll
+    for (int c = 0; c < CO_BLK; ++c) {
+      const long long rowo = ((long long)b * a.Cout + co0 + c) * a.Lout;
+#pragma unroll
+      for (int j = 0; j < TT; ++j) {
+        const int q = t0 + tid + 256 * j;
+        const int to = q * a.n_phase + ph + a.ph_off;
+        if (q < a.Lq && to >= 0 && to < a.Lout && co0 + c < a.Cout) a.y[rowo + to] = acc[c][j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < CO_BLK; ++c) {
     const long long rowo = ((long long)b * a.Cout + co0 + c) * a.L;
@@ -177,6 +196,20 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restric
   out[i] = co < Cout ? w[((long long)co * Cin + ci) * K + k] : 0.f;
 }
 
+// ConvTranspose1d weight [Cin][Cout][K], K = 2u  ->  per output phase r a 2-tap Conv1d over the input positions:
+//   y[co][q*u + r - p] = b + sum_ci ( x[ci][q-1] * w[ci][co][r+u] + x[ci][q] * w[ci][co][r] )
+// packed like pack_conv_w_kernel: out[r][co-block][ci][k'][CO], k' = 0 -> tap x[q-1], k' = 1 -> tap x[q]
+__global__ void pack_convT_w_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int u, int CO) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nblk = (Cout + CO - 1) / CO;
+  const int per_phase = nblk * Cin * 2 * CO;
+  if (i >= u * per_phase) return;
+  const int r = i / per_phase, rem = i - r * per_phase;
+  const int c = rem % CO, kk = (rem / CO) % 2, ci = (rem / (2 * CO)) % Cin, blk = rem / (2 * CO * Cin);
+  const int co = blk * CO + c;
+  out[i] = co < Cout ? w[((long long)ci * Cout + co) * (2 * u) + r + (1 - kk) * u] : 0.f;
+}
+
 template <int K, int TT>
 int launch_conv_kt(const ConvArgs& a, int B, hipStream_t st) {
   constexpr int TILE = 256 * TT;
@@ -199,6 +232,23 @@ int launch_conv_k(const ConvArgs& a, int B, hipStream_t st) {
   if (wgs4 >= 512) return launch_conv_kt<K, 4>(a, B, st);
   if (wgs4 >= 256) return launch_conv_kt<K, 2>(a, B, st);
   return launch_conv_kt<K, 1>(a, B, st);
+}
+
+// polyphase ConvTranspose1d (K = 2u): one launch, blockIdx.z = (batch row, phase), 2-tap convs with strided stores
+template <int TT>
+int launch_convT_t(const ConvArgs& a, int B, hipStream_t st) {
+  constexpr int TILE = 256 * TT;
+  const size_t lds = (size_t)CI_CHUNK * (TILE + 1) * sizeof(float);
+  if (a.Cout >= 16) hipLaunchKernelGGL((conv1d_kernel<2, 16, TT>), dim3(cdiv(a.Lq, TILE), cdiv(a.Cout, 16), B * a.n_phase), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((conv1d_kernel<2, 8, TT>), dim3(cdiv(a.Lq, TILE), cdiv(a.Cout, 8), B * a.n_phase), dim3(256), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+int launch_convT(const ConvArgs& a, int B, hipStream_t st) {
+  const long long wgs4 = (long long)cdiv(a.Lq, 1024) * cdiv(a.Cout, a.Cout >= 16 ? 16 : 8) * B * a.n_phase;
+  if (wgs4 >= 512) return launch_convT_t<4>(a, B, st);
+  if (wgs4 >= 256) return launch_convT_t<2>(a, B, st);
+  return launch_convT_t<1>(a, B, st);
 }
 
 int launch_conv(const ConvArgs& a, int K, int B, hipStream_t st) {
@@ -292,6 +342,17 @@ static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st) {
   return BSG_OK;
 }
 
+// ConvTranspose1d with K == 2*u: per-phase 2-tap weights for the polyphase launch
+static int pack_convT(bsg_hifigan* h, ConvW& c, int u, hipStream_t st) {
+  if (c.k != 2 * u) return BSG_OK;   // other shapes keep the gather kernel
+  const int CO = c.cout >= 16 ? 16 : 8;
+  const int n = u * cdiv(c.cout, CO) * c.cin * 2 * CO;
+  TRY(hg_alloc(h, &c.wpk, n));
+  hipLaunchKernelGGL(pack_convT_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, c.wpk, c.cin, c.cout, u, CO);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
 extern "C" int bsg_hifigan_n_weights(const bsg_hifigan_cfg* c) {
   const int convs = 2 + c->n_ups + 2 * c->n_ups * c->n_kernels * c->n_dil;
   return convs * (c->weight_norm ? 3 : 2) + (c->use_nsf ? 2 + 2 * c->n_ups : 0);
@@ -360,6 +421,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
     ConvW& c = h->ups[i];
     c.cin = C0 >> i; c.cout = C0 >> (i + 1); c.k = cfg->upsample_kernel_sizes[i];
     if ((rc = take_conv(h, c, w, c.cin, c.cout * c.k, st)) != BSG_OK) return fail(rc);   // weight [Cin][Cout][K], g over dim 0 = Cin
+    if ((rc = pack_convT(h, c, cfg->upsample_rates[i], st)) != BSG_OK) return fail(rc);
   }
   const int nrb = cfg->n_ups * cfg->n_kernels;
   h->rb1.resize((size_t)nrb * cfg->n_dil);
@@ -425,9 +487,19 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
     t.x = cur; t.w = up.w; t.bias = up.b; t.y = (cur == x ? xs : x); t.in_slope = slope; t.Cin = up.cin; t.Cout = up.cout;
     t.Lin = L; t.K = up.k; t.u = c.upsample_rates[i]; t.p = (up.k - c.upsample_rates[i]) / 2;
     const int Lout = L * t.u;
-    if (up.cout >= 16) hipLaunchKernelGGL(conv_transpose1d_kernel<16>, dim3(cdiv(Lout, 256), cdiv(up.cout, 16), B), dim3(256), 0, st, t);
-    else hipLaunchKernelGGL(conv_transpose1d_kernel<8>, dim3(cdiv(Lout, 256), cdiv(up.cout, 8), B), dim3(256), 0, st, t);
-    BSG_LAUNCH_CHECK();
+    if (up.wpk && !getenv("BSG_NO_POLYPHASE")) {
+      // polyphase form: u interleaved 2-tap convolutions over the input positions (weights wave-uniform -> scalar loads)
+      ConvArgs a{};
+      a.x = cur; a.w = up.wpk; a.bias = up.b; a.y = t.y; a.out_div = 1.0f; a.in_slope = slope;
+      a.Cin = up.cin; a.Cout = up.cout; a.L = L; a.dil = 1; a.pad = 1;
+      a.n_phase = t.u; a.ph_off = -t.p; a.Lq = L + 1; a.Lout = Lout;
+      a.w_phase_stride = (long long)cdiv(up.cout, up.cout >= 16 ? 16 : 8) * up.cin * 2 * (up.cout >= 16 ? 16 : 8);
+      TRY(launch_convT(a, B, st));
+    } else {
+      if (up.cout >= 16) hipLaunchKernelGGL(conv_transpose1d_kernel<16>, dim3(cdiv(Lout, 256), cdiv(up.cout, 16), B), dim3(256), 0, st, t);
+      else hipLaunchKernelGGL(conv_transpose1d_kernel<8>, dim3(cdiv(Lout, 256), cdiv(up.cout, 8), B), dim3(256), 0, st, t);
+      BSG_LAUNCH_CHECK();
+    }
     if (har) {   // x = x + LayerNorm_C(relu(noise_conv_i(har_source)))                       (hifigan.py:154-160)
       const ConvW& nc = h->noise_convs[i];
       const int stride = i + 1 < c.n_ups ? nc.k / 2 : 1;
