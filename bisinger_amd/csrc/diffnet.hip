@@ -428,7 +428,11 @@ __global__ void pack_a16_kernel(const float* __restrict__ w, float* __restrict__
   out[i] = w[(long long)(16 * mt + (lane & 15)) * K + 16 * q + 4 * jj + (lane >> 4)];
 }
 
-__global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
+// WIDE = false: the pair form described above (2 workgroups x 8 waves per tile).  WIDE = true: ONE workgroup of 16 waves per
+// tile — the same wave program, z exchanged through LDS only — for launches of 129..256 tiles (B = 5..8 at T=1000), where the
+// regular launch has one 8-wave workgroup per CU: 4 waves per SIMD instead of 2 for the same matrix work.
+template <bool WIDE>
+__global__ __launch_bounds__(WIDE ? 1024 : 512, 4) void residual_split_kernel(SplitArgs s) {
   const ResArgs& a = s.base;
   constexpr int NT = 32, LDX = NT + 2 * HALO, LDZ = 48, NR = 4;   // NR: depth of the A-fragment rings (k-groups)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -438,7 +442,9 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p16 = lane & 15, lq = lane >> 4;
-  const int tile_id = (int)blockIdx.x >> 1, part = (int)blockIdx.x & 1;
+  constexpr int NTHR = WIDE ? 1024 : 512;
+  const int tile_id = WIDE ? (int)blockIdx.x : (int)blockIdx.x >> 1;
+  const int part = WIDE ? 0 : (int)blockIdx.x & 1;
   const int b = tile_id / a.tiles_per_row;
   const int t0 = (tile_id - b * a.tiles_per_row) * NT;
   const int T = a.T;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
   const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * a.L + a.layer) * C, C * 4);
   const rsrc_t rs_zb = mk_rsrc(s.zbuf + (long long)tile_id * C * NT, C * NT * 4);
   const int rowT = T * 4, vfrag = lane * 16;
-  const int gt = 8 * part + wave;   // this wave's 16-row tile: gate 16gt.., filter C+16gt..; later residual 16gt.., skip C+16gt..
+  const int gt = WIDE ? wave : 8 * part + wave;   // this wave's 16-row tile: gate 16gt.., filter C+16gt..; later residual 16gt.., skip C+16gt..
 
   // ---- (1) first A fragments fly while the x tile is staged ---------------------------------------
   const int sw[2] = {gt * 16 * 1024, (16 + gt) * 16 * 1024};
@@ -468,8 +474,8 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
   // ---- (2) stage xs = x + d (zero padded), as residual_tile ---------------------------------------
   if ((T & 3) == 0) {
 #pragma unroll 3
-    for (int k = 0; k < 6; ++k) {
-      const int idx = tid + 512 * k;
+    for (int k = 0; k < 3072 / NTHR; ++k) {
+      const int idx = tid + NTHR * k;
       const int c = idx / 12, j4 = idx - c * 12;
       const int t = t0 - HALO + 4 * j4;
       const bool ok = t >= 0 && t < T;
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
     }
   } else {
 #pragma unroll 4
-    for (int idx = tid; idx < C * LDX; idx += 512) {
+    for (int idx = tid; idx < C * LDX; idx += NTHR) {
       const int c = idx / LDX, j = idx - c * LDX;
       const int t = t0 - HALO + j;
       const bool ok = t >= 0 && t < T;
@@ -585,6 +591,15 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
   }
   __syncthreads();   // every wave is done reading xs
   // ---- (5) z: own half -> LDS and (write-through) -> the exchange tile; partner half <- exchange tile ------
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * gt + 4 * lq + r;
+      zs[row * LDZ + tp] = z0[r];
+      zs[row * LDZ + tp + dil] = z1[r];
+    }
+    __syncthreads();
+  } else {
   {
     const int vz = ((4 * lq) * NT + tp) * 4;
 #pragma unroll
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(512, 4) void residual_split_kernel(SplitArgs s) {
     }
   }
   __syncthreads();
+  }
   // ---- (6) GEMM2: residual tile + skip tile of 16 rows x 2 column tiles of 16 frames -------------------------
   {
     const float* zb = zs + lq * LDZ + p16;
@@ -1453,19 +1469,31 @@ static bool use_wino() {
 // A pair of workgroups per tile pays (a z exchange through L2) only when single workgroups would leave CUs idle: measured on
 // MI355X at T=1000, B = 1 / 2 / 4 (32 / 64 / 128 tiles): 63 -> 41, 64 -> 42, 65 -> 47 us per layer; B = 6 (192 tiles): 68 -> 70.
 // So: at most one workgroup per CU after the split, which also keeps every workgroup of the launch resident (the partner
-// of a polling workgroup is always running).  BSG_SPLIT=0 disables it.
-static bool use_split(bsg_diffnet* h, int B, int T) {
-  static int env = -1, occ = -1;
+// of a polling workgroup is always running).  Between 129 and 256 tiles the 16-wave form (no inter-workgroup traffic) takes over.
+// BSG_SPLIT=0 disables both.
+// The pair form runs with at most one workgroup per CU by construction of its threshold, but the dispatcher may still place two
+// of them on one CU while others stay empty; asking for more than half of the CU's 160 KB of LDS (only 48 KB are used) makes
+// that impossible.
+static constexpr size_t kSplitLds = 84 * 1024;
+
+static int use_split(bsg_diffnet* h, int B, int T) {   // 0: regular launch, 1: pair of workgroups per tile, 2: one 16-wave workgroup per tile
+  static int env = -1, occ = -1, occw = -1;
   if (env < 0) { const char* e = getenv("BSG_SPLIT"); env = e ? atoi(e) : 1; }
-  if (!env || !h->num_cus || !h->zbuf) return false;
+  if (!env || !h->num_cus || !h->zbuf) return 0;
   const long long tiles = (long long)B * cdiv(T, 32);
-  if (2 * tiles > h->num_cus || (size_t)tiles > h->split_cap) return false;
+  if ((size_t)tiles > h->split_cap) return 0;
+  const int lds = C * 48 * (int)sizeof(float);
   if (occ < 0) {
-    if (hipFuncSetAttribute((const void*)residual_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C * 48 * (int)sizeof(float)) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)residual_split_kernel, 512, (size_t)C * 48 * sizeof(float)) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)residual_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)residual_split_kernel<false>, 512, kSplitLds) != hipSuccess)
       occ = 0;
+    if (hipFuncSetAttribute((const void*)residual_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occw, (const void*)residual_split_kernel<true>, 1024, (size_t)lds) != hipSuccess)
+      occw = 0;
   }
-  return occ >= 2;
+  if (2 * tiles <= h->num_cus) return occ >= 1 ? 1 : 0;
+  if (tiles <= h->num_cus && env != 3) return occw >= 1 ? 2 : 0;   // BSG_SPLIT=3: pair form only (A/B measurements)
+  return 0;
 }
 
 static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long long* t_dev, int t_uniform, float* x_out,
@@ -1496,7 +1524,8 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     s.status = h->split_flags + 2 * h->split_cap;
     if (++h->split_epoch == 0) h->split_epoch = 1;
     s.epoch = h->split_epoch;
-    hipLaunchKernelGGL(residual_split_kernel, dim3(2 * B * a.tiles_per_row), dim3(512), (size_t)C * 48 * sizeof(float), st, s);
+    if (use_split(h, B, T) == 2) hipLaunchKernelGGL(residual_split_kernel<true>, dim3(B * a.tiles_per_row), dim3(1024), (size_t)C * 48 * sizeof(float), st, s);
+    else hipLaunchKernelGGL(residual_split_kernel<false>, dim3(2 * B * a.tiles_per_row), dim3(512), kSplitLds, st, s);
     BSG_LAUNCH_CHECK();
     return BSG_OK;
   }
