@@ -413,7 +413,7 @@ struct SplitArgs {
   ResArgs base;
   const float* apack2w;   // output projection packed for 16x16x4 MFMAs [32 row tiles][16 k-groups][64][4]
   float* zbuf;            // [tiles][C][32] scratch for the z exchange
-  unsigned* flags;        // [tiles][2]
+  unsigned* flags;        // [tiles][parts][parts]: (producer, consumer)
   unsigned* status;       // += 1 for a poll that gave up
   unsigned epoch;         // launch counter (never 0): the value a flag takes in this launch
 };
@@ -431,8 +431,10 @@ __global__ void pack_a16_kernel(const float* __restrict__ w, float* __restrict__
 // WIDE = false: the pair form described above (2 workgroups x 8 waves per tile).  WIDE = true: ONE workgroup of 16 waves per
 // tile — the same wave program, z exchanged through LDS only — for launches of 129..256 tiles (B = 5..8 at T=1000), where the
 // regular launch has one 8-wave workgroup per CU: 4 waves per SIMD instead of 2 for the same matrix work.
-template <bool WIDE>
-__global__ __launch_bounds__(WIDE ? 1024 : 512, 4) void residual_split_kernel(SplitArgs s) {
+// NPART = 4 (launches of <= 64 tiles, B <= 2): four workgroups of 4 waves per tile, each a quarter of the channels; every part
+// publishes its z quarter to the three others through per-(producer, consumer) flags.
+template <bool WIDE, int NPART>
+__global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_kernel(SplitArgs s) {
   const ResArgs& a = s.base;
   constexpr int NT = 32, LDX = NT + 2 * HALO, LDZ = 48, NR = 4;   // NR: depth of the A-fragment rings (k-groups)
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -442,9 +444,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 4) void residual_split_kernel(Sp
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p16 = lane & 15, lq = lane >> 4;
-  constexpr int NTHR = WIDE ? 1024 : 512;
-  const int tile_id = WIDE ? (int)blockIdx.x : (int)blockIdx.x >> 1;
-  const int part = WIDE ? 0 : (int)blockIdx.x & 1;
+  constexpr int WAVES = WIDE ? 16 : 16 / NPART, NTHR = 64 * WAVES;
+  const int tile_id = WIDE ? (int)blockIdx.x : (int)blockIdx.x / NPART;
+  const int part = WIDE ? 0 : (int)blockIdx.x % NPART;
   const int b = tile_id / a.tiles_per_row;
   const int t0 = (tile_id - b * a.tiles_per_row) * NT;
   const int T = a.T;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 4) void residual_split_kernel(Sp
   const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * a.L + a.layer) * C, C * 4);
   const rsrc_t rs_zb = mk_rsrc(s.zbuf + (long long)tile_id * C * NT, C * NT * 4);
   const int rowT = T * 4, vfrag = lane * 16;
-  const int gt = WIDE ? wave : 8 * part + wave;   // this wave's 16-row tile: gate 16gt.., filter C+16gt..; later residual 16gt.., skip C+16gt..
+  const int gt = WIDE ? wave : WAVES * part + wave;   // this wave's 16-row tile: gate 16gt.., filter C+16gt..; later residual 16gt.., skip C+16gt..
 
   // ---- (1) first A fragments fly while the x tile is staged ---------------------------------------
   const int sw[2] = {gt * 16 * 1024, (16 + gt) * 16 * 1024};
@@ -614,28 +616,39 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, 4) void residual_split_kernel(Sp
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __hip_atomic_store(s.flags + 2 * tile_id + part, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(s.flags + 2 * tile_id + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 22)) {   // ~ seconds: never reached unless the partner is not resident
-        atomicAdd(s.status, 1u);
-        break;
+    // flags[tile][producer][consumer]: a producer publishes to each of the other parts; a consumer clears what it has consumed,
+    // so that a replay of this very launch (a captured graph holding a single layer launch replays the same epoch) cannot match
+    // a stale value; the producer sets it again only in a later launch
+    unsigned* f = s.flags + (long long)tile_id * (NPART * NPART);
+#pragma unroll
+    for (int o = 0; o < NPART; ++o)
+      if (o != part) __hip_atomic_store(f + part * NPART + o, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 0; o < NPART; ++o) {
+      if (o == part) continue;
+      unsigned spins = 0;
+      while (__hip_atomic_load(f + o * NPART + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a partner is not resident
+          atomicAdd(s.status, 1u);
+          break;
+        }
       }
+      __hip_atomic_store(f + o * NPART + part, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // consumed: clear the partner's flag, so that a replay of this very launch (a captured graph holding a single layer
-    // launch replays the same epoch) cannot match a stale value; the partner sets it again only in a later launch
-    __hip_atomic_store(s.flags + 2 * tile_id + (1 - part), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   {
-    const int c0 = (C / 2) * (1 - part);
+    // the other parts' channels: (NPART-1) * C/NPART rows of 8 float4
+    constexpr int CP = C / NPART, ITEMS = (NPART - 1) * CP * 8;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int idx = tid + 512 * k;
-      const int c = c0 + (idx >> 3), j4 = idx & 7;
+    for (int k = 0; k < ITEMS / NTHR; ++k) {
+      const int idx = tid + NTHR * k;
+      int c = idx >> 3;
+      const int j4 = idx & 7;
+      c += c >= part * CP ? CP : 0;   // skip the own block
       *reinterpret_cast<f32x4*>(zs + c * LDZ + 4 * j4) = ldf4(rs_zb, (c * NT + 4 * j4) * 4, 0);
     }
   }
@@ -1211,7 +1224,7 @@ struct bsg_diffnet {
   // channel-split launch for small batches (residual_split_kernel)
   float* apack2w = nullptr;            // [L][2C*C] output projection packed for 16x16x4 MFMAs
   float* zbuf = nullptr;               // [tiles][C][32] z exchange scratch
-  unsigned* split_flags = nullptr;     // [tiles][2] + status word
+  unsigned* split_flags = nullptr;     // [tiles][16] (producer, consumer) flags + status word
   size_t split_cap = 0;                // tiles the scratch is sized for
   unsigned split_epoch = 0;
 };
@@ -1429,8 +1442,8 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       h->split_flags = nullptr;
       h->split_cap = 0;
       TRY(dev_alloc(&h->zbuf, tiles * C * 32));
-      BSG_HIP(hipMalloc((void**)&h->split_flags, (2 * tiles + 4) * sizeof(unsigned)));
-      BSG_HIP(hipMemsetAsync(h->split_flags, 0, (2 * tiles + 4) * sizeof(unsigned), st));
+      BSG_HIP(hipMalloc((void**)&h->split_flags, (16 * tiles + 4) * sizeof(unsigned)));
+      BSG_HIP(hipMemsetAsync(h->split_flags, 0, (16 * tiles + 4) * sizeof(unsigned), st));
       h->split_cap = tiles;
     }
     if (!h->num_cus) {
@@ -1476,21 +1489,25 @@ static bool use_wino() {
 // that impossible.
 static constexpr size_t kSplitLds = 84 * 1024;
 
-static int use_split(bsg_diffnet* h, int B, int T) {   // 0: regular launch, 1: pair of workgroups per tile, 2: one 16-wave workgroup per tile
-  static int env = -1, occ = -1, occw = -1;
+static int use_split(bsg_diffnet* h, int B, int T) {   // 0: regular launch; 1 / 4: 2 / 4 workgroups per tile; 2: one 16-wave workgroup per tile
+  static int env = -1, occ = -1, occw = -1, occ4 = -1;
   if (env < 0) { const char* e = getenv("BSG_SPLIT"); env = e ? atoi(e) : 1; }
   if (!env || !h->num_cus || !h->zbuf) return 0;
   const long long tiles = (long long)B * cdiv(T, 32);
   if ((size_t)tiles > h->split_cap) return 0;
   const int lds = C * 48 * (int)sizeof(float);
   if (occ < 0) {
-    if (hipFuncSetAttribute((const void*)residual_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)residual_split_kernel<false>, 512, kSplitLds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)residual_split_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)residual_split_kernel<false, 2>, 512, kSplitLds) != hipSuccess)
       occ = 0;
-    if (hipFuncSetAttribute((const void*)residual_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occw, (const void*)residual_split_kernel<true>, 1024, (size_t)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)residual_split_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, (const void*)residual_split_kernel<false, 4>, 256, kSplitLds) != hipSuccess)
+      occ4 = 0;
+    if (hipFuncSetAttribute((const void*)residual_split_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occw, (const void*)residual_split_kernel<true, 1>, 1024, (size_t)lds) != hipSuccess)
       occw = 0;
   }
+  if (4 * tiles <= h->num_cus && env != 2 && occ4 >= 1) return 4;   // BSG_SPLIT=2: no 4-way split (A/B measurements)
   if (2 * tiles <= h->num_cus) return occ >= 1 ? 1 : 0;
   if (tiles <= h->num_cus && env != 3) return occw >= 1 ? 2 : 0;   // BSG_SPLIT=3: pair form only (A/B measurements)
   return 0;
@@ -1521,11 +1538,13 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     s.apack2w = h->apack2w + (size_t)layer * 2 * C * C;
     s.zbuf = h->zbuf;
     s.flags = h->split_flags;
-    s.status = h->split_flags + 2 * h->split_cap;
+    s.status = h->split_flags + 16 * h->split_cap;
     if (++h->split_epoch == 0) h->split_epoch = 1;
     s.epoch = h->split_epoch;
-    if (use_split(h, B, T) == 2) hipLaunchKernelGGL(residual_split_kernel<true>, dim3(B * a.tiles_per_row), dim3(1024), (size_t)C * 48 * sizeof(float), st, s);
-    else hipLaunchKernelGGL(residual_split_kernel<false>, dim3(2 * B * a.tiles_per_row), dim3(512), kSplitLds, st, s);
+    const int mode = use_split(h, B, T);
+    if (mode == 2) hipLaunchKernelGGL((residual_split_kernel<true, 1>), dim3(B * a.tiles_per_row), dim3(1024), (size_t)C * 48 * sizeof(float), st, s);
+    else if (mode == 4) hipLaunchKernelGGL((residual_split_kernel<false, 4>), dim3(4 * B * a.tiles_per_row), dim3(256), kSplitLds, st, s);
+    else hipLaunchKernelGGL((residual_split_kernel<false, 2>), dim3(2 * B * a.tiles_per_row), dim3(512), kSplitLds, st, s);
     BSG_LAUNCH_CHECK();
     return BSG_OK;
   }
@@ -1795,7 +1814,7 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
   }
   if (h->split_flags) {
     unsigned v = 0;
-    BSG_HIP(hipMemcpy(&v, h->split_flags + 2 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost));
+    BSG_HIP(hipMemcpy(&v, h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost));
     *handoff_timeouts += (int32_t)v;
   }
   return BSG_OK;
