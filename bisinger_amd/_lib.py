@@ -72,6 +72,7 @@ _SIGS = {
     'bsg_diffnet_persist_clocks': (c_int32, [c_void_p, c_void_p, c_int32]),
     'bsg_diffnet_status': (c_int32, [c_void_p, POINTER(c_int32)]),
     'bsg_diffnet_set_compute': (c_int32, [c_void_p, c_int32]),
+    'bsg_diffnet_status_async': (c_int32, [c_void_p, c_void_p, c_void_p]),
     'bsg_diffnet_profile': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_profile_read': (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'bsg_fs2midi_n_weights': (c_int32, [POINTER(Fs2Cfg)]),

@@ -1820,6 +1820,15 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
   return BSG_OK;
 }
 
+extern "C" int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream) {
+  BSG_REQUIRE(h && host_counts, "diffnet_status_async: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  host_counts[0] = host_counts[1] = 0;
+  if (h->flags) BSG_HIP(hipMemcpyAsync(&host_counts[0], h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (h->split_flags) BSG_HIP(hipMemcpyAsync(&host_counts[1], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  return BSG_OK;
+}
+
 extern "C" int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg) {
   BSG_REQUIRE(h && out && h->clk && n_wg > 0 && n_wg <= 1024, "diffnet_persist_clocks: bad argument");
   BSG_HIP(hipMemcpy(out, h->clk, (size_t)n_wg * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

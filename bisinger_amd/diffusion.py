@@ -216,6 +216,8 @@ class GaussianDiffusion(nn.Module):
             _lib.check(lib.bsg_mel_finish(_lib.ptr(x), _lib.ptr(smin), _lib.ptr(smax), _lib.ptr(m2p), _lib.ptr(out), B, M, T,
                                           _lib.stream_ptr()), 'bsg_mel_finish')
         ret['mel_out'] = out
+        if hasattr(self.denoise_fn, 'check_handoffs_async'):
+            self.denoise_fn.check_handoffs_async()
         return ret
 
     def norm_spec(self, x):

@@ -148,6 +148,10 @@ int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode);
  * BSG_PERSIST=1, and the channel-split launch used for small batches): number of inter-workgroup hand-off spins that
  * gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
 int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
+/* Asynchronous form: enqueues copies of the two give-up counters into host_counts[0..1] (pinned host memory, caller-owned)
+ * on `stream` and returns; the values are valid once the stream has passed that point (e.g. an event recorded after the
+ * call).  Lets a caller fail loudly one call later without adding a synchronisation to the path. */
+int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream);
 /* Diagnostic: {s_memtime, s_memrealtime} at the start and end of each workgroup of the LAST persistent launch,
  * out [n_wg][4] uint64 (host).  Shader clock held = d(memtime)/d(memrealtime) x 100 MHz.  Synchronous. */
 int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg);
