@@ -949,7 +949,7 @@ __device__ __forceinline__ void tile_gemm(f32x16& acc, rsrc_t rs, int vfrag, int
   }
 }
 
-template <int MP>   // MP = in_dims padded to a multiple of 8 (K of the head GEMM); in_dims <= 96
+template <int MP, bool PLMS>   // MP = in_dims padded to a multiple of 8 (K of the head GEMM), in_dims <= 96; PLMS: multistep update form
 __global__ __launch_bounds__(512, 4) void step_tail_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ss = lds;               // [C][32]  skip tile, then h tile
@@ -1033,8 +1033,8 @@ __global__ __launch_bounds__(512, 4) void step_tail_kernel(TailArgs a) {
       xv[r] = ldf(rs_x, vcol, m0 * rowT);
       nv[r] = a.noise ? ldf(rs_n, vcol, m0 * rowT) : 0.f;
     }
-    float h1v[16], h2v[16], h3v[16];
-    if (a.plms_hist) {
+    float h1v[PLMS ? 16 : 1], h2v[PLMS ? 16 : 1], h3v[PLMS ? 16 : 1];
+    if constexpr (PLMS) {
       const unsigned hb = (unsigned)M * T * 4;
       const rsrc_t rs_h1 = mk_rsrc(a.h1 + (long long)b * M * T, hb);
       const rsrc_t rs_h2 = mk_rsrc(a.plms_hist > 1 ? a.h2 + (long long)b * M * T : a.x, a.plms_hist > 1 ? hb : 0u);
@@ -1049,13 +1049,13 @@ __global__ __launch_bounds__(512, 4) void step_tail_kernel(TailArgs a) {
     }
     tile_gemm<32>(acc, rs_wo, vfrag, wave * 32 * 1024, ss + lh * 32 + l31);
     const int vst = (lh * 4 * T + col) * 4;
-    const rsrc_t rs_en = mk_rsrc(a.plms_hist ? a.e_new + (long long)b * M * T : a.x, a.plms_hist ? (unsigned)M * T * 4 : 0u);
+    const rsrc_t rs_en = mk_rsrc(PLMS ? a.e_new + (long long)b * M * T : a.x, PLMS ? (unsigned)M * T * 4 : 0u);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * wave + acc_row(r, lh);
       float o = 0.f;
       if (m < M) {
-        if (a.plms_hist) {
+        if constexpr (PLMS) {
           o = plms_update(xv[r], acc[r], h1v[r], h2v[r], h3v[r], a.plms_hist, a.pk, nullptr);
           if (col_ok) stf(acc[r], rs_en, vst, (32 * wave + acc_row0(r)) * rowT);
         } else {
@@ -1729,8 +1729,10 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
   static bool tail_attr = false;
   const size_t tail_lds = (size_t)(C * 32 + 96 * 32) * sizeof(float);
   if (!tail_attr) {
-    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<80, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
     tail_attr = true;
   }
   a.skip = h->skip; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h : nullptr;
@@ -1738,8 +1740,13 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
   a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
   a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32);
   const dim3 grid(B * a.tiles_per_row), block(512);
-  if (h->MP == 80) hipLaunchKernelGGL(step_tail_kernel<80>, grid, block, tail_lds, st, a);
-  else hipLaunchKernelGGL(step_tail_kernel<96>, grid, block, tail_lds, st, a);
+  if (a.plms_hist) {
+    if (h->MP == 80) hipLaunchKernelGGL((step_tail_kernel<80, true>), grid, block, tail_lds, st, a);
+    else hipLaunchKernelGGL((step_tail_kernel<96, true>), grid, block, tail_lds, st, a);
+  } else {
+    if (h->MP == 80) hipLaunchKernelGGL((step_tail_kernel<80, false>), grid, block, tail_lds, st, a);
+    else hipLaunchKernelGGL((step_tail_kernel<96, false>), grid, block, tail_lds, st, a);
+  }
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
