@@ -223,6 +223,13 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
       xs[idx] = ok ? v : 0.f;
     }
   }
+  // Winograd form (registers to spare below its 128-VGPR budget): the residual input x of this wave's rows — the initial
+  // accumulator of GEMM2 — is requested together with the staging loads, while the tile's lines are in flight / L2-hot, instead
+  // of after the gate (≈50 us later, when they have left L2 and cost 16 MB of fabric reads per launch a second time)
+  if constexpr (WINO) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
+  }
   __syncthreads();
   BSG_STAMP(1);
 
@@ -346,7 +353,7 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
+    if constexpr (!WINO) acc0[r] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
     acc1[r] = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
   }
   __syncthreads();  // every wave is done reading xs
