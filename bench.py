@@ -206,23 +206,28 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = B_total * T_FRAMES * args.steps / dt
-        frames_per_launch = B_PER_GPU * T_FRAMES
         layers_per_launch = 20 if os.environ.get('BSG_PERSIST', '0') not in ('', '0') else 1
         avg_ms = layer_ms / max(n_layer, 1)
-        achieved = FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch / (avg_ms * 1e-3) / 1e12 if n_layer else None
+        # what one launch of the dominant kernel covers, from the counts: the sampler runs the batch as two concurrent launch
+        # chains over half the rows each (bsg_ddpm_sample, BSG_DUAL), so a launch is B/2 x T frames and two are in flight
+        frame_layers = args.steps * N_DIFF_STEPS * 20 * B_PER_GPU * T_FRAMES
+        frames_per_launch = frame_layers / max(n_layer * layers_per_launch, 1)
+        concurrent = max(1, round(B_PER_GPU * T_FRAMES / frames_per_launch))
+        per_launch = FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch / (avg_ms * 1e-3) / 1e12 if n_layer else None
+        achieved = per_launch * concurrent if n_layer else None
         bf16 = args.dtype == 'bf16'
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_bf16.json' if bf16 else 'traffic.json')
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get('frames_per_launch', 16000) == frames_per_launch:
+            if abs(tj.get('frames_per_launch', 16000) - frames_per_launch) < 1:
                 traffic = tj.get('residual_layer_kernel_hbm_bytes_per_launch')
             if traffic is not None:
                 traffic *= layers_per_launch
         if bf16:
             # 16x the fp32 MFMA rate moves the layer under the HBM roof: AI = 1,048,576 FLOP / 4 KB = 256 FLOP/B against a
             # ridge of 2,500 TFLOP/s / 8 TB/s = 312 FLOP/B (and the measured fabric traffic is 1.4x the algorithmic bytes)
-            ach_gbs = HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch / (avg_ms * 1e-3) / 1e9 if n_layer else None
+            ach_gbs = HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch * concurrent / (avg_ms * 1e-3) / 1e9 if n_layer else None
             roof = {'kernel': 'residual_layer_bf16_kernel (fused DiffNet residual block, bf16 MFMA operands)', 'bound': 'hbm',
                     'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS if ach_gbs else None,
                     'traffic': traffic, 'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
@@ -234,7 +239,11 @@ def main():
                     'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': achieved / PEAK_F32_MFMA_TFLOPS if achieved else None, 'traffic': traffic,
                     'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
-                    'flop_per_launch': FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch}
+                    'flop_per_launch': FLOP_PER_FRAME_LAYER * frames_per_launch * layers_per_launch,
+                    'frames_per_launch': frames_per_launch, 'concurrent_launches': concurrent, 'achieved_per_launch': per_launch,
+                    'executed_tflops': achieved * 0.75 if achieved and os.environ.get('BSG_WINO', '1') != '0' else achieved,
+                    'note': 'achieved = algorithmic FLOPs (direct conv; the Winograd form executes 3/4 of them) of one launch / its '
+                            'average duration (HIP events on its own stream) x launches in flight'}
         cfg_name = 'configs[2]' if bf16 else 'configs[1]'
         rec = {
             'metric': 'mel_frames_per_sec', 'value': value, 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps,

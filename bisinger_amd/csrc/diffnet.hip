@@ -1234,6 +1234,11 @@ struct bsg_diffnet {
   unsigned* split_flags = nullptr;     // [tiles][16] (producer, consumer) flags + status word
   size_t split_cap = 0;                // tiles the scratch is sized for
   unsigned split_epoch = 0;
+  // two half-batches on two streams (bsg_ddpm_sample): rows [row_off, row_off + B_sub) of the bound batch
+  int row_off = 0;                     // row offset the launch helpers add to the handle's buffers
+  bool no_split = false;               // half-batch launches always use the regular one-workgroup-per-tile kernel
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static int dev_alloc(float** p, size_t n) {
@@ -1255,6 +1260,9 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->flags) (void)hipFree(h->flags);
   if (h->clk) (void)hipFree(h->clk);
   if (h->split_flags) (void)hipFree(h->split_flags);
+  if (h->st2) (void)hipStreamDestroy(h->st2);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->apack1h) (void)hipFree(h->apack1h);
   if (h->condterm_h) (void)hipFree(h->condterm_h);
   if (h->skip_h) (void)hipFree(h->skip_h);
@@ -1524,7 +1532,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
                         float* skip, int B, int T, hipStream_t st, unsigned long long* stamps = nullptr) {
   ResArgs a{};
   a.x_in = x_in; a.x_out = x_out; a.skip = skip;
-  a.condterm = h->condterm + (size_t)layer * 2 * C * (size_t)B * T;
+  a.condterm = h->condterm + ((size_t)layer * h->B + h->row_off) * 2 * C * (size_t)T;   // [L][B bound][2C][T], this launch's rows
   a.dproj = h->dproj; a.t_dev = t_dev; a.t_uniform = t_uniform;
   a.apack1 = h->apack1 + (size_t)layer * 2 * C * 3 * C;
   a.apack2 = h->apack2 + (size_t)layer * 2 * C * C;
@@ -1537,7 +1545,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   a.first = layer == 0;
   a.skip_div = layer == h->L - 1 ? sqrtf((float)h->L) : 1.0f;
   a.stamps = stamps;
-  if (h->compute == BSG_COMPUTE_F32 && !stamps && use_wino() && use_split(h, B, T)) {
+  if (h->compute == BSG_COMPUTE_F32 && !stamps && use_wino() && !h->no_split && use_split(h, B, T)) {
     // small launch: a pair of workgroups per tile, each half of the channels (residual_split_kernel)
     SplitArgs s{};
     a.tiles_per_row = cdiv(T, 32);
@@ -1558,9 +1566,9 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   if (h->compute == BSG_COMPUTE_BF16) {
     // the running skip sum lives in h->skip_h (bf16); a caller-supplied fp32 buffer (the unit-test hook) is converted
     // in and out around the launch
-    a.condterm_h = h->condterm_h + (size_t)layer * 2 * C * (size_t)B * T;
-    a.skip_h = h->skip_h;
-    const bool ext = skip != h->skip;
+    a.condterm_h = h->condterm_h + ((size_t)layer * h->B + h->row_off) * 2 * C * (size_t)T;
+    a.skip_h = h->skip_h + (size_t)h->row_off * C * T;
+    const bool ext = skip != h->skip + (size_t)h->row_off * C * T;
     if (ext && !a.first) TRY(f32_to_quad_bf16(skip, h->skip_h, B, C, T, st));
     TRY(launch_residual_layer_bf16(a, st));
     if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
@@ -1701,20 +1709,21 @@ static int check_schedule(const bsg_schedule* s, const char* who, bool plms) {
 
 // the 20 residual layers of one evaluation, input h->xa (the in-projection of x), output = the skip sum in h->skip(_h)
 static int layers_from_xa(bsg_diffnet* h, int t_uniform, int B, int T, hipStream_t st) {
-  float* cur = h->xa;
-  float* nxt = h->xb;
+  const size_t off = (size_t)h->row_off * C * T;
+  float* cur = h->xa + off;
+  float* nxt = h->xb + off;
   const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
   if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   // the persistent launch zeroes its hand-off flags with a memset before every launch; inside a stream capture that pair did
   // not replay correctly (measured), so a capturing stream gets the per-layer launches
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
-  const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32 && cap == hipStreamCaptureStatusNone;
+  const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32 && cap == hipStreamCaptureStatusNone && !h->no_split;
   if (persist) {
     TRY(launch_layers_persistent(h, nullptr, t_uniform, B, T, st));
   } else {
     for (int l = 0; l < h->L; ++l) {
-      TRY(launch_layer(h, l, cur, nullptr, t_uniform, nxt, h->skip, B, T, st));
+      TRY(launch_layer(h, l, cur, nullptr, t_uniform, nxt, h->skip + off, B, T, st));
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
   }
@@ -1742,8 +1751,9 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
     BSG_HIP(hipFuncSetAttribute((const void*)step_tail_kernel<96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds));
     tail_attr = true;
   }
-  a.skip = h->skip; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h : nullptr;
-  a.x = x; a.xa_next = h->xa;
+  const size_t off = (size_t)h->row_off * C * T;
+  a.skip = h->skip + off; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h + off : nullptr;
+  a.x = x; a.xa_next = h->xa + off;
   a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
   a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32);
   const dim3 grid(B * a.tiles_per_row), block(512);
@@ -1788,19 +1798,58 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   }
   // fused loop: [in-projection once] -> per step: 20 residual layers -> step_tail_kernel (skip projection, output
   // projection, sampler update, next step's in-projection)
-  if (n_steps > 0) TRY(conv1x1(h->w_in, h->b_in, x, h->xa, C, h->M, B, T, ACT_RELU, st));
-  for (int k = 0; k < n_steps; ++k) {
-    const int i = t_start - k;
-    TRY(layers_from_xa(h, i, B, T, st));
-    TailArgs a{};
-    a.noise = noise ? noise + (long long)k * n : nullptr;
-    a.k = StepCoef{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
-                   s->posterior_mean_coef2[i], s->sigma[i]};
-    a.seed = seed; a.quad_row0 = (unsigned long long)row0 * h->M * T; a.stream = (unsigned)(i + 1);
-    a.do_head = k + 1 < n_steps;
-    TRY(launch_tail(h, a, x, B, T, st));
+  // Two half-batches on two streams.  One launch per layer puts all workgroups of the chip in the same phase (they stage, hit
+  // the gate and drain together, and the younger of the two workgroups of a CU finishes alone); two independent launch chains
+  // drift apart and fill each other's gaps: measured 239.6 -> 226.5 ms per 100 steps at B=16, T=1000 (+5.8 %), +4.0 % at B=32,
+  // +9.9 % at B=12, +1.2 % at B=64, +4 % for the bf16 form at B=64; four chains are worse (a CU only holds two of these
+  // workgroups).  On one of the boxes measured the two chains brought no gain (and no loss).  BSG_DUAL=0 disables.
+  static int dual_env = -1;
+  if (dual_env < 0) { const char* e = getenv("BSG_DUAL"); dual_env = e ? atoi(e) : 1; }
+  const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() &&
+                    (long long)B * cdiv(T, 32) > h->num_cus && n_steps > 0;
+  struct Sub { int off, B; hipStream_t st; } subs[2] = {{0, B, st}, {0, 0, nullptr}};
+  int n_sub = 1;
+  if (dual) {
+    if (!h->st2) {
+      BSG_HIP(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
+      BSG_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      BSG_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    subs[0] = Sub{0, B / 2, st};
+    subs[1] = Sub{B / 2, B - B / 2, h->st2};
+    n_sub = 2;
+    BSG_HIP(hipEventRecord(h->ev_fork, st));
+    BSG_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
   }
-  return BSG_OK;
+  int rc = BSG_OK;
+  h->no_split = dual;
+  for (int u = 0; u < n_sub && rc == BSG_OK; ++u)
+    rc = conv1x1(h->w_in, h->b_in, x + (size_t)subs[u].off * h->M * T, h->xa + (size_t)subs[u].off * C * T, C, h->M, subs[u].B, T, ACT_RELU,
+                 subs[u].st);
+  for (int k = 0; k < n_steps && rc == BSG_OK; ++k) {
+    const int i = t_start - k;
+    for (int u = 0; u < n_sub && rc == BSG_OK; ++u) {
+      h->row_off = subs[u].off;
+      rc = layers_from_xa(h, i, subs[u].B, T, subs[u].st);
+      if (rc != BSG_OK) break;
+      TailArgs a{};
+      a.noise = noise ? noise + (long long)k * n + (long long)subs[u].off * h->M * T : nullptr;
+      a.k = StepCoef{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
+                     s->posterior_mean_coef2[i], s->sigma[i]};
+      a.seed = seed; a.quad_row0 = (unsigned long long)(row0 + subs[u].off) * h->M * T; a.stream = (unsigned)(i + 1);
+      a.do_head = k + 1 < n_steps;
+      rc = launch_tail(h, a, x + (size_t)subs[u].off * h->M * T, subs[u].B, T, subs[u].st);
+    }
+  }
+  h->row_off = 0;
+  h->no_split = false;
+  if (dual) {
+    // join even after an error, so that the caller's stream stays ordered after everything enqueued on the second one
+    hipError_t e1 = hipEventRecord(h->ev_join, h->st2);
+    hipError_t e2 = hipStreamWaitEvent(st, h->ev_join, 0);
+    if (rc == BSG_OK && (e1 != hipSuccess || e2 != hipSuccess)) { set_error("ddpm_sample: stream join failed"); rc = BSG_EHIP; }
+  }
+  return rc;
 }
 
 extern "C" int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode) {

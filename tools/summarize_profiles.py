@@ -51,6 +51,9 @@ for cfg in ('f32', 'bf16'):
         rd = 128 * g('TCC_EA0_RDREQ_128B_sum') + 64 * g('TCC_EA0_RDREQ_64B_sum') + 32 * g('TCC_EA0_RDREQ_32B_sum')
         wr = 64 * g('TCC_EA0_WRREQ_64B_sum') + 32 * (g('TCC_EA0_WRREQ_sum') - g('TCC_EA0_WRREQ_64B_sum'))
         frames = 64000 if cfg == 'bf16' else 16000
+        n_launch = r.get('FETCH_SIZE', r.get('TCC_EA0_RDREQ_sum', {})).get('n')
+        if n_launch:   # one pass = 100 steps x 20 layers; more launches than that = the batch runs as concurrent half-batch chains
+            frames = frames * 2000 // n_launch
         t = {'kernel': dom, 'frames_per_launch': frames, 'fabric_read_bytes': rd, 'fabric_write_bytes': wr,
              'algorithmic_bytes_per_launch': 6 * 256 * 4 * frames,
              'FETCH_SIZE_KB_raw': g('FETCH_SIZE'), 'WRITE_SIZE_KB': g('WRITE_SIZE'),
