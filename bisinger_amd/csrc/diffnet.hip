@@ -1768,6 +1768,47 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
   return BSG_OK;
 }
 
+struct SubBatch { int off, B; hipStream_t st; };
+
+// Two half-batches on two streams.  One launch per layer puts all workgroups of the chip in the same phase (they stage, hit
+// the gate and drain together, and the younger of the two workgroups of a CU finishes alone); two independent launch chains
+// drift apart and fill each other's gaps: measured 239.6 -> 226.5 ms per 100 steps at B=16, T=1000 (+5.8 %), +4.0 % at B=32,
+// +9.9 % at B=12, +1.2 % at B=64, +4 % for the bf16 form at B=64; four chains are worse (a CU only holds two of these
+// workgroups).  On one of the boxes measured the two chains brought no gain (and no loss).  BSG_DUAL=0 disables.
+// Returns the number of sub-batches (1 or 2) and, for 2, forks the second stream off `st`.
+static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&subs)[2]) {
+  static int dual_env = -1;
+  if (dual_env < 0) { const char* e = getenv("BSG_DUAL"); dual_env = e ? atoi(e) : 1; }
+  subs[0] = SubBatch{0, B, st};
+  subs[1] = SubBatch{0, 0, nullptr};
+  const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() && (long long)B * cdiv(T, 32) > h->num_cus;
+  if (!dual) return 1;
+  if (!h->st2) {
+    if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+      return 1;
+  }
+  if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_fork, 0) != hipSuccess) return 1;
+  subs[0] = SubBatch{0, B / 2, st};
+  subs[1] = SubBatch{B / 2, B - B / 2, h->st2};
+  h->no_split = true;
+  return 2;
+}
+
+// joins the second stream back into `st` (also after an error, so that the caller's stream stays ordered after everything
+// that was enqueued on the second one) and restores the handle's launch state
+static int dual_join(bsg_diffnet* h, int n_sub, hipStream_t st, int rc) {
+  h->row_off = 0;
+  h->no_split = false;
+  if (n_sub == 2) {
+    hipError_t e1 = hipEventRecord(h->ev_join, h->st2);
+    hipError_t e2 = hipStreamWaitEvent(st, h->ev_join, 0);
+    if (rc == BSG_OK && (e1 != hipSuccess || e2 != hipSuccess)) { set_error("sampler: stream join failed"); rc = BSG_EHIP; }
+  }
+  return rc;
+}
+
 extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float* noise, uint64_t seed,
                                int32_t t_start, int32_t n_steps, int32_t B, int32_t T, int32_t row0, int32_t B_total,
                                void* stream) {
@@ -1798,31 +1839,10 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   }
   // fused loop: [in-projection once] -> per step: 20 residual layers -> step_tail_kernel (skip projection, output
   // projection, sampler update, next step's in-projection)
-  // Two half-batches on two streams.  One launch per layer puts all workgroups of the chip in the same phase (they stage, hit
-  // the gate and drain together, and the younger of the two workgroups of a CU finishes alone); two independent launch chains
-  // drift apart and fill each other's gaps: measured 239.6 -> 226.5 ms per 100 steps at B=16, T=1000 (+5.8 %), +4.0 % at B=32,
-  // +9.9 % at B=12, +1.2 % at B=64, +4 % for the bf16 form at B=64; four chains are worse (a CU only holds two of these
-  // workgroups).  On one of the boxes measured the two chains brought no gain (and no loss).  BSG_DUAL=0 disables.
-  static int dual_env = -1;
-  if (dual_env < 0) { const char* e = getenv("BSG_DUAL"); dual_env = e ? atoi(e) : 1; }
-  const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() &&
-                    (long long)B * cdiv(T, 32) > h->num_cus && n_steps > 0;
-  struct Sub { int off, B; hipStream_t st; } subs[2] = {{0, B, st}, {0, 0, nullptr}};
-  int n_sub = 1;
-  if (dual) {
-    if (!h->st2) {
-      BSG_HIP(hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking));
-      BSG_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-      BSG_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
-    subs[0] = Sub{0, B / 2, st};
-    subs[1] = Sub{B / 2, B - B / 2, h->st2};
-    n_sub = 2;
-    BSG_HIP(hipEventRecord(h->ev_fork, st));
-    BSG_HIP(hipStreamWaitEvent(h->st2, h->ev_fork, 0));
-  }
+  SubBatch subs[2];
+  const int n_sub = n_steps > 0 ? dual_fork(h, B, T, st, subs) : 1;
+  if (n_sub == 1) subs[0] = SubBatch{0, B, st};
   int rc = BSG_OK;
-  h->no_split = dual;
   for (int u = 0; u < n_sub && rc == BSG_OK; ++u)
     rc = conv1x1(h->w_in, h->b_in, x + (size_t)subs[u].off * h->M * T, h->xa + (size_t)subs[u].off * C * T, C, h->M, subs[u].B, T, ACT_RELU,
                  subs[u].st);
@@ -1841,14 +1861,7 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
       rc = launch_tail(h, a, x + (size_t)subs[u].off * h->M * T, subs[u].B, T, subs[u].st);
     }
   }
-  h->row_off = 0;
-  h->no_split = false;
-  if (dual) {
-    // join even after an error, so that the caller's stream stays ordered after everything enqueued on the second one
-    hipError_t e1 = hipEventRecord(h->ev_join, h->st2);
-    hipError_t e2 = hipStreamWaitEvent(st, h->ev_join, 0);
-    if (rc == BSG_OK && (e1 != hipSuccess || e2 != hipSuccess)) { set_error("ddpm_sample: stream join failed"); rc = BSG_EHIP; }
-  }
+  rc = dual_join(h, n_sub, st, rc);
   return rc;
 }
 
@@ -1981,6 +1994,8 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   float* hist[4] = {h->eps_hist[0], h->eps_hist[1], h->eps_hist[2], h->eps_hist[3]};
   int n_hist = 0;
   const int last = ((K_step - 1) / interval) * interval;
+  SubBatch subs[2];
+  int n_sub = 0, rc = BSG_OK;   // n_sub == 0: the half-batch chains have not been forked yet
   for (int i = last; i >= 0; i -= interval) {
     const int ip = i - interval > 0 ? i - interval : 0;
     PlmsCoef c{};
@@ -1990,14 +2005,21 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     if (n_hist > 0 && fused) {
       // fused iteration: h->xa already holds the in-projection of x (left by the previous iteration); the tail projects the skip
       // sum to eps, stores it to the history slot, applies the multistep update to x and projects the new x for the next one
-      TRY(layers_from_xa(h, i, B, T, st));
-      TailArgs a{};
-      a.plms_hist = n_hist; a.pk = c; a.e_new = e_new; a.h1 = hist[0]; a.h2 = hist[1]; a.h3 = hist[2];
-      if (n_hist == 1) { a.pk.w0 = 3.f; a.pk.inv = 2.f; }
-      else if (n_hist == 2) { a.pk.w0 = 23.f; a.pk.w1 = -16.f; a.pk.w2 = 5.f; a.pk.inv = 12.f; }
-      else { a.pk.w0 = 55.f; a.pk.w1 = -59.f; a.pk.w2 = 37.f; a.pk.w3 = -9.f; a.pk.inv = 24.f; }
-      a.do_head = i - interval >= 0;
-      TRY(launch_tail(h, a, x, B, T, st));
+      if (n_sub == 0) n_sub = dual_fork(h, B, T, st, subs);   // the first fused iteration forks the two half-batch chains
+      for (int u = 0; u < n_sub && rc == BSG_OK; ++u) {
+        const size_t mo = (size_t)subs[u].off * h->M * T;
+        h->row_off = subs[u].off;
+        rc = layers_from_xa(h, i, subs[u].B, T, subs[u].st);
+        if (rc != BSG_OK) break;
+        TailArgs a{};
+        a.plms_hist = n_hist; a.pk = c; a.e_new = e_new + mo; a.h1 = hist[0] + mo; a.h2 = hist[1] + mo; a.h3 = hist[2] + mo;
+        if (n_hist == 1) { a.pk.w0 = 3.f; a.pk.inv = 2.f; }
+        else if (n_hist == 2) { a.pk.w0 = 23.f; a.pk.w1 = -16.f; a.pk.w2 = 5.f; a.pk.inv = 12.f; }
+        else { a.pk.w0 = 55.f; a.pk.w1 = -59.f; a.pk.w2 = 37.f; a.pk.w3 = -9.f; a.pk.inv = 24.f; }
+        a.do_head = i - interval >= 0;
+        rc = launch_tail(h, a, x + mo, subs[u].B, T, subs[u].st);
+      }
+      if (rc != BSG_OK) break;
       hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = e_new;
       if (n_hist < 3) ++n_hist;
       continue;
@@ -2029,5 +2051,5 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = e_new;
     if (n_hist < 3) ++n_hist;
   }
-  return BSG_OK;
+  return dual_join(h, n_sub, st, rc);
 }
