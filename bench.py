@@ -9,7 +9,8 @@ A "step" = one pass of the hot path over one batch of synthetic utterances alrea
 GaussianDiffusion.forward(infer=True) = FastSpeech2-MIDI encoder+decoder, 100 DDPM ancestral sampler
 steps of the 20-layer DiffNet (on-device Philox noise), de-normalisation — and, for N > 1, the RCCL
 all-gather of the generated mels.  Workload at N = 1: BASELINE.json configs[1] (B=16, T=1000, 80 mel,
-fp32).  Weak scaling: every rank generates 16 utterances of the 16*N batch.
+fp32).  Weak scaling: every rank generates 16 utterances of the 16*N batch.  Inside a rank the sampler runs
+the batch as two concurrent launch chains over half the rows each (two HIP streams, BSG_DUAL=0 disables).
 
 The JSON line also carries
   roofline     : the dominant kernel (fused residual layer), timed live with HIP events on the launch
@@ -232,7 +233,10 @@ def main():
                     'achieved': ach_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': ach_gbs / PEAK_HBM_GBS if ach_gbs else None,
                     'traffic': traffic, 'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer,
                     'bytes_per_launch': HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch,
-                    'mfma_tflops': achieved, 'mfma_frac_of_bf16_peak': achieved / 2516.0 if achieved else None}
+                    'mfma_tflops': achieved, 'mfma_frac_of_bf16_peak': achieved / 2516.0 if achieved else None,
+                    'frames_per_launch': frames_per_launch, 'concurrent_launches': concurrent,
+                    'note': 'achieved = algorithmic bytes of one launch / its average duration (HIP events on its own stream) x '
+                            'launches in flight'}
         else:
             roof = {'kernel': ('persistent_layers_kernel (20 fused DiffNet residual blocks per launch)' if layers_per_launch > 1
                                else 'residual_layer_kernel<false,true> (fused DiffNet residual block, Winograd GEMM1)'), 'bound': 'mfma',
