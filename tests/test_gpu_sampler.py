@@ -178,10 +178,12 @@ print(json.dumps({'hashes': hs, 'timeouts': m.denoise_fn.handoff_timeouts(), 'fi
     assert res['0']['hashes'][0] == res['1']['hashes'][0]
 
 
-def test_sampler_loop_is_graph_capturable(model):
+@pytest.mark.parametrize('B,T,n', [(2, 96, 12), (10, 900, 4)])
+def test_sampler_loop_is_graph_capturable(model, B, T, n):
     """The whole K-step loop is enqueued by one ABI call without host synchronisation (coefficients and Philox keys are
-    kernel arguments), so a caller can capture it into a hipGraph and replay it: same bits as the eager call."""
-    B, T, n = 2, 96, 12
+    kernel arguments), so a caller can capture it into a hipGraph and replay it: same bits as the eager call.
+    (10, 900): 290 tiles > 256 CUs, i.e. the two concurrent half-batch chains (a second stream forked and joined with
+    events inside the capture)."""
     rs = np.random.RandomState(17)
     cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
     x0 = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
