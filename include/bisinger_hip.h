@@ -105,7 +105,8 @@ typedef struct {
  * x: [B,M,T] in (x_{t_start+1}) / out.  noise: [n_steps,B,M,T] N(0,1) draws, one per executed step
  * (parity mode), or NULL: draws come from the on-device Philox4x32-10 stream (seed, global row, step)
  * documented in bisinger_amd/synth.py (bench mode).  row0/B_total: global batch row of this shard's
- * row 0 and global batch size, so a sharded run reproduces the unsharded noise.  * For batches with more 32-frame tiles than the device has CUs the loop runs as two concurrent launch chains over half the
+ * row 0 and global batch size, so a sharded run reproduces the unsharded noise.
+ * For batches with more 32-frame tiles than the device has CUs the loop runs as two concurrent launch chains over half the
  * rows each: a handle-owned second stream is forked off `stream` and joined back before the call returns (BSG_DUAL=0
  * disables); results are bit-identical either way. */
 int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float* noise, uint64_t seed,
