@@ -1236,7 +1236,9 @@ struct bsg_diffnet {
   unsigned split_epoch = 0;
   // two half-batches on two streams (bsg_ddpm_sample): rows [row_off, row_off + B_sub) of the bound batch
   int row_off = 0;                     // row offset the launch helpers add to the handle's buffers
-  bool no_split = false;               // half-batch launches always use the regular one-workgroup-per-tile kernel
+  bool no_split = false;               // half-batch launches of a large batch use the regular one-workgroup-per-tile kernel
+  bool split_small_lds = false;        // half-batch launches of a small batch: split kernels without the LDS padding, so that
+                                       // workgroups of the two chains can share a CU
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -1551,15 +1553,18 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     a.tiles_per_row = cdiv(T, 32);
     s.base = a;
     s.apack2w = h->apack2w + (size_t)layer * 2 * C * C;
-    s.zbuf = h->zbuf;
-    s.flags = h->split_flags;
+    // exchange tiles and flags of this launch's rows (two half-batch chains may be in flight at once)
+    const size_t tile0 = (size_t)h->row_off * a.tiles_per_row;
+    s.zbuf = h->zbuf + tile0 * C * 32;
+    s.flags = h->split_flags + tile0 * 16;
     s.status = h->split_flags + 16 * h->split_cap;
     if (++h->split_epoch == 0) h->split_epoch = 1;
     s.epoch = h->split_epoch;
     const int mode = use_split(h, B, T);
+    const size_t slds = h->split_small_lds ? (size_t)C * 48 * sizeof(float) : kSplitLds;
     if (mode == 2) hipLaunchKernelGGL((residual_split_kernel<true, 1>), dim3(B * a.tiles_per_row), dim3(1024), (size_t)C * 48 * sizeof(float), st, s);
-    else if (mode == 4) hipLaunchKernelGGL((residual_split_kernel<false, 4>), dim3(4 * B * a.tiles_per_row), dim3(256), kSplitLds, st, s);
-    else hipLaunchKernelGGL((residual_split_kernel<false, 2>), dim3(2 * B * a.tiles_per_row), dim3(512), kSplitLds, st, s);
+    else if (mode == 4) hipLaunchKernelGGL((residual_split_kernel<false, 4>), dim3(4 * B * a.tiles_per_row), dim3(256), slds, st, s);
+    else hipLaunchKernelGGL((residual_split_kernel<false, 2>), dim3(2 * B * a.tiles_per_row), dim3(512), slds, st, s);
     BSG_LAUNCH_CHECK();
     return BSG_OK;
   }
@@ -1781,7 +1786,13 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
   if (dual_env < 0) { const char* e = getenv("BSG_DUAL"); dual_env = e ? atoi(e) : 1; }
   subs[0] = SubBatch{0, B, st};
   subs[1] = SubBatch{0, 0, nullptr};
-  const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() && (long long)B * cdiv(T, 32) > h->num_cus;
+  const long long tiles = (long long)B * cdiv(T, 32);
+  const bool big = tiles > h->num_cus;
+  // 129..256 tiles (B = 5..8): two chains of channel-split launches (each workgroup half the matrix work, two per CU, one of each
+  // chain) instead of one chain of 16-wave workgroups
+  // (measured per 100 steps at T=1000: B=5 130.5 -> 105.9 ms, B=6 133.5 -> 120.4, B=8 135.9 -> 133.8; BSG_DUAL=2: big batches only)
+  const bool small = dual_env != 2 && !big && 2 * tiles > h->num_cus && h->compute == BSG_COMPUTE_F32;
+  const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() && (big || small);
   if (!dual) return 1;
   if (!h->st2) {
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess ||
@@ -1792,7 +1803,8 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
   if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->st2, h->ev_fork, 0) != hipSuccess) return 1;
   subs[0] = SubBatch{0, B / 2, st};
   subs[1] = SubBatch{B / 2, B - B / 2, h->st2};
-  h->no_split = true;
+  h->no_split = big;
+  h->split_small_lds = small;
   return 2;
 }
 
@@ -1801,6 +1813,7 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
 static int dual_join(bsg_diffnet* h, int n_sub, hipStream_t st, int rc) {
   h->row_off = 0;
   h->no_split = false;
+  h->split_small_lds = false;
   if (n_sub == 2) {
     hipError_t e1 = hipEventRecord(h->ev_join, h->st2);
     hipError_t e2 = hipStreamWaitEvent(st, h->ev_join, 0);
