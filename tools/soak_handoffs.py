@@ -13,7 +13,7 @@ import bench  # noqa: E402
 torch.set_grad_enabled(False)
 m = bench.build_model(torch.device('cuda', 0))
 n_rep = int(os.environ.get('SOAK_REPS', 6))
-for B, T in [(1, 1000), (2, 777), (4, 1000), (3, 250), (16, 1000)]:
+for B, T in [(1, 1000), (2, 777), (4, 1000), (3, 250), (6, 1000), (8, 1000), (16, 1000)]:
     cond = torch.randn(B, 256, T, device='cuda')
     x0 = torch.randn(B, 1, 80, T, device='cuda')
     ref = m.sample(cond, x0.clone(), seed=3).clone()
