@@ -1791,7 +1791,8 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
   // 129..256 tiles (B = 5..8): two chains of channel-split launches (each workgroup half the matrix work, two per CU, one of each
   // chain) instead of one chain of 16-wave workgroups
   // (measured per 100 steps at T=1000: B=5 130.5 -> 105.9 ms, B=6 133.5 -> 120.4, B=8 135.9 -> 133.8; BSG_DUAL=2: big batches only)
-  const bool small = dual_env != 2 && !big && 2 * tiles > h->num_cus && h->compute == BSG_COMPUTE_F32;
+  // 65..128 tiles (B = 3, 4): two chains of 4-way split launches: B=3 89.0 -> 83.8 ms, B=4 93.3 -> 90.6
+  const bool small = dual_env != 2 && !big && 4 * tiles > h->num_cus && h->compute == BSG_COMPUTE_F32;
   const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() && (big || small);
   if (!dual) return 1;
   if (!h->st2) {
