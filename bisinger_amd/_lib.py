@@ -73,6 +73,10 @@ _SIGS = {
     'bsg_diffnet_status': (c_int32, [c_void_p, POINTER(c_int32)]),
     'bsg_diffnet_set_compute': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_status_async': (c_int32, [c_void_p, c_void_p, c_void_p]),
+    'bsg_diffnet_handoff_take': (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
+    'bsg_diffnet_uses_handoffs': (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32)]),
+    'bsg_diffnet_set_split': (c_int32, [c_void_p, c_int32]),
+    'bsg_diffnet_debug_inject_giveup': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_profile': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_profile_read': (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'bsg_fs2midi_n_weights': (c_int32, [POINTER(Fs2Cfg)]),

@@ -82,15 +82,16 @@ class FFT(FFTBlocks):
         B, H, T = cond.shape
         with torch.cuda.device(cond.device):
             _lib.check(_lib.load().bsg_fftden_prepare(h, _lib.ptr(cond), B, T, _lib.stream_ptr()), 'bsg_fftden_prepare')
-        self._bound = (cond.data_ptr(), cond._version, B, T)
+        self._bound = (cond, cond._version, B, T)      # strong reference (see DiffNet._ensure_bound)
         return B, T
 
     def _ensure_bound(self, cond):
-        key = (cond.data_ptr(), cond._version, cond.shape[0], cond.shape[2])
-        if self._h is None or self._key() != self._h_key or self._bound != key or not cond.is_contiguous():
+        b = self._bound
+        if (self._h is None or self._key() != self._h_key or b is None or b[0] is not cond or b[1] != cond._version
+                or not cond.is_contiguous() or cond.dtype != torch.float32):
             self.prepare(cond)
             if cond.is_contiguous() and cond.dtype == torch.float32:
-                self._bound = key
+                self._bound = (cond, cond._version, cond.shape[0], cond.shape[2])
 
     @torch.no_grad()
     def forward(self, spec, diffusion_step, cond, padding_mask=None, attn_mask=None, return_hiddens=False):

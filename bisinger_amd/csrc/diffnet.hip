@@ -423,6 +423,7 @@ struct SplitArgs {
   unsigned* flags;        // [tiles][parts][parts]: (producer, consumer)
   unsigned* status;       // += 1 for a poll that gave up
   unsigned epoch;         // launch counter (never 0): the value a flag takes in this launch
+  int inject;             // fault injection (bsg_diffnet_debug_inject_giveup): consumers give up at once, without waiting
 };
 
 // out[((mt*(K/16) + q)*64 + lane)*4 + jj] = W(m = 16*mt + (lane&15), k = 16*q + 4*jj + (lane>>4)),  W row-major [M][K]
@@ -633,8 +634,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
 #pragma unroll
     for (int o = 0; o < NPART; ++o) {
       if (o == part) continue;
-      unsigned spins = 0;
-      while (__hip_atomic_load(f + o * NPART + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
+      unsigned spins = s.inject ? (1u << 22) : 0u;   // injected fault: the first failed poll gives up (or none is made at all)
+      if (s.inject) atomicAdd(s.status, 1u);
+      while (!s.inject && __hip_atomic_load(f + o * NPART + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a partner is not resident
           atomicAdd(s.status, 1u);
@@ -1234,6 +1236,11 @@ struct bsg_diffnet {
   unsigned* split_flags = nullptr;     // [tiles][16] (producer, consumer) flags + status word
   size_t split_cap = 0;                // tiles the scratch is sized for
   unsigned split_epoch = 0;
+  bool split_off = false;              // bsg_diffnet_set_split(h, 0): regular launches only (the self-heal path after a give-up)
+  int inject_giveup = 0;               // bsg_diffnet_debug_inject_giveup: split launches left that give up without waiting
+  // residency of the split kernels on this handle's device (workgroups per CU; -1 = not queried yet): pair / 4-way form with the
+  // padded LDS size (one workgroup per CU by construction) and with the plain size (two chains share a CU), 16-wave form
+  int occ2 = -1, occ4 = -1, occw = -1, occ2s = -1, occ4s = -1;
   // two half-batches on two streams (bsg_ddpm_sample): rows [row_off, row_off + B_sub) of the bound batch
   int row_off = 0;                     // row offset the launch helpers add to the handle's buffers
   bool no_split = false;               // half-batch launches of a large batch use the regular one-workgroup-per-tile kernel
@@ -1435,6 +1442,9 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     TRY(dev_alloc(&h->skip, C * bt));
     TRY(dev_alloc(&h->hid, C * bt));
     TRY(dev_alloc(&h->eps, (size_t)h->M * bt));
+    // PLMS history ring + x_pred scratch (5 x [B][M][T]: 2 % of the conditioner term) — here, so that no sampler call allocates
+    for (int i = 0; i < 4; ++i) TRY(dev_alloc(&h->eps_hist[i], (size_t)h->M * bt));
+    TRY(dev_alloc(&h->xpred, (size_t)h->M * bt));
     h->cap_bt = bt;
   }
   h->B = B;
@@ -1506,27 +1516,40 @@ static bool use_wino() {
 // that impossible.
 static constexpr size_t kSplitLds = 84 * 1024;
 
-static int use_split(bsg_diffnet* h, int B, int T) {   // 0: regular launch; 1 / 4: 2 / 4 workgroups per tile; 2: one 16-wave workgroup per tile
-  static int env = -1, occ = -1, occw = -1, occ4 = -1;
+static int split_env() {
+  static int env = -1;
   if (env < 0) { const char* e = getenv("BSG_SPLIT"); env = e ? atoi(e) : 1; }
-  if (!env || !h->num_cus || !h->zbuf) return 0;
+  return env;
+}
+
+static void query_split_occupancy(bsg_diffnet* h) {
+  const int lds = C * 48 * (int)sizeof(float);
+  auto occ_of = [](const void* fn, int threads, size_t bytes) {
+    int o = 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, fn, threads, bytes) != hipSuccess)
+      return 0;
+    return o;
+  };
+  h->occ2 = occ_of((const void*)residual_split_kernel<false, 2>, 512, kSplitLds);
+  h->occ4 = occ_of((const void*)residual_split_kernel<false, 4>, 256, kSplitLds);
+  h->occ2s = occ_of((const void*)residual_split_kernel<false, 2>, 512, (size_t)lds);
+  h->occ4s = occ_of((const void*)residual_split_kernel<false, 4>, 256, (size_t)lds);
+  h->occw = occ_of((const void*)residual_split_kernel<true, 1>, 1024, (size_t)lds);
+}
+
+static int use_split(bsg_diffnet* h, int B, int T) {   // 0: regular launch; 1 / 4: 2 / 4 workgroups per tile; 2: one 16-wave workgroup per tile
+  const int env = split_env();
+  if (!env || h->split_off || !h->num_cus || !h->zbuf) return 0;
   const long long tiles = (long long)B * cdiv(T, 32);
   if ((size_t)tiles > h->split_cap) return 0;
-  const int lds = C * 48 * (int)sizeof(float);
-  if (occ < 0) {
-    if (hipFuncSetAttribute((const void*)residual_split_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)residual_split_kernel<false, 2>, 512, kSplitLds) != hipSuccess)
-      occ = 0;
-    if (hipFuncSetAttribute((const void*)residual_split_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ4, (const void*)residual_split_kernel<false, 4>, 256, kSplitLds) != hipSuccess)
-      occ4 = 0;
-    if (hipFuncSetAttribute((const void*)residual_split_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occw, (const void*)residual_split_kernel<true, 1>, 1024, (size_t)lds) != hipSuccess)
-      occw = 0;
-  }
-  if (4 * tiles <= h->num_cus && env != 2 && occ4 >= 1) return 4;   // BSG_SPLIT=2: no 4-way split (A/B measurements)
-  if (2 * tiles <= h->num_cus) return occ >= 1 ? 1 : 0;
-  if (tiles <= h->num_cus && env != 3) return occw >= 1 ? 2 : 0;   // BSG_SPLIT=3: pair form only (A/B measurements)
+  if (h->occ2 < 0) query_split_occupancy(h);
+  // residency is what makes a hand-off terminate: every workgroup of the launch (and, for two chains sharing CUs, of both
+  // launches: dual_fork checks that sum) must fit the device at the LDS size actually launched
+  const int o4 = h->split_small_lds ? h->occ4s : h->occ4, o2 = h->split_small_lds ? h->occ2s : h->occ2;
+  if (4 * tiles <= h->num_cus && env != 2 && o4 >= 1) return 4;   // BSG_SPLIT=2: no 4-way split (A/B measurements)
+  if (2 * tiles <= h->num_cus) return o2 >= 1 ? 1 : 0;
+  if (tiles <= h->num_cus && env != 3) return h->occw >= 1 ? 2 : 0;   // BSG_SPLIT=3: pair form only (A/B measurements)
   return 0;
 }
 
@@ -1561,6 +1584,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     if (++h->split_epoch == 0) h->split_epoch = 1;
     s.epoch = h->split_epoch;
     const int mode = use_split(h, B, T);
+    if (h->inject_giveup > 0 && mode != 2) { s.inject = 1; --h->inject_giveup; }
     const size_t slds = h->split_small_lds ? (size_t)C * 48 * sizeof(float) : kSplitLds;
     if (mode == 2) hipLaunchKernelGGL((residual_split_kernel<true, 1>), dim3(B * a.tiles_per_row), dim3(1024), (size_t)C * 48 * sizeof(float), st, s);
     else if (mode == 4) hipLaunchKernelGGL((residual_split_kernel<false, 4>), dim3(4 * B * a.tiles_per_row), dim3(256), slds, st, s);
@@ -1792,7 +1816,24 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
   // chain) instead of one chain of 16-wave workgroups
   // (measured per 100 steps at T=1000: B=5 130.5 -> 105.9 ms, B=6 133.5 -> 120.4, B=8 135.9 -> 133.8; BSG_DUAL=2: big batches only)
   // 65..128 tiles (B = 3, 4): two chains of 4-way split launches: B=3 89.0 -> 83.8 ms, B=4 93.3 -> 90.6
-  const bool small = dual_env != 2 && !big && 4 * tiles > h->num_cus && h->compute == BSG_COMPUTE_F32;
+  bool small = dual_env != 2 && !big && 4 * tiles > h->num_cus && h->compute == BSG_COMPUTE_F32 && split_env() && !h->split_off;
+  if (small) {
+    // two chains of split launches share CUs (un-padded LDS): all workgroups of BOTH launches must be resident at once, or a
+    // polling workgroup could wait for a partner that cannot start.  Per half: parts x tiles workgroups of 1024/parts threads.
+    if (h->occ2 < 0) query_split_occupancy(h);
+    double cus = 0.0;   // CUs the workgroups of both launches occupy at the residency the runtime reports for each form
+    bool ok = true;
+    for (int half = 0; half < 2; ++half) {
+      const long long th = (long long)(half ? B - B / 2 : B / 2) * cdiv(T, 32);
+      const int parts = 4 * th <= h->num_cus && split_env() != 2 ? 4 : 2 * th <= h->num_cus ? 2 : 0;
+      int occ = parts == 4 ? h->occ4s : h->occ2s;
+      const int cap = parts == 4 ? 3 : 2;   // 48 KB of LDS each -> 3 per CU; 8 waves of 128 VGPRs -> 2 per CU
+      if (occ > cap) occ = cap;
+      if (!parts || occ < 1) { ok = false; break; }
+      cus += (double)(parts * th) / occ;
+    }
+    small = ok && cus <= (double)h->num_cus;
+  }
   const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() && (big || small);
   if (!dual) return 1;
   if (!h->st2) {
@@ -1910,6 +1951,41 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
   return BSG_OK;
 }
 
+extern "C" int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeouts, void* stream) {
+  BSG_REQUIRE(h && handoff_timeouts, "diffnet_handoff_take: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  *handoff_timeouts = 0;
+  unsigned v[2] = {0, 0};
+  if (h->flags) BSG_HIP(hipMemcpyAsync(&v[0], h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (h->split_flags) BSG_HIP(hipMemcpyAsync(&v[1], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  BSG_HIP(hipStreamSynchronize(st));
+  if (v[0]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap - 1, 0, sizeof(unsigned), st));
+  if (v[1]) BSG_HIP(hipMemsetAsync(h->split_flags + 16 * h->split_cap, 0, sizeof(unsigned), st));
+  *handoff_timeouts = (int32_t)(v[0] + v[1]);
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, int32_t* uses) {
+  BSG_REQUIRE(h && uses && B > 0 && T > 0, "diffnet_uses_handoffs: bad argument");
+  // conservative: any launch shape for which a channel-split (pair / 4-way) or persistent launch may be chosen
+  const long long tiles = (long long)B * cdiv(T, 32);
+  const bool split = h->compute == BSG_COMPUTE_F32 && use_wino() && split_env() && !h->split_off && h->num_cus && tiles <= h->num_cus;
+  *uses = (split || (use_persistent() && h->compute == BSG_COMPUTE_F32)) ? 1 : 0;
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable) {
+  BSG_REQUIRE(h, "diffnet_set_split: null handle");
+  h->split_off = enable == 0;
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches) {
+  BSG_REQUIRE(h && n_launches >= 0, "diffnet_debug_inject_giveup: bad argument");
+  h->inject_giveup = n_launches;
+  return BSG_OK;
+}
+
 extern "C" int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream) {
   BSG_REQUIRE(h && host_counts, "diffnet_status_async: null argument");
   hipStream_t st = (hipStream_t)stream;
@@ -1997,11 +2073,7 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
               "plms_sample: K_step=%d interval=%d schedule=%d", K_step, interval, s->num_timesteps);
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)B * h->M * T;
-  if (!h->xpred) {
-    BSG_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < 4; ++i) TRY(dev_alloc(&h->eps_hist[i], (size_t)h->M * h->cap_bt));
-    TRY(dev_alloc(&h->xpred, (size_t)h->M * h->cap_bt));
-  }
+  BSG_REQUIRE(h->xpred, "plms_sample: history buffers missing (bsg_diffnet_prepare allocates them)");
   const dim3 grid(cdiv((long long)n, 256)), block(256);
   const bool fused = fused_tail_ok(h);
   // history ring: hist[0] = newest

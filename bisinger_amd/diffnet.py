@@ -108,6 +108,8 @@ class DiffNet(nn.Module):
                                               _lib.ptr(table), _lib.stream_ptr()), 'bsg_diffnet_create')
         self._h, self._h_key, self._bound = h, key, None
         self._apply_compute()
+        if getattr(self, 'split_disabled', False):
+            _lib.check(lib.bsg_diffnet_set_split(h, 0), 'bsg_diffnet_set_split')
         return h
 
     _COMPUTE = {'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
@@ -146,15 +148,18 @@ class DiffNet(nn.Module):
         assert H == self.encoder_hidden
         with torch.cuda.device(cond.device):
             _lib.check(_lib.load().bsg_diffnet_prepare(h, _lib.ptr(cond), B, T, _lib.stream_ptr()), 'bsg_diffnet_prepare')
-        self._bound = (cond.data_ptr(), cond._version, B, T)
+        self._bound = (cond, cond._version, B, T)      # strong reference: the allocator cannot hand this address to another tensor
         return B, T
 
     def _ensure_bound(self, cond):
-        key = (cond.data_ptr(), cond._version, cond.shape[0], cond.shape[2])
-        if self._h is None or self._key() != self._h_key or self._bound != key or not cond.is_contiguous():
+        """Skip the hoisted conditioner work only when ``cond`` IS the tensor bound last (same object, not modified since).
+        Keying on the address would be wrong: the caching allocator gives a freed block to the next same-size tensor."""
+        b = self._bound
+        if (self._h is None or self._key() != self._h_key or b is None or b[0] is not cond or b[1] != cond._version
+                or not cond.is_contiguous() or cond.dtype != torch.float32):
             self.prepare(cond)
             if cond.is_contiguous() and cond.dtype == torch.float32:
-                self._bound = key
+                self._bound = (cond, cond._version, cond.shape[0], cond.shape[2])
 
     # ------------------------------------------------------------------ reference call contract
     @torch.no_grad()
@@ -165,10 +170,57 @@ class DiffNet(nn.Module):
         x = spec[:, 0].contiguous().float()
         t = diffusion_step.to(device=x.device, dtype=torch.long).contiguous()
         eps = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.load().bsg_diffnet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(eps), B, T,
-                                                       _lib.stream_ptr()), 'bsg_diffnet_forward')
+
+        def run():
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().bsg_diffnet_forward(self._h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(eps), B, T,
+                                                           _lib.stream_ptr()), 'bsg_diffnet_forward')
+        self.guarded(run, B, T)
         return eps[:, None, :, :]
+
+    # ------------------------------------------------------------------ hand-off health, checked in the SAME call
+    def uses_handoffs(self, B, T):
+        """True when launches of shape (B, T) may hand data between workgroups (channel-split launches of small batches,
+        the opt-in persistent launch).  Large batches never do, and then nothing below synchronises."""
+        from ctypes import c_int32
+        u = c_int32()
+        _lib.check(_lib.load().bsg_diffnet_uses_handoffs(self.handle(), B, T, byref(u)), 'bsg_diffnet_uses_handoffs')
+        return bool(u.value)
+
+    def take_handoff_timeouts(self):
+        """Wait for the current stream; return (and reset) the number of hand-off spins that gave up since the last take."""
+        from ctypes import c_int32
+        n = c_int32()
+        _lib.check(_lib.load().bsg_diffnet_handoff_take(self._h, byref(n), _lib.stream_ptr()), 'bsg_diffnet_handoff_take')
+        return n.value
+
+    def guarded(self, run, B, T, restore=None):
+        """Run ``run()`` (which enqueues evaluations on this handle) so that an invalid result never leaves the call: if a
+        workgroup of a split launch gave up waiting for its partner (a partner not resident: the GPU shared with another
+        process), split launches are switched off for this handle — one workgroup per tile, no hand-offs — and the work is
+        run again (``restore()`` first puts back inputs that run() modified in place).  Costs one stream synchronisation
+        per call, and only for launch shapes that use hand-offs at all; never inside a stream capture."""
+        run()
+        if torch.cuda.is_current_stream_capturing() or not self.uses_handoffs(B, T):
+            return
+        n = self.take_handoff_timeouts()
+        if n == 0:
+            return
+        import warnings
+        warnings.warn(f'bisinger_amd: {n} inter-workgroup hand-offs gave up (a partner workgroup was not resident); '
+                      f'channel-split launches are now off for this DiffNet handle and the evaluation is repeated')
+        _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
+        self.split_disabled = True
+        if restore is not None:
+            restore()
+        run()
+        n = self.take_handoff_timeouts()
+        if n:
+            raise _lib.BsgError(f'{n} inter-workgroup hand-offs gave up with split launches off: the result is invalid')
+
+    def debug_inject_giveup(self, n_launches):
+        """Fault injection (tests): the next ``n_launches`` channel-split launches give up their hand-offs without waiting."""
+        _lib.check(_lib.load().bsg_diffnet_debug_inject_giveup(self.handle(), int(n_launches)), 'bsg_diffnet_debug_inject_giveup')
 
     def profile(self, enable):
         """Record hipEvent pairs around the residual-layer launches of every evaluation (bench.py roofline)."""

@@ -109,6 +109,9 @@ class GaussianDiffusion(nn.Module):
         lib = _lib.load()
         B, _, M, T = x.shape
         assert x.is_contiguous() and x.dtype == torch.float32
+        if hparams.get('pndm_speedup') and (n_steps is not None or noise is not None):
+            raise ValueError('sample(): the PLMS loop (pndm_speedup) is deterministic after x_T and always runs the whole '
+                             'schedule; n_steps / noise only apply to the DDPM loop')
         self.denoise_fn.prepare(cond)
         s, _keep = self._schedule()
         h = self.denoise_fn._h
@@ -128,17 +131,23 @@ class GaussianDiffusion(nn.Module):
                     _lib.check(lib.bsg_ddpm_step(_lib.ptr(x), _lib.ptr(eps.contiguous()), _lib.ptr(nz), byref(s), i, x.numel(), seed,
                                                  row0 * M * T, _lib.stream_ptr()), 'bsg_ddpm_step')
             return x
-        with torch.cuda.device(x.device):
-            if hparams.get('pndm_speedup'):
-                _lib.check(lib.bsg_plms_sample(h, byref(s), _lib.ptr(x), t, int(hparams['pndm_speedup']), B, T,
-                                               _lib.stream_ptr()), 'bsg_plms_sample')
-            else:
-                n = t if n_steps is None else n_steps
-                if noise is not None:
-                    noise = noise.contiguous()
-                    assert tuple(noise.shape) == (n, B, M, T), noise.shape
-                _lib.check(lib.bsg_ddpm_sample(h, byref(s), _lib.ptr(x), _lib.ptr(noise), seed, t - 1, n, B, T, row0,
-                                               B if B_total is None else B_total, _lib.stream_ptr()), 'bsg_ddpm_sample')
+        n = t if n_steps is None else n_steps
+        if noise is not None:
+            noise = noise.contiguous()
+            assert tuple(noise.shape) == (n, B, M, T), noise.shape
+
+        def run():
+            with torch.cuda.device(x.device):
+                if hparams.get('pndm_speedup'):
+                    _lib.check(lib.bsg_plms_sample(h, byref(s), _lib.ptr(x), t, int(hparams['pndm_speedup']), B, T,
+                                                   _lib.stream_ptr()), 'bsg_plms_sample')
+                else:
+                    _lib.check(lib.bsg_ddpm_sample(h, byref(s), _lib.ptr(x), _lib.ptr(noise), seed, t - 1, n, B, T, row0,
+                                                   B if B_total is None else B_total, _lib.stream_ptr()), 'bsg_ddpm_sample')
+        # the loop updates x in place: keep x_T (B*M*T floats, small-batch shapes only) so that the call can repeat itself
+        # without split launches if a hand-off gave up — an invalid x never leaves this function
+        keep = x.clone() if (self.denoise_fn.uses_handoffs(B, T) and not torch.cuda.is_current_stream_capturing()) else None
+        self.denoise_fn.guarded(run, B, T, restore=None if keep is None else (lambda: x.copy_(keep)))
         return x
 
     @torch.no_grad()
@@ -153,9 +162,13 @@ class GaussianDiffusion(nn.Module):
         self.denoise_fn._ensure_bound(cond)
         s, _keep = self._schedule()
         nz = None if noise is None else noise.reshape(1, B, M, T).contiguous()
-        with torch.cuda.device(x.device):
-            _lib.check(lib.bsg_ddpm_sample(self.denoise_fn._h, byref(s), _lib.ptr(x), _lib.ptr(nz), seed, ti, 1, B, T, 0, B,
-                                           _lib.stream_ptr()), 'bsg_ddpm_sample')
+        x_in = x.clone()
+
+        def run():
+            with torch.cuda.device(x.device):
+                _lib.check(lib.bsg_ddpm_sample(self.denoise_fn._h, byref(s), _lib.ptr(x), _lib.ptr(nz), seed, ti, 1, B, T, 0, B,
+                                               _lib.stream_ptr()), 'bsg_ddpm_sample')
+        self.denoise_fn.guarded(run, B, T, restore=lambda: x.copy_(x_in))
         return x
 
     def philox_normal(self, shape, device, seed, stream_id, offset=0):
@@ -209,15 +222,13 @@ class GaussianDiffusion(nn.Module):
                 _lib.check(lib.bsg_mel_start(_lib.ptr(ret['mel_out'].contiguous()), _lib.ptr(smin), _lib.ptr(smax), _lib.ptr(draw0),
                                              float(self.sqrt_alphas_cumprod[t - 1]), float(self.sqrt_one_minus_alphas_cumprod[t - 1]),
                                              _lib.ptr(x), B, M, T, _lib.stream_ptr()), 'bsg_mel_start')
-        x = self.sample(cond, x, noise=steps, seed=seed, row0=row0, B_total=B_total)
+        x = self.sample(cond, x, noise=None if hparams.get('pndm_speedup') else steps, seed=seed, row0=row0, B_total=B_total)
         out = torch.empty(B, T, M, device=cond.device)
         m2p = None if mel2ph is None else mel2ph.to(device=cond.device, dtype=torch.long).contiguous()
         with torch.cuda.device(cond.device):
             _lib.check(lib.bsg_mel_finish(_lib.ptr(x), _lib.ptr(smin), _lib.ptr(smax), _lib.ptr(m2p), _lib.ptr(out), B, M, T,
                                           _lib.stream_ptr()), 'bsg_mel_finish')
         ret['mel_out'] = out
-        if hasattr(self.denoise_fn, 'check_handoffs_async'):
-            self.denoise_fn.check_handoffs_async()
         return ret
 
     def norm_spec(self, x):

@@ -221,13 +221,82 @@ class DiffSingerE2EInfer(BaseSVSInfer):
         wav_out = self.run_vocoder(mel_out, f0=f0_pred)
         return wav_out.cpu().numpy()[0]
 
-    def forward_batch(self, items, seed=None):
-        """Batched generation: list of items -> list of 1-D waveforms trimmed to each utterance's frames.
-        NB (reference quirk kept): ESM attends over the batch axis, so a row's result depends on its batch."""
+    def estimate_frames(self, item):
+        """Frames an item will take, before any model runs (the true count is the duration predictor's): consecutive phonemes
+        that share a note (same pitch and duration entry) count once — a-*.py:468-483 repeats a note's duration for each of
+        its phonemes.  Only used to order and budget buckets; never for shapes."""
+        d = np.asarray(item['midi_dur'], dtype=np.float64)
+        p = np.asarray(item['pitch_midi'])
+        if len(d) == 0:
+            return 0
+        new = np.ones(len(d), dtype=bool)
+        new[1:] = (d[1:] != d[:-1]) | (p[1:] != p[:-1])
+        return int(np.ceil(d[new].sum() * hparams['audio_sample_rate'] / hparams['hop_size']))
+
+    def _generate_wavs(self, items, seed):
+        """One padded batch -> (list of trimmed waveforms, frames per item, padded frame count T)."""
         sample = self.collate(items)
         output = self._generate(sample, seed)
         mel, mel2ph = output['mel_out'], output['mel2ph']
         hop = int(np.prod(self.vocoder.h['upsample_rates']))
-        wav = self.vocoder(mel.transpose(2, 1))[:, 0]
+        if hparams.get('use_nsf'):                                   # the shipped M4Singer set-up: PitchExtractor f0 -> NSF source
+            f0 = self.pe(mel)['f0_denorm_pred'] if hparams.get('pe_enable') else output.get('f0_denorm')
+            assert f0 is not None, 'use_nsf needs an f0: enable pe_enable (a-*.py:629-632)'
+            wav = self.vocoder(mel.transpose(2, 1), f0, seed=int(hparams.get('seed', 1234) if seed is None else seed))[:, 0]
+        else:
+            wav = self.vocoder(mel.transpose(2, 1))[:, 0]
         n_frames = (mel2ph > 0).sum(-1).tolist()
-        return [wav[i, :n * hop].cpu().numpy() for i, n in enumerate(n_frames)]
+        return [wav[i, :n * hop].cpu().numpy() for i, n in enumerate(n_frames)], n_frames, int(mel.shape[1])
+
+    def forward_batch(self, items, seed=None, max_frames=None, max_sentences=None):
+        """Batched generation: list of items -> list of 1-D waveforms (in the order given), each trimmed to its utterance.
+
+        With ``max_frames`` (budget on padded frames per batch: rows x longest row) and/or ``max_sentences`` the items are
+        length-bucketed the way the reference batches its datasets (utils/__init__.py:90-143 batch_by_size over
+        size-ordered indices): sorted by estimated length, packed greedily while (n + 1) x longest <= max_frames and
+        n < max_sentences; each bucket is one padded batch.  Without either, all items form one batch.
+
+        NB (reference quirk kept): ESM attends over the batch axis (common_layers.py:853), so a row's result depends on
+        the rows it is batched with — the unit of reproducibility (and of the oracle in the tests) is the BUCKET.
+        ``self.last_batch_stats`` reports the buckets and the padded-frame waste with and without bucketing."""
+        est = [self.estimate_frames(it) for it in items]
+        if max_frames is None and max_sentences is None:
+            buckets = [list(range(len(items)))]
+        else:
+            buckets = bucket_by_size(est, max_frames, max_sentences)
+        wavs, frames = [None] * len(items), [0] * len(items)
+        padded = 0
+        for b in buckets:
+            w, nf, T = self._generate_wavs([items[i] for i in b], seed)
+            padded += T * len(b)
+            for i, wi, ni in zip(b, w, nf):
+                wavs[i], frames[i] = wi, ni
+        real = int(sum(frames))
+        one = max(frames) * len(items) if items else 0
+        self.last_batch_stats = {
+            'buckets': buckets, 'estimated_frames': est, 'frames': frames, 'real_frames': real, 'padded_frames': padded,
+            'waste': 1.0 - real / max(padded, 1), 'padded_frames_single_batch': one, 'waste_single_batch': 1.0 - real / max(one, 1)}
+        return wavs
+
+
+def bucket_by_size(lengths, max_frames=None, max_sentences=None):
+    """Length bucketing with the semantics of the reference's batch_by_size (utils/__init__.py:90-143) applied to
+    size-sorted indices: walk the items from longest to shortest and close the current bucket when one more row would make
+    rows x longest exceed ``max_frames`` or the row count exceed ``max_sentences``.  Returns lists of indices into
+    ``lengths``; every index appears exactly once.  An item longer than ``max_frames`` raises, as the reference asserts."""
+    max_frames = float('inf') if max_frames is None else max_frames
+    max_sentences = float('inf') if max_sentences is None else max_sentences
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    buckets, cur, longest = [], [], 0
+    for i in order:
+        if lengths[i] > max_frames:
+            raise ValueError(f'item {i} of {lengths[i]} frames exceeds max_frames={max_frames}')
+        new_longest = max(longest, lengths[i])
+        if cur and ((len(cur) + 1) * new_longest > max_frames or len(cur) + 1 > max_sentences):
+            buckets.append(cur)
+            cur, new_longest = [], lengths[i]
+        cur.append(i)
+        longest = new_longest
+    if cur:
+        buckets.append(cur)
+    return buckets

@@ -72,9 +72,11 @@ class HifiGAN(BaseVocoder):
         with torch.no_grad():
             c = torch.as_tensor(np.asarray(mel), dtype=torch.float32).unsqueeze(0).transpose(2, 1).to(self.device)
             f0 = kwargs.get('f0')
-            if f0 is not None and hparams.get('use_nsf'):
-                raise NotImplementedError('NSF-HiFiGAN (use_nsf) is SURVEY.md §8 row f2: not built')
-            y = self.model(c).view(-1)
+            if f0 is not None and hparams.get('use_nsf'):          # vocoders/hifigan.py:60-63
+                f0 = torch.as_tensor(np.asarray(f0), dtype=torch.float32)[None, :].to(self.device)
+                y = self.model(c, f0, seed=int(kwargs.get('seed', hparams.get('seed', 1234)))).view(-1)
+            else:
+                y = self.model(c).view(-1)
         if hparams.get('vocoder_denoise_c', 0.0) > 0:
             raise NotImplementedError('vocoder_denoise_c needs the librosa spectral denoiser (out of scope)')
         return y.cpu().numpy()

@@ -155,6 +155,17 @@ int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
  * on `stream` and returns; the values are valid once the stream has passed that point (e.g. an event recorded after the
  * call).  Lets a caller fail loudly one call later without adding a synchronisation to the path. */
 int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream);
+/* Same-call form (what the Python drop-ins use): waits for `stream`, returns the give-up count accumulated since the last
+ * take and resets it.  bsg_diffnet_uses_handoffs says whether launches of shape (B,T) on this handle may hand data between
+ * workgroups at all (small batches: B*ceil(T/32) <= CUs); when it says 0 no check — and no synchronisation — is needed.
+ * bsg_diffnet_set_split(h, 0) makes the handle use one-workgroup-per-tile launches only (no hand-offs): the caller's
+ * recovery after a non-zero take is set_split(0) + re-running the evaluation, which then cannot give up. */
+int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeouts, void* stream);
+int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, int32_t* uses);
+int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable);
+/* Fault injection for tests: the next n_launches channel-split launches on the handle give up every hand-off without
+ * waiting (counted exactly like a timed-out spin, and their consumers read whatever the exchange tile holds). */
+int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches);
 /* Diagnostic: {s_memtime, s_memrealtime} at the start and end of each workgroup of the LAST persistent launch,
  * out [n_wg][4] uint64 (host).  Shader clock held = d(memtime)/d(memrealtime) x 100 MHz.  Synchronous. */
 int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg);

@@ -64,18 +64,29 @@ def residual_block(sd, p, x, cond, d, dilation, dtype=torch.float32, operand_bf1
 
 
 def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=torch.float32, operand_bf16=False):
-    """spec [B,1,M,T], t [B] int64, cond [B,H,T] -> eps [B,1,M,T]   (net.py:107-130)."""
+    """spec [B,1,M,T], t [B] int64, cond [B,H,T] -> eps [B,1,M,T]   (net.py:107-130).
+    operand_bf16: emulate the build's bf16 configuration end to end — residual_block's operand roundings plus the RUNNING
+    skip sum stored as bf16 after every layer (s_0 = bf16(o_0), s_i = bf16(s_{i-1} + o_i), last layer bf16((s + o)/sqrt(L)));
+    the in/skip/out projections stay fp32, as in the build."""
     g = lambda k: sd[prefix + k].to(dtype)
     spec = spec.to(dtype)
     cond = cond.to(dtype)
     x = spec[:, 0]
     x = F.relu(F.conv1d(x, g('input_projection.weight'), g('input_projection.bias')))
     d = step_embedding(sd, t, x.shape[1], prefix, dtype)
-    skips = []
-    for i in range(n_layers):
-        x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype, operand_bf16)
-        skips.append(s)
-    x = torch.sum(torch.stack(skips), dim=0) / math.sqrt(n_layers)
+    if operand_bf16:
+        run = None
+        for i in range(n_layers):
+            x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype, True)
+            run = s if run is None else run + s
+            run = _bf16(run / math.sqrt(n_layers) if i == n_layers - 1 else run)
+        x = run
+    else:
+        skips = []
+        for i in range(n_layers):
+            x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype)
+            skips.append(s)
+        x = torch.sum(torch.stack(skips), dim=0) / math.sqrt(n_layers)
     x = F.relu(F.conv1d(x, g('skip_projection.weight'), g('skip_projection.bias')))
     x = F.conv1d(x, g('output_projection.weight'), g('output_projection.bias'))
     return x[:, None, :, :]

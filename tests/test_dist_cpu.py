@@ -72,3 +72,22 @@ def test_shard_rows_partition():
             assert all(a.stop == b.start for a, b in zip(sl, sl[1:]))
             sizes = [s.stop - s.start for s in sl]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_starts_its_own_workers_from_a_bare_shell():
+    """`python bench.py --gpus N` without torchrun must start N fresh worker processes itself (the parent touches no GPU),
+    hand them the torchrun environment and print rank 0's record as the LAST stdout line.  Here: the process-management
+    self-test over gloo (no GPU in this container); without --selftest-procs it must refuse cleanly, not hang."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--selftest-procs'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = [l for l in p.stdout.splitlines() if l.strip()][-1]
+    assert json.loads(last) == {'selftest': True, 'n_gpus': 2, 'ranks': [0, 1]}
+    if not torch.cuda.is_available():
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and 'GPUs' in p.stderr

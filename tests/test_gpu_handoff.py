@@ -1,0 +1,144 @@
+"""GPU: a hand-off that gives up never yields a bad tensor (VERDICT r01 item 4 / ADVICE r01), and the bound-condition cache
+cannot be fooled by the allocator.
+
+Small batches run channel-split launches: a tile is computed by 2 or 4 workgroups that exchange their z halves through
+flags (csrc/diffnet.hip residual_split_kernel).  If a partner is not resident the consumer's bounded spin gives up and
+the tile is garbage.  ``bsg_diffnet_debug_inject_giveup`` forces exactly that (consumers skip the wait and count a
+give-up); the drop-ins must notice in the SAME call, switch the handle to one-workgroup-per-tile launches and repeat.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from bisinger_amd import synth
+from bisinger_amd.hparams import hparams
+from tests.util import load_formula_weights, maxabs, use_config
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+T_ = torch.from_numpy
+
+
+class _Enc:
+    def __len__(self):
+        return 65
+
+    def pad(self):
+        return 0
+
+
+def _model():
+    use_config()
+    from bisinger_amd.diffnet import DIFF_DECODERS
+    from bisinger_amd.diffusion import GaussianDiffusion
+    m = GaussianDiffusion(_Enc(), 80, DIFF_DECODERS[hparams['diff_decoder_type']](hparams), timesteps=100, K_step=100,
+                          spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+    load_formula_weights(m, 0, synth.DIFFNET_GAIN)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize('B', [1, 3])      # 4-way split (<= 64 tiles) / pair or two-chain forms
+def test_injected_giveup_self_heals_in_the_same_call(B):
+    T = 320
+    rs = np.random.RandomState(7)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    noise = T_(synth.synth_noise(8, B, 80, T, seed=3)).cuda()
+    x0 = noise[0][:, None].contiguous()
+    t = torch.full((B,), 42, device='cuda', dtype=torch.long)
+
+    good = _model()
+    net = good.denoise_fn
+    assert net.uses_handoffs(B, T)
+    want_eps = net(x0, t, cond).clone()
+    want_x = good.sample(cond, x0.clone(), noise=noise[1:], n_steps=8).clone()
+    assert net.handoff_timeouts() == 0
+
+    # (1) DiffNet.forward: inject into the 20 layer launches of one evaluation
+    m = _model()
+    net = m.denoise_fn
+    net.prepare(cond)
+    net.debug_inject_giveup(20)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = net(x0, t, cond).clone()
+    assert any('hand-offs gave up' in str(x.message) for x in w), 'the give-up went unnoticed'
+    assert torch.equal(got, want_eps), 'a tensor computed from a given-up hand-off left the call'
+    assert getattr(net, 'split_disabled', False) and not net.uses_handoffs(B, T)
+    assert net.handoff_timeouts() == 0                      # the take reset the counter
+
+    # (2) the sampler loop (in place on x): inject mid-way through a fresh handle's loop
+    m = _model()
+    net = m.denoise_fn
+    net.prepare(cond)
+    net.debug_inject_giveup(3)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=8).clone()
+    assert any('hand-offs gave up' in str(x.message) for x in w)
+    assert torch.equal(got, want_x)
+    # and the healed handle keeps producing the same bits without hand-offs
+    again = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=8).clone()
+    assert torch.equal(again, want_x) and net.handoff_timeouts() == 0
+
+
+def test_injection_really_corrupts_without_the_guard():
+    """the fault injection is a real fault: with the check bypassed the result differs (otherwise the test above proves nothing)"""
+    B, T = 1, 320
+    rs = np.random.RandomState(7)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    x = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
+    t = torch.full((B,), 42, device='cuda', dtype=torch.long)
+    m = _model()
+    net = m.denoise_fn
+    want = net(x, t, cond).clone()
+    from bisinger_amd import _lib
+    from ctypes import c_int32, byref
+    net.debug_inject_giveup(20)
+    eps = torch.empty(B, 80, T, device='cuda')
+    xx = x[:, 0].contiguous()
+    _lib.check(_lib.load().bsg_diffnet_forward(net._h, _lib.ptr(xx), _lib.ptr(t), _lib.ptr(eps), B, T, _lib.stream_ptr()), 'fwd')
+    torch.cuda.synchronize()
+    n = c_int32()
+    _lib.check(_lib.load().bsg_diffnet_handoff_take(net._h, byref(n), _lib.stream_ptr()), 'take')
+    assert n.value > 0
+    # consumers that do not wait read a partner's z tile from the previous launch (or half-written): not the right result
+    assert not torch.equal(eps[:, None], want)
+
+
+def test_bound_condition_is_not_keyed_on_the_address():
+    """two different same-shape conds allocated back to back (the caching allocator reuses the freed block): the second call
+    must re-bind, not reuse the first utterance's hoisted conditioner term"""
+    m = _model()
+    net = m.denoise_fn
+    B, T = 2, 96
+    rs = np.random.RandomState(11)
+    x = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
+    t = torch.tensor([5, 60], device='cuda')
+    c1 = rs.standard_normal((B, 256, T)).astype(np.float32)
+    c2 = rs.standard_normal((B, 256, T)).astype(np.float32)
+    a = T_(c1).cuda()
+    p1 = a.data_ptr()
+    e1 = net(x, t, a).clone()
+    del a
+    b = T_(c2).cuda()                      # same size: typically lands at the same address, _version 0 again
+    same_address = b.data_ptr() == p1
+    e2 = net(x, t, b).clone()
+    ref2 = _model().denoise_fn(x, t, T_(c2).cuda()).clone()
+    assert torch.equal(e2, ref2), f'stale conditioner term reused (same address: {same_address})'
+    assert not torch.equal(e1, e2)
+    # the same tensor object, unmodified, IS reused (no second prepare) and modified in place is re-bound
+    bound = net._bound
+    e2b = net(x, t, b).clone()
+    assert net._bound is bound and torch.equal(e2b, e2)
+    b.mul_(0.5)
+    e3 = net(x, t, b).clone()
+    assert not torch.equal(e3, e2)
+    # p_sample goes through the same check
+    c = T_(c1).cuda()
+    y1 = m.p_sample(x, torch.full((B,), 9, device='cuda'), c, noise=torch.zeros_like(x)).clone()
+    del c
+    c = T_(c2).cuda()
+    y2 = m.p_sample(x, torch.full((B,), 9, device='cuda'), c, noise=torch.zeros_like(x)).clone()
+    assert not torch.equal(y1, y2)

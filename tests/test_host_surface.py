@@ -146,3 +146,26 @@ def test_diffnet_compute_dtype_option():
     assert a.compute_dtype == 'bf16'
     with pytest.raises(_lib.BsgError):
         a.set_compute('int8')
+
+
+def test_length_bucketing_matches_reference_batch_by_size():
+    """bucket_by_size == the reference's batch_by_size over size-ordered indices (tests/golden/buckets.json, made by
+    tools/make_golden_cfg.py from utils/__init__.py:90-143); every index exactly once; budget respected"""
+    import json
+    from bisinger_amd.infer import bucket_by_size
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'buckets.json')))
+    assert len(cases) >= 5
+    for c in cases:
+        got = bucket_by_size(c['lengths'], c['max_frames'], c['max_sentences'])
+        assert got == c['batches']
+        assert sorted(i for b in got for i in b) == list(range(len(c['lengths'])))
+        for b in got:
+            if c['max_frames'] is not None:
+                assert len(b) * max(c['lengths'][i] for i in b) <= c['max_frames']
+            if c['max_sentences'] is not None:
+                assert len(b) <= c['max_sentences']
+    import pytest
+    with pytest.raises(ValueError):
+        bucket_by_size([10, 5000], max_frames=4000)
+    assert bucket_by_size([], 100) == []
+    assert bucket_by_size([3, 9, 4]) == [[1, 2, 0]]

@@ -234,3 +234,39 @@ def test_oracle_bf16_operand_emulation_is_a_small_perturbation():
     for u, v in zip(a, f):
         dev = float((u - v).abs().max())
         assert 1e-5 < dev < 3e-2, dev
+
+
+# ---- BASELINE's stated configurations at their stated sizes (tools/make_golden_cfg.py) -------------------------------
+def _cfg_oracle(c, tag, gold, sd_spec, gd_sd):
+    from tests.cfg_fixtures import inputs_and_noise, oracle_state_dict
+    g = gold('cfg')
+    inp, noise = inputs_and_noise(c)
+    assert sha(*[inp[k] for k in sorted(inp)], noise) == str(g[f'{tag}.sha_in'])
+    sd = oracle_state_dict(c, sd_spec, gd_sd['spec_min'], gd_sd['spec_max'])
+    out = omg.mel_gen(sd, tin(inp), T(noise), timesteps=c['timesteps'], K_step=c['K_step'], max_beta=c['max_beta'],
+                      pndm_speedup=c['pndm_speedup'])
+    return float(np.abs(out['mel_out'].numpy() - g[f'{tag}.mel_out']).max())
+
+
+def test_config0_single_utterance_T500(gold, sd_spec, gd_sd):
+    """BASELINE configs[0] / SURVEY §8(d) Config 1: B=1, T_txt=50, T=500, FS2 + 100-step DDPM; oracle vs reference <= 1e-4"""
+    from tests.cfg_fixtures import CFG0
+    assert _cfg_oracle(CFG0, 'cfg0', gold, sd_spec, gd_sd) <= 1e-4
+
+
+def test_shipped_config_plms1000(gold, sd_spec, gd_sd):
+    """the shipped sampler (1000-step schedule to beta 0.02, PLMS interval 5: 201 evaluations); oracle vs reference <= 1e-4"""
+    from tests.cfg_fixtures import SHIPPED
+    assert _cfg_oracle(SHIPPED, 'shipped', gold, sd_spec, gd_sd) <= 1e-4
+
+
+def test_bf16_emulation_of_diffnet_is_close_to_fp32(gd_sd):
+    """oracle.diffnet.diffnet_forward(operand_bf16=True) (what the GPU's bf16 configuration is checked against at full size)
+    stays within bf16 rounding of the fp32 oracle and is not identical to it"""
+    rs = np.random.RandomState(3)
+    x, cond = T(rs.standard_normal((1, 1, 80, 40)).astype(np.float32)), T(rs.standard_normal((1, 256, 40)).astype(np.float32))
+    t = torch.tensor([17])
+    a = odn.diffnet_forward(gd_sd, x, t, cond, 'denoise_fn.')
+    b = odn.diffnet_forward(gd_sd, x, t, cond, 'denoise_fn.', operand_bf16=True)
+    d = float((a - b).abs().max())
+    assert 1e-5 < d < 5e-2
