@@ -1967,6 +1967,11 @@ extern "C" int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeout
 
 extern "C" int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, int32_t* uses) {
   BSG_REQUIRE(h && uses && B > 0 && T > 0, "diffnet_uses_handoffs: bad argument");
+  if (!h->num_cus) {   // normally set by prepare(); asked before any condition was bound
+    int dev = 0;
+    BSG_HIP(hipGetDevice(&dev));
+    BSG_HIP(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
   // conservative: any launch shape for which a channel-split (pair / 4-way) or persistent launch may be chosen
   const long long tiles = (long long)B * cdiv(T, 32);
   const bool split = h->compute == BSG_COMPUTE_F32 && use_wino() && split_env() && !h->split_off && h->num_cus && tiles <= h->num_cus;

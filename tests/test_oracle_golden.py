@@ -270,3 +270,22 @@ def test_bf16_emulation_of_diffnet_is_close_to_fp32(gd_sd):
     b = odn.diffnet_forward(gd_sd, x, t, cond, 'denoise_fn.', operand_bf16=True)
     d = float((a - b).abs().max())
     assert 1e-5 < d < 5e-2
+
+
+def test_bf16_emulation_noise_floor(gd_sd):
+    """How closely can ANY two correct implementations of the bf16 configuration agree?  The same emulation with fp64 instead
+    of fp32 accumulation (identical roundings, only the summation precision differs) lands as far from the fp32-accumulating
+    emulation as that one is from the fp32 oracle: a 1e-7 difference flips a bf16 operand by one ulp (0.4 %) now and then, and
+    20 layers carry every flip forward.  This is the floor tests/test_gpu_configs.py::test_config2_* holds the HIP path to
+    (measured there: HIP vs emulation rms 7.1e-4, max 4.1e-3; here fp64 vs fp32 emulation rms ~7e-4, max ~3.6e-3)."""
+    rs = np.random.RandomState(4)
+    B, Tn = 2, 200
+    x, cond = T(rs.standard_normal((B, 1, 80, Tn)).astype(np.float32)), T(rs.standard_normal((B, 256, Tn)).astype(np.float32))
+    t = T(rs.randint(0, 100, size=(B,)).astype(np.int64))
+    f32 = odn.diffnet_forward(gd_sd, x, t, cond, 'denoise_fn.')
+    e32 = odn.diffnet_forward(gd_sd, x, t, cond, 'denoise_fn.', operand_bf16=True)
+    e64 = odn.diffnet_forward(gd_sd, x, t, cond, 'denoise_fn.', operand_bf16=True, dtype=torch.float64).float()
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt())
+    cost, floor = rms(e32, f32), rms(e64, e32)
+    assert 2e-4 < cost < 3e-3
+    assert 0.3 * cost < floor < 1.5 * cost
