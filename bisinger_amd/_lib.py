@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
 if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
     LIB_PATH = os.environ['BSG_LIB']
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class BsgError(RuntimeError):
@@ -69,7 +69,8 @@ _SIGS = {
     'bsg_philox_normal': (c_int32, [c_void_p, c_int64, c_uint64, c_uint32, c_uint64, c_void_p]),
     'bsg_mel_start': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_mel_finish': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    'bsg_diffnet_persist_clocks': (c_int32, [c_void_p, c_void_p, c_int32]),
+    'bsg_diffnet_last_path': (c_char_p, [c_void_p]),
+    'bsg_diffnet_debug_stack_stamps': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'bsg_diffnet_status': (c_int32, [c_void_p, POINTER(c_int32)]),
     'bsg_diffnet_set_compute': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_status_async': (c_int32, [c_void_p, c_void_p, c_void_p]),

@@ -130,14 +130,19 @@ __device__ __forceinline__ void mfma_pipe(f32x16& acc0, f32x16& acc1, f32x4 (&A0
   }
 }
 
+// byte offset of group g's weights inside a row tile of the packed Winograd matrix [comp][32 tiles][16 q][64 lanes][4]
+__device__ __forceinline__ int wino_so(int g) {
+  g = g < 63 ? g : 63;
+  return ((g >> 4) * 512 + (g & 15)) * 1024;
+}
+
 // One workgroup = 8 waves = one 32-frame tile of one utterance; wave w owns gate rows [32w,32w+32) and filter
 // rows [256+32w, ...) in GEMM1 and residual rows [32w, ...) + skip rows [256+32w, ...) in GEMM2.
 // Both GEMM loops are software-pipelined by hand: A fragments (global, L2) are requested a full 8-MFMA group
 // before use and B fragments (LDS) one group before use; sched_barrier pins that order (left alone, hipcc
 // sinks the prefetch loads next to their consumers, which exposes the L2 latency on every trip).
-template <bool STAMP, bool WT, int NS, bool WINO>   // WT: x_out is stored write-through (sc1) for the in-launch hand-off of the
-                                         // persistent kernel; NS: depth of the A-fragment ring of GEMM2 (and of GEMM1 when
-                                         // !WINO); WINO: GEMM1 as Winograd F(2,3) over the dilated taps (2/3 of the MFMA work)
+template <bool STAMP, int NS, bool WINO>   // NS: depth of the A-fragment ring of GEMM2 (and of GEMM1 when !WINO); WINO: GEMM1 as
+                                         // Winograd F(2,3) over the dilated taps (2/3 of the MFMA work)
 __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_id) {
   constexpr int NT = 32;               // frames per workgroup
   constexpr int LDX = NT + 2 * HALO;   // xs row stride (48 floats = 12 x 16 B)
@@ -294,7 +299,9 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
     };
     BSG_STAMP(2);
     f32x4 Bw[2];
+    {
     Bw[0] = ldbw(0);
+
 #pragma unroll 1
     for (int g = 0; g < 64; g += 2) {
 #pragma unroll
@@ -324,6 +331,7 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
           M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
+    }
     }
     BSG_STAMP(3);
     // ---- (4w) + hoisted conditioner term, gate ----------------------------------------------------
@@ -384,8 +392,7 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int so = (32 * wave + acc_row0(r)) * rowT;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc0[r] / 1.41421356237309504880f), rs_xo, vst, so,
-                                            WT ? 16 : 0);                          // (x + residual) / sqrt(2), net.py:78
+      stf(acc0[r] / 1.41421356237309504880f, rs_xo, vst, so);                      // (x + residual) / sqrt(2), net.py:78
       stf(((a.first ? 0.f : prevs[r]) + acc1[r]) / a.skip_div, rs_sk, vst, so);    // running skip sum (/ sqrt(L) last, :126)
     }
   }
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(512, WINO ? 4 : 6) void residual_layer_kernel(ResAr
   const int n_tiles = a.B * a.tiles_per_row, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (tile_id >= n_tiles) return;
-  residual_tile<STAMP, false, 2, WINO>(a, tile_id);
+  residual_tile<STAMP, 2, WINO>(a, tile_id);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(512, WINO ? 4 : 6) void residual_layer_kernel(ResAr
 //   part p: gate rows [128p, 128p+128) + filter rows [256+128p, ...)  ->  z channels [128p, 128p+128)   (Winograd GEMM1)
 //   exchange: each part stores its z half to a global scratch tile write-through (sc1), every wave drains (vmcnt(0)),
 //             barrier, one relaxed agent-scope flag store (value = launch epoch); one lane polls the partner's flag (bounded),
-//             ONE agent-scope acquire, barrier, plain loads of the partner half   (same protocol as the persistent launch)
+//             ONE agent-scope acquire, barrier, plain loads of the partner half   (same protocol as the stack launch)
 //   part p: residual rows [128p, ...) + skip rows [256+128p, ...) of GEMM2 over all 256 z channels
 // Wave w owns ONE 16-row tile (gate/filter, then residual/skip): 16x16x4 MFMAs throughout.  The host only takes this
 // path when every workgroup of the launch is resident (2 * tiles <= 2 per CU), so the partner is always running.
@@ -715,89 +722,362 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
 }
 
 // ------------------------------------------------------------------------------------------------
-// All L residual layers of one DiffNet evaluation in ONE launch.  Workgroup w owns tiles w, w+G, ... and walks the
-// layers in order; layer l of tile j needs layer l-1 of tiles j-1, j, j+1 (the dilation halo is <= 8 frames < 32),
-// so the only inter-workgroup traffic is the x tile of the two neighbours:
-//   producer: x_out stored write-through (sc1) -> every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed agent-scope
-//             flag store per (layer, tile);
-//   consumer: one lane polls the two neighbour flags (relaxed, s_sleep, bounded) -> ONE agent-scope acquire ->
-//             s_waitcnt vmcnt(0) -> barrier -> plain loads            (cdna_hip_programming.md Guideline 16, valid form).
-// Dependencies only point to the previous layer, so any set of co-resident workgroups makes progress; the host sizes
-// the grid to <= 2 workgroups per CU (3 fit) so every workgroup is resident.  The flags are zeroed by a memset node
-// before every launch.  Why: with one launch per layer all 512 workgroups stage their tile at the same moment (no
-// MFMA work for ~6 us) and the younger of the two co-resident workgroups finishes ~20 us after the older one; here
-// the phases of neighbouring workgroups drift apart and the load / epilogue phases hide under the other's MFMAs.
+// All L residual layers of one DiffNet evaluation in ONE launch, with the residual stream ON CHIP (residual_stack_kernel).
+// Workgroup = one 32-frame tile of one utterance for the whole stack:
+//   * x lives in LDS (xs = x + d_l, the B operand of GEMM1) and in registers (the lane's 16 accumulator positions, the
+//     initial value of GEMM2's residual rows); it is read from HBM once (layer 0) and never written back;
+//   * the running skip sum lives in 16 registers and is stored once, after the last layer;
+//   * per layer the only inter-workgroup traffic is the 8-frame edge of the new x that each of the two neighbour tiles
+//     needs as its halo (dilation <= 8 < 32): 2 x 8 KB per tile, published write-through (sc1) into a double-buffered (layer
+//     parity) exchange array; flag[tile] = base + number of layers published.  Protocol (cdna_hip_programming.md Guideline 16,
+//     valid form, as the split launch): producer: sc1 stores -> every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed
+//     agent-scope flag store; consumer: one lane polls the two neighbour flags (relaxed, s_sleep, bounded) -> ONE agent-scope
+//     acquire -> s_waitcnt vmcnt(0) -> barrier -> plain loads.  Double buffering is enough: a tile can only publish layer l+2
+//     after its neighbours published l+1, which they do after reading its l.
+//   * the hoisted conditioner term of the NEXT layer (the largest HBM stream, 64 KB per tile and layer, independent of
+//     everything) is requested straight into the GEMM1 accumulators while the workgroup waits for its neighbours, so the gate
+//     phase no longer waits for memory; GEMM2 is split into its residual half (-> new x -> publish) and its skip half, which
+//     runs while the published edges drain.
+// HBM bytes per frame and layer: 2 KB (conditioner term) + 0.5 KB edges, against 6 KB for the per-layer launch; no launch
+// boundary, no staging phase, no skip read-modify-write between layers.  Arithmetic per output element is the per-layer
+// kernel's, except that the conditioner term is the accumulator's initial value instead of being added after the products.
+// Every workgroup must be resident (neighbours wait for each other): the host launches at most 2 per CU (80 KB of LDS each)
+// and never inside a stream capture; spins are bounded and counted in `status` like the split launch's.
 // ------------------------------------------------------------------------------------------------
-struct PersistArgs {
-  ResArgs base;   // pointers of layer 0
-  float* xa;
-  float* xb;
-  long long ct_stride, a1_stride, a2_stride, aw_stride, bo_stride;   // per-layer strides (elements)
-  int n_tiles, cycle;
-  unsigned* flags;    // [L][n_tiles], zero before the launch
-  unsigned* status;   // [0] += 1 for every spin that gave up
-  unsigned long long* clk;   // optional [grid][4]: s_memtime / s_memrealtime at start and end (diagnostic)
+struct StackArgs {
+  const float* x_in;      // [B][C][T] in-projected x of this launch's rows
+  float* skip;            // [B][C][T] output: skip sum / sqrt(L)
+  const float* condterm;  // layer 0, this launch's rows: [B][2C][T]; + l * ct_stride for layer l
+  const float* dproj;     // [S][L][C]
+  const long long* t_dev; // [B] or null
+  const float* apackw;    // layer 0; + l * aw_stride
+  const float* apack2;    // layer 0; + l * a2_stride
+  const float* bias_out;  // layer 0; + l * 2C
+  long long ct_stride;
+  float* hx;              // [2 parities][n_tiles][2 sides][C][8] edge exchange
+  unsigned* flags;        // [n_tiles]
+  unsigned* status;       // += 1 for every spin that gave up
+  int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
+  unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
+  int inject;             // fault injection: consumers do not wait
+  int stagger;            // 100 MHz ticks the second half of the grid waits before it starts (anti-phase of the two workgroups of a CU)
+  unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
 };
 
-template <bool WINO>
-__global__ __launch_bounds__(512, 4) void persistent_layers_kernel(PersistArgs p) {
-  const int L = p.base.L, n_tiles = p.n_tiles, tpr = p.base.tiles_per_row;
-  if (p.clk && threadIdx.x == 0) {
-    p.clk[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
-    p.clk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-  }
-  // Tile assignment.  Workgroups i and i + G/2 are (in practice) the two that share a CU, and the older one wins the
-  // MFMA arbitration.  If the first G/2 workgroups owned the first G/2 tiles, they would only ever wait for each
-  // other and run up to 25 % ahead, leaving the second half to finish alone at half occupancy.  Interleaving makes
-  // every tile's neighbours belong to the other half, so neither half can get more than one layer ahead.
-  const int G = (int)gridDim.x, half = G >> 1;
-  const int slot = (G & 1) ? (int)blockIdx.x : ((int)blockIdx.x % half) * 2 + (int)blockIdx.x / half;
-  for (int l = 0; l < L; ++l) {
-    ResArgs a = p.base;
-    a.layer = l;
-    a.x_in = (l & 1) ? p.xb : p.xa;
-    a.x_out = (l & 1) ? p.xa : p.xb;
-    a.condterm = p.base.condterm + (long long)l * p.ct_stride;
-    a.apack1 = p.base.apack1 + (long long)l * p.a1_stride;
-    a.apackw = p.base.apackw + (long long)l * p.aw_stride;
-    a.apack2 = p.base.apack2 + (long long)l * p.a2_stride;
-    a.bias_out = p.base.bias_out + (long long)l * p.bo_stride;
-    a.dil = 1 << (l % p.cycle);
-    a.first = l == 0;
-    a.skip_div = l == L - 1 ? sqrtf((float)L) : 1.0f;
-    for (int tile = slot; tile < n_tiles; tile += gridDim.x) {
-      if (l > 0) {
-        if (threadIdx.x == 0) {
-          const int j = tile % tpr;
-          const unsigned* f = p.flags + (long long)(l - 1) * n_tiles;
+// one row tile (32 rows) x 32 columns, K = 8 * (q_end - q_begin): A fragments in a ring of NS groups of 4 k-steps
+template <int NS, typename LDB>
+__device__ __forceinline__ void mfma_pipe1(f32x16& acc, f32x4 (&A)[NS], rsrc_t rs, int vfrag, int sa, int q_begin, int q_end, int q_last,
+                                           LDB ldb) {
+  f32x4 Bf[2];
+  Bf[0] = ldb(q_begin);
+#pragma unroll 1
+  for (int q = q_begin; q < q_end; q += NS) {
 #pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            const int nb = side == 0 ? tile - 1 : tile + 1;
-            if (side == 0 ? j == 0 : j == tpr - 1) continue;
-            unsigned spins = 0;
-            while (__hip_atomic_load(f + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-              __builtin_amdgcn_s_sleep(4);
-              if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
-                atomicAdd(p.status, 1u);
-                break;
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-      }
-      residual_tile<false, true, WINO ? 2 : 4, WINO>(a, tile);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-      __syncthreads();
-      if (threadIdx.x == 0 && l + 1 < L)
-        __hip_atomic_store(p.flags + (long long)l * n_tiles + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int s = 0; s < NS; ++s) {
+      const int qn = q + s + 1 <= q_last ? q + s + 1 : q_last;
+      Bf[(s + 1) & 1] = ldb(qn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][j], Bf[s & 1][j], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int qr = q + s + NS <= q_last ? q + s + NS : q_last;
+      A[s] = ldf4(rs, vfrag, sa + qr * 1024);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (p.clk && threadIdx.x == 0) {
-    p.clk[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-    p.clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+__global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
+  constexpr int NT = 32, LDX = NT + 2 * HALO, LDZ = NT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;             // [C][48]  x + d of the current layer, halo columns included
+  float* zs = lds + C * LDX;   // [C][32]  gated activation (own region: the next layer's xs is written while GEMM2 still reads zs)
+
+  const StackArgs& a = p;
+  // XCD-aware tile order (see residual_layer_kernel): neighbouring tiles exchange their edges through one L2
+  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile_id >= n_tiles) return;
+  // All workgroups start together and run the same program at the same pace, so the two that share a CU would stage, gate
+  // and wait for their neighbours at the same moments — with nobody using the matrix pipe.  The second half of the grid
+  // (dispatched as the second workgroup of every CU; whole rows of other utterances under the tile order above) starts half a
+  // layer late: while one waits, the other multiplies.  Rows keep their own pace afterwards (only tiles of ONE row wait for
+  // each other), so the offset persists.
+  if (p.stagger > 0 && 2 * (int)blockIdx.x >= (int)gridDim.x) {
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t_start) < (long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5, p16 = lane & 15, lq = lane >> 4;
+  const int tpr = a.tiles_per_row, L = a.L, T = a.T;
+  const int b = tile_id / tpr, j = tile_id - b * tpr;
+  const int t0 = j * NT;
+  const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
+  const int col = t0 + l31;
+  const bool col_ok = col < T;
+  const int colc = col_ok ? col : T - 1;
+  const bool has_left = j > 0, has_right = j + 1 < tpr;
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(a.x_in + (long long)b * C * T, plane);
+  const rsrc_t rs_sk = mk_rsrc(a.skip + (long long)b * C * T, plane);
+  const int rowT = T * 4, vfrag = lane * 16;
+  const int vcol = (lh * 4 * T + colc) * 4;
+  const int sw[4] = {(2 * wave) * 16 * 1024, (2 * wave + 1) * 16 * 1024, (16 + 2 * wave) * 16 * 1024, (16 + 2 * wave + 1) * 16 * 1024};
+  const int sb_r = wave * 32 * 1024, sb_s = (8 + wave) * 32 * 1024;
+
+  f32x16 skipacc;         // this lane's 16 positions (rows 32w + acc_row(r, lh), frame col) of the running skip sum
+  f32x4 y0[4], y1[4];     // GEMM1 outputs of the pair (t, t+d): [0..1] gate tiles, [2..3] filter tiles; start from the conditioner term
+
+  // conditioner term of layer l -> y0 / y1 (the accumulators' initial value)
+  auto load_cond = [&](int l, int dil) {
+    const rsrc_t rs_ct = mk_rsrc(a.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+    const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
+    const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
+    const int f0c = t0 + tp < T ? t0 + tp : T - 1, f1c = t0 + tp + dil < T ? t0 + tp + dil : T - 1;
+    const int vc0 = (lq * 4 * T + f0c) * 4, vc1 = (lq * 4 * T + f1c) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so_g = (32 * wave + 16 * i + r) * rowT, so_f = so_g + C * rowT;
+        y0[i][r] = ldf(rs_ct, vc0, so_g);
+        y0[2 + i][r] = ldf(rs_ct, vc0, so_f);
+        y1[i][r] = ldf(rs_ct, vc1, so_g);
+        y1[2 + i][r] = ldf(rs_ct, vc1, so_f);
+      }
+  };
+
+  // ---- layer 0: stage xs = x + d_0 from HBM (halo included: the whole input exists), x into registers ----------------
+  {
+    const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * L + 0) * C, C * 4);
+    if ((T & 3) == 0) {
+#pragma unroll 3
+      for (int k = 0; k < 6; ++k) {
+        const int idx = tid + 512 * k;
+        const int c = idx / 12, j4 = idx - c * 12;
+        const int t = t0 - HALO + 4 * j4;
+        const bool ok = t >= 0 && t < T;
+        f32x4 v = ldf4(rs_x, ok ? (c * T + t) * 4 : 0, 0);
+        const float d = ldf(rs_dp, c * 4, 0);
+        v += d;
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(xs + c * LDX + 4 * j4) = v;
+      }
+    } else {
+#pragma unroll 4
+      for (int idx = tid; idx < C * LDX; idx += 512) {
+        const int c = idx / LDX, jj = idx - c * LDX;
+        const int t = t0 - HALO + jj;
+        const bool ok = t >= 0 && t < T;
+        const float v = ldf(rs_x, ok ? (c * T + t) * 4 : 0, 0) + ldf(rs_dp, c * 4, 0);
+        xs[idx] = ok ? v : 0.f;
+      }
+    }
+    // x of this lane's 16 accumulator positions -> its stash in zs (read back at GEMM2; rows 32w.. belong to wave w alone)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
+    load_cond(0, 1);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) skipacc[r] = 0.f;
+
+#define STK_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int dil = 1 << (l % p.cycle);
+    const rsrc_t rs_aw = mk_rsrc(a.apackw + (long long)l * (4 * 2 * C * C), 4 * 2 * C * C * 4);
+    const rsrc_t rs_a2 = mk_rsrc(a.apack2 + (long long)l * (2 * C * C), 2 * C * C * 4);
+    const rsrc_t rs_bo = mk_rsrc(a.bias_out + (long long)l * (2 * C), 2 * C * 4);
+    f32x4 AW[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) AW[k][i] = ldf4(rs_aw, vfrag, sw[i] + k * 1024);
+    __syncthreads();   // (A) xs of layer l is complete: core columns (own x + d_l) and halo columns
+    STK_STAMP(0);
+
+    // ---- GEMM1 as Winograd F(2,3) over the dilated taps (see residual_tile) ---------------------------
+    const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
+    const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
+    {
+      f32x4 M[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int xo = lq * LDX + HALO + tp;   // element offset of this lane's B operand in xs
+      // raw operands of group g: V_comp = x[.. + oa] + sgn * x[.. + ob]; offsets and sign by arithmetic on the (wave-uniform) component
+      auto raw = [&](int g, f32x4& ra, f32x4& rb, float& sgn) {
+        const int comp = g >> 4, q = g & 15;
+        const int oa = ((comp == 2) - (comp == 0)) * dil;
+        const int ob = ((comp < 2) + 2 * (comp == 3)) * dil;
+        const int base = xo + 16 * q * LDX;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { ra[jj] = xs[base + oa + 4 * jj * LDX]; rb[jj] = xs[base + ob + 4 * jj * LDX]; }
+        sgn = comp == 1 ? 1.0f : -1.0f;
+      };
+      f32x4 Bw[2];
+      {
+        f32x4 ra, rb;
+        float sgn;
+        raw(0, ra, rb, sgn);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Bw[0][jj] = __builtin_fmaf(sgn, rb[jj], ra[jj]);
+      }
+#pragma unroll 1
+      for (int g = 0; g < 64; g += 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int gn = g + s2 + 1 < 64 ? g + s2 + 1 : 63;
+          f32x4 ra, rb;
+          float sgn;
+          raw(gn, ra, rb, sgn);                       // LDS reads of the NEXT group: their latency passes under the MFMAs below
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[s2][i][jj], Bw[s2 & 1][jj], M[i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) Bw[(s2 + 1) & 1][jj] = __builtin_fmaf(sgn, rb[jj], ra[jj]);   // xa +/- xb (one rounding)
+          const int so = wino_so(g + s2 + 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) AW[s2][i] = ldf4(rs_aw, vfrag, sw[i] + so);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((g & 15) == 14) {   // a Winograd component is complete: y(t) = c + M0 + M1 + M2, y(t+d) = c + M1 - M2 - M3
+          const int comp = g >> 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (comp == 0) { y0[i] += M[i]; }
+            else if (comp == 1) { y0[i] += M[i]; y1[i] += M[i]; }
+            else if (comp == 2) { y0[i] += M[i]; y1[i] -= M[i]; }
+            else { y1[i] -= M[i]; }
+            M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    }
+    STK_STAMP(1);
+    // ---- gate: z = sigmoid(gate) * tanh(filter) -> zs (net.py:73-74); first A fragments of GEMM2 fly meanwhile -------
+    f32x4 A2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A2[k] = ldf4(rs_a2, vfrag, sb_r + k * 1024);
+    // x of this lane's 16 positions comes back from its stash in zs (rows 32w.. are written and read by wave w only — the
+    // stash and, below, this wave's z rows — so no barrier is needed around it)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc[r] = zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] + ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);   // x + b_out (residual rows)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 32 * wave + 16 * i + 4 * lq + r;
+        zs[row * LDZ + tp] = fast_sigmoid(y0[i][r]) * fast_tanh(y0[2 + i][r]);
+        zs[row * LDZ + tp + dil] = fast_sigmoid(y1[i][r]) * fast_tanh(y1[2 + i][r]);
+      }
+    __syncthreads();   // (B) zs complete; every wave is done reading xs of this layer
+    STK_STAMP(2);
+
+    const float* zrow = zs + lh * LDZ + l31;
+    auto ldbz = [&](int q) {
+      const float* pz = zrow + 8 * q * LDZ;
+      return f32x4{pz[0], pz[2 * LDZ], pz[4 * LDZ], pz[6 * LDZ]};
+    };
+    // ---- GEMM2, residual half: x_new = (x + b + W_res z) / sqrt(2)   (net.py:75-78) ----------------------------------
+    mfma_pipe1<4>(acc, A2, rs_a2, vfrag, sb_r, 0, 32, 31, ldbz);
+    STK_STAMP(3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A2[k] = ldf4(rs_a2, vfrag, sb_s + k * 1024);
+    f32x16 accs;   // skip rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accs[r] = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
+    const bool more = l + 1 < L;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc[r] / 1.41421356237309504880f;   // x_new: stays in `acc` through the skip half, then goes to the stash
+    if (more) {
+      // next layer's xs core = x_new + d_{l+1} (zero beyond T: the conv pads x + d), and the two 8-frame edges for the neighbours
+      const rsrc_t rs_dn = mk_rsrc(a.dproj + ((long long)tb * L + l + 1) * C, C * 4);
+      float* xcore = xs + (32 * wave + 4 * lh) * LDX + HALO + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        xcore[acc_row0(r) * LDX] = col_ok ? acc[r] + ldf(rs_dn, lh * 16, (32 * wave + acc_row0(r)) * 4) : 0.f;
+      // publish: rows 32w..32w+31 of xs were written by this wave alone, so it reads its two 8-frame edges back (program order
+      // within a wave) as 16-byte pieces: lane = (row, side), 2 x float4 -> 2 write-through (sc1) 16-byte stores
+      float* hx_t = p.hx + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (2 * C * 8);
+      const rsrc_t rs_hx = mk_rsrc(hx_t, 2 * C * 8 * 4);
+      const int erow = 32 * wave + (lane >> 1), eside = lane & 1;
+      const float* ep = xs + erow * LDX + HALO + (eside ? NT - 8 : 0);
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep), e1 = *reinterpret_cast<const f32x4*>(ep + 4);
+      const int vh = ((eside ? C * 8 : 0) + erow * 8) * 4;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e0), rs_hx, vh, 0, 16);        // sc1
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e1), rs_hx, vh + 16, 0, 16);   // sc1
+    }
+    // ---- GEMM2, skip half (covers the drain of the published edges) ----------------------------------------------------
+    mfma_pipe1<4>(accs, A2, rs_a2, vfrag, sb_s, 0, 32, 31, ldbz);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) skipacc[r] = (l == 0 ? 0.f : skipacc[r]) + accs[r];
+    STK_STAMP(4);
+    if (!more) break;
+
+    // ---- hand-off: publish, then wait for the neighbours' edges of the same layer ----------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+    __syncthreads();   // (C) also: every wave is done reading zs
+    STK_STAMP(5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] = acc[r];   // stash x for the next layer's GEMM2
+    load_cond(l + 1, 1 << ((l + 1) % p.cycle));        // 64 KB per tile, independent of the neighbours: lands while we wait
+    if (tid == 0) {
+      const unsigned want = p.fbase + (unsigned)(l + 1);
+      __hip_atomic_store(p.flags + tile_id, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !has_left : !has_right) continue;
+        const unsigned* f = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
+        if (p.inject) { atomicAdd(p.status, 1u); continue; }
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
+            atomicAdd(p.status, 1u);
+            break;
+          }
+        }
+      }
+      if (p.stamps) p.stamps[((long long)tile_id * L + l) * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // neighbours' flags seen
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();   // (D)
+    STK_STAMP(7);
+    {
+      // halo columns of the next layer's xs: left = the left neighbour's right edge, right = the right neighbour's left edge
+      const int side = tid >> 8, row = tid & 255;
+      const bool have = side == 0 ? has_left : has_right;
+      const float* src = p.hx + ((long long)((l + 1) & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (2 * C * 8) +
+                         (side == 0 ? C * 8 : 0) + row * 8;
+      f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (have) {
+        v0 = *reinterpret_cast<const f32x4*>(src);
+        v1 = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+      float* dst = xs + row * LDX + (side == 0 ? 0 : HALO + NT);
+      *reinterpret_cast<f32x4*>(dst) = v0;
+      *reinterpret_cast<f32x4*>(dst + 4) = v1;
+    }
+  }
+#undef STK_STAMP
+  // ---- the skip sum / sqrt(L) (net.py:126), stored once ----------------------------------------------------------------
+  if (col_ok) {
+    const int vst = (lh * 4 * T + col) * 4;
+    const float div = sqrtf((float)L);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stf(skipacc[r] / div, rs_sk, vst, (32 * wave + acc_row0(r)) * rowT);
   }
 }
 
@@ -1224,12 +1504,15 @@ struct bsg_diffnet {
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
-  size_t prof_launches = 0;   // kernel launches covered by the recorded pairs (L per pair, or 1 in persistent mode)
-  // persistent multi-layer launch: hand-off flags [L][tiles] + status word
+  size_t prof_launches = 0;   // layer-equivalents covered by the recorded pairs (L per evaluation)
+  // on-chip stack launch (residual_stack_kernel): edge exchange [2][tiles][2][C][8], flags [tiles] + status word
+  float* hx = nullptr;
   unsigned* flags = nullptr;
-  size_t flags_cap = 0;
+  size_t flags_cap = 0;                // tiles the exchange array and the flags are sized for
+  unsigned stack_epoch = 0;
+  int occ_stack = -1;                  // resident workgroups per CU of residual_stack_kernel (-1: not queried)
   int num_cus = 0;
-  unsigned long long* clk = nullptr;   // [1024][4] diagnostic clock stamps of the last persistent launch
+  const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
   float* apack2w = nullptr;            // [L][2C*C] output projection packed for 16x16x4 MFMAs
   float* zbuf = nullptr;               // [tiles][C][32] z exchange scratch
@@ -1267,7 +1550,7 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   for (float** p : all) dev_free(*p);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->flags) (void)hipFree(h->flags);
-  if (h->clk) (void)hipFree(h->clk);
+  if (h->hx) (void)hipFree(h->hx);
   if (h->split_flags) (void)hipFree(h->split_flags);
   if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1450,17 +1733,26 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   h->B = B;
   h->T = T;
   {
-    const size_t need = (size_t)h->L * B * cdiv(T, 32) + 64;
+    if (!h->num_cus) {
+      int dev = 0;
+      BSG_HIP(hipGetDevice(&dev));
+      BSG_HIP(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    // the stack launch handles at most 2 workgroups per CU at a time (larger batches run as groups of rows, one after the other)
+    const size_t all_tiles = (size_t)B * cdiv(T, 32);
+    const size_t need = all_tiles < 2 * (size_t)h->num_cus ? all_tiles : 2 * (size_t)h->num_cus;
     if (need > h->flags_cap) {
       BSG_HIP(hipStreamSynchronize(st));
       if (h->flags) (void)hipFree(h->flags);
+      if (h->hx) (void)hipFree(h->hx);
       h->flags = nullptr;
+      h->hx = nullptr;
       h->flags_cap = 0;
-      BSG_HIP(hipMalloc((void**)&h->flags, need * sizeof(unsigned)));
-      BSG_HIP(hipMemsetAsync(h->flags, 0, need * sizeof(unsigned), st));
+      BSG_HIP(hipMalloc((void**)&h->flags, (need + 4) * sizeof(unsigned)));
+      BSG_HIP(hipMemsetAsync(h->flags, 0, (need + 4) * sizeof(unsigned), st));
+      BSG_HIP(hipMalloc((void**)&h->hx, 2 * need * 2 * C * 8 * sizeof(float)));
       h->flags_cap = need;
     }
-    if (!h->clk) BSG_HIP(hipMalloc((void**)&h->clk, 1024 * 4 * sizeof(unsigned long long)));
     const size_t tiles = (size_t)B * cdiv(T, 32);
     if (tiles > h->split_cap) {
       BSG_HIP(hipStreamSynchronize(st));
@@ -1472,11 +1764,6 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       BSG_HIP(hipMalloc((void**)&h->split_flags, (16 * tiles + 4) * sizeof(unsigned)));
       BSG_HIP(hipMemsetAsync(h->split_flags, 0, (16 * tiles + 4) * sizeof(unsigned), st));
       h->split_cap = tiles;
-    }
-    if (!h->num_cus) {
-      int dev = 0;
-      BSG_HIP(hipGetDevice(&dev));
-      BSG_HIP(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
     }
   }
   if (h->compute == BSG_COMPUTE_BF16 && bt > h->cap_bt_h) {
@@ -1590,6 +1877,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     else if (mode == 4) hipLaunchKernelGGL((residual_split_kernel<false, 4>), dim3(4 * B * a.tiles_per_row), dim3(256), slds, st, s);
     else hipLaunchKernelGGL((residual_split_kernel<false, 2>), dim3(2 * B * a.tiles_per_row), dim3(512), slds, st, s);
     BSG_LAUNCH_CHECK();
+    h->last_path = mode == 2 ? "wide" : mode == 4 ? "split4" : "split2";
     return BSG_OK;
   }
   if (h->compute == BSG_COMPUTE_BF16) {
@@ -1600,6 +1888,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     const bool ext = skip != h->skip + (size_t)h->row_off * C * T;
     if (ext && !a.first) TRY(f32_to_quad_bf16(skip, h->skip_h, B, C, T, st));
     TRY(launch_residual_layer_bf16(a, st));
+    h->last_path = "bf16";
     if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
     return BSG_OK;
   }
@@ -1625,53 +1914,75 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     else hipLaunchKernelGGL((residual_layer_kernel<false, false>), grid, block, lds, st, a);
   }
   BSG_LAUNCH_CHECK();
+  h->last_path = "layer";
   return BSG_OK;
 }
 
-// all L layers in one launch (persistent_layers_kernel); x chain starts in h->xa
-static int launch_layers_persistent(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, hipStream_t st) {
-  PersistArgs p{};
-  ResArgs& a = p.base;
-  a.skip = h->skip; a.condterm = h->condterm; a.dproj = h->dproj; a.t_dev = t_dev; a.t_uniform = t_uniform;
-  a.apack1 = h->apack1; a.apack2 = h->apack2; a.apackw = h->apackw; a.bias_out = h->b_out;
-  a.B = B; a.T = T; a.L = h->L; a.tiles_per_row = cdiv(T, 32); a.stamps = nullptr;
-  p.xa = h->xa; p.xb = h->xb;
-  p.ct_stride = (long long)2 * C * (long long)B * T; p.a1_stride = (long long)2 * C * 3 * C; p.a2_stride = (long long)2 * C * C; p.aw_stride = (long long)4 * 2 * C * C;
-  p.bo_stride = 2 * C;
-  p.n_tiles = B * a.tiles_per_row; p.cycle = h->cfg.dilation_cycle_length;
-  const size_t nflags = (size_t)h->L * p.n_tiles;
-  p.flags = h->flags; p.status = h->flags + h->flags_cap - 1; p.clk = h->clk;
-  BSG_HIP(hipMemsetAsync(h->flags, 0, ((nflags * sizeof(unsigned) + 15) / 16) * 16, st));
-  const size_t lds = (size_t)C * (32 + 2 * HALO) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    BSG_HIP(hipFuncSetAttribute((const void*)persistent_layers_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)persistent_layers_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  // every workgroup must be resident: 2 per CU (the kernel is built for 4 waves/SIMD, 48 KB of LDS each)
-  static int occ = -1;
-  if (occ < 0) {
-    int o0 = 0, o1 = 0;
-    BSG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, (const void*)persistent_layers_kernel<false>, 512, lds));
-    BSG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, (const void*)persistent_layers_kernel<true>, 512, lds));
-    occ = o0 < o1 ? o0 : o1;
-  }
-  BSG_REQUIRE(occ >= 2, "persistent launch needs 2 resident workgroups per CU, the runtime reports %d", occ);
-  const int grid = p.n_tiles < 2 * h->num_cus ? p.n_tiles : 2 * h->num_cus;
-  if (use_wino()) hipLaunchKernelGGL(persistent_layers_kernel<true>, dim3(grid), dim3(512), lds, st, p);
-  else hipLaunchKernelGGL(persistent_layers_kernel<false>, dim3(grid), dim3(512), lds, st, p);
-  BSG_LAUNCH_CHECK();
-  return BSG_OK;
-}
-
-// Opt-in (BSG_PERSIST=1).  Measured in round 1 at B=16, T=1000: bit-identical results, 2.63 ms per 20 layers vs
-// 20 x 136.9 us = 2.74 ms with one launch per layer (+2.4 % end to end, MFMA pipe 85 % busy).  Kept off by default: it
-// needs every workgroup resident (2 per CU on all CUs of the device), which a per-layer launch does not.
-static bool use_persistent() {
+// The on-chip stack launch (residual_stack_kernel): all L layers of `rows` utterances in one launch.  Opt-in (BSG_STACK=1; 2: also for
+// launches of at most one workgroup per CU): measured 121 us per layer at B=16, T=1000 against 108.6 us for two chains of per-layer
+// launches (DESIGN.md section 9 has the phase timeline and what would have to change).
+static int stack_env() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("BSG_PERSIST"); v = e ? atoi(e) : 0; }
-  return v != 0;
+  if (v < 0) { const char* e = getenv("BSG_STACK"); v = e ? atoi(e) : 0; }
+  return v;
+}
+static constexpr size_t kStackLds = (size_t)C * (32 + 2 * HALO + 32) * sizeof(float);   // xs + zs = 80 KB: two workgroups fill a CU's LDS
+
+// rows per launch group (0: the stack launch is not used for this shape).  A tile row is ceil(T/32) workgroups that wait for
+// each other, and every workgroup of a launch must be resident: at most occ x CUs workgroups, whole rows only.  It pays when a
+// launch has more workgroups than CUs (two per CU overlap each other's waits); smaller launches keep the channel-split kernels.
+static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
+  if (!stack_env() || h->compute != BSG_COMPUTE_F32 || !use_wino() || h->split_off || !h->num_cus || !h->hx) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  if (cap != hipStreamCaptureStatusNone) return 0;   // a replay would reuse the launch epoch of the flags
+  if (h->occ_stack < 0) {
+    int o = 0;
+    if (hipFuncSetAttribute((const void*)residual_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStackLds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_kernel, 512, kStackLds) != hipSuccess)
+      o = 0;
+    h->occ_stack = o > 2 ? 2 : o;
+  }
+  const int tpr = cdiv(T, 32);
+  const long long slots = (long long)h->occ_stack * h->num_cus;
+  if (h->occ_stack < 2 || tpr > slots) return 0;
+  const int env = stack_env();
+  if ((long long)B * tpr <= h->num_cus && env != 2) return 0;   // BSG_STACK=2: also for launches of at most one workgroup per CU
+  int rows = (int)(slots / tpr);
+  if (rows > B) rows = B;
+  return rows;
+}
+
+static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
+                        unsigned long long* stamps = nullptr) {
+  const int tpr = cdiv(T, 32);
+  const size_t bt = (size_t)h->B * T;   // bound batch: per-layer stride of the conditioner term
+  for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
+    const int nb = B - r0 < rows_per_launch ? B - r0 : rows_per_launch;
+    const size_t row = (size_t)h->row_off + r0;
+    StackArgs p{};
+    p.x_in = h->xa + row * C * T;
+    p.skip = h->skip + row * C * T;
+    p.condterm = h->condterm + row * 2 * C * T;
+    p.dproj = h->dproj; p.t_dev = t_dev ? t_dev + r0 : nullptr; p.t_uniform = t_uniform;
+    p.apackw = h->apackw; p.apack2 = h->apack2; p.bias_out = h->b_out;
+    p.T = T; p.L = h->L; p.tiles_per_row = tpr;
+    p.ct_stride = (long long)2 * C * (long long)bt;
+    p.n_tiles = nb * tpr; p.cycle = h->cfg.dilation_cycle_length;
+    BSG_REQUIRE((size_t)p.n_tiles <= h->flags_cap && h->L < 64, "stack launch: %d tiles exceed the exchange array (%zu)", p.n_tiles, h->flags_cap);
+    p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
+    if (++h->stack_epoch == 0) h->stack_epoch = 1;
+    p.fbase = h->stack_epoch * 64u;
+    if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("BSG_STACK_STAGGER"); stagger = e ? atoi(e) : 0; }
+    p.stagger = p.n_tiles > h->num_cus ? stagger : 0;   // only when CUs hold two workgroups
+    p.stamps = stamps && r0 == 0 ? stamps : nullptr;
+    hipLaunchKernelGGL(residual_stack_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), kStackLds, st, p);
+    BSG_LAUNCH_CHECK();
+  }
+  h->last_path = "stack";
+  return BSG_OK;
 }
 
 static int check_bound(bsg_diffnet* h, int B, int T, const char* who) {
@@ -1695,9 +2006,14 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
   float* nxt = h->xb;
   const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
   if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-  for (int l = 0; l < h->L; ++l) {
-    TRY(launch_layer(h, l, cur, t_dev, t_uniform, nxt, h->skip, B, T, st));
-    float* tmp = cur; cur = nxt; nxt = tmp;
+  const int srows = stack_rows(h, B, T, st);
+  if (srows) {
+    TRY(launch_stack(h, t_dev, t_uniform, B, T, srows, st));
+  } else {
+    for (int l = 0; l < h->L; ++l) {
+      TRY(launch_layer(h, l, cur, t_dev, t_uniform, nxt, h->skip, B, T, st));
+      float* tmp = cur; cur = nxt; nxt = tmp;
+    }
   }
   if (prof) {
     BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
@@ -1743,13 +2059,9 @@ static int layers_from_xa(bsg_diffnet* h, int t_uniform, int B, int T, hipStream
   float* nxt = h->xb + off;
   const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
   if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-  // the persistent launch zeroes its hand-off flags with a memset before every launch; inside a stream capture that pair did
-  // not replay correctly (measured), so a capturing stream gets the per-layer launches
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);
-  const bool persist = use_persistent() && h->compute == BSG_COMPUTE_F32 && cap == hipStreamCaptureStatusNone && !h->no_split;
-  if (persist) {
-    TRY(launch_layers_persistent(h, nullptr, t_uniform, B, T, st));
+  const int srows = h->no_split ? 0 : stack_rows(h, B, T, st);
+  if (srows) {
+    TRY(launch_stack(h, nullptr, t_uniform, B, T, srows, st));
   } else {
     for (int l = 0; l < h->L; ++l) {
       TRY(launch_layer(h, l, cur, nullptr, t_uniform, nxt, h->skip + off, B, T, st));
@@ -1759,7 +2071,7 @@ static int layers_from_xa(bsg_diffnet* h, int t_uniform, int B, int T, hipStream
   if (prof) {
     BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
     h->prof_used += 2;
-    h->prof_launches += persist ? 1 : h->L;
+    h->prof_launches += h->L;   // layer-equivalents (the stack launch runs L layers in one kernel)
   }
   return BSG_OK;
 }
@@ -1834,7 +2146,7 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
     }
     small = ok && cus <= (double)h->num_cus;
   }
-  const bool dual = dual_env && B >= 2 && use_wino() && !use_persistent() && (big || small);
+  const bool dual = dual_env && B >= 2 && use_wino() && !stack_rows(h, B, T, st) && (big || small);
   if (!dual) return 1;
   if (!h->st2) {
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess ||
@@ -1940,7 +2252,7 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
   *handoff_timeouts = 0;
   if (h->flags) {
     unsigned v = 0;
-    BSG_HIP(hipMemcpy(&v, h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    BSG_HIP(hipMemcpy(&v, h->flags + h->flags_cap, sizeof(unsigned), hipMemcpyDeviceToHost));
     *handoff_timeouts = (int32_t)v;
   }
   if (h->split_flags) {
@@ -1956,10 +2268,10 @@ extern "C" int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeout
   hipStream_t st = (hipStream_t)stream;
   *handoff_timeouts = 0;
   unsigned v[2] = {0, 0};
-  if (h->flags) BSG_HIP(hipMemcpyAsync(&v[0], h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (h->flags) BSG_HIP(hipMemcpyAsync(&v[0], h->flags + h->flags_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   if (h->split_flags) BSG_HIP(hipMemcpyAsync(&v[1], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   BSG_HIP(hipStreamSynchronize(st));
-  if (v[0]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap - 1, 0, sizeof(unsigned), st));
+  if (v[0]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap, 0, sizeof(unsigned), st));
   if (v[1]) BSG_HIP(hipMemsetAsync(h->split_flags + 16 * h->split_cap, 0, sizeof(unsigned), st));
   *handoff_timeouts = (int32_t)(v[0] + v[1]);
   return BSG_OK;
@@ -1972,10 +2284,10 @@ extern "C" int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, i
     BSG_HIP(hipGetDevice(&dev));
     BSG_HIP(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  // conservative: any launch shape for which a channel-split (pair / 4-way) or persistent launch may be chosen
+  // conservative: any launch shape for which a channel-split (pair / 4-way) or the stack launch may be chosen
   const long long tiles = (long long)B * cdiv(T, 32);
   const bool split = h->compute == BSG_COMPUTE_F32 && use_wino() && split_env() && !h->split_off && h->num_cus && tiles <= h->num_cus;
-  *uses = (split || (use_persistent() && h->compute == BSG_COMPUTE_F32)) ? 1 : 0;
+  *uses = (split || stack_rows(h, B, T, nullptr) > 0) ? 1 : 0;
   return BSG_OK;
 }
 
@@ -1995,16 +2307,20 @@ extern "C" int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, vo
   BSG_REQUIRE(h && host_counts, "diffnet_status_async: null argument");
   hipStream_t st = (hipStream_t)stream;
   host_counts[0] = host_counts[1] = 0;
-  if (h->flags) BSG_HIP(hipMemcpyAsync(&host_counts[0], h->flags + h->flags_cap - 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (h->flags) BSG_HIP(hipMemcpyAsync(&host_counts[0], h->flags + h->flags_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   if (h->split_flags) BSG_HIP(hipMemcpyAsync(&host_counts[1], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   return BSG_OK;
 }
 
-extern "C" int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg) {
-  BSG_REQUIRE(h && out && h->clk && n_wg > 0 && n_wg <= 1024, "diffnet_persist_clocks: bad argument");
-  BSG_HIP(hipMemcpy(out, h->clk, (size_t)n_wg * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  return BSG_OK;
+extern "C" int bsg_diffnet_debug_stack_stamps(bsg_diffnet* h, int32_t t_uniform, int32_t B, int32_t T, uint64_t* stamps, void* stream) {
+  TRY(check_bound(h, B, T, "diffnet_debug_stack_stamps"));
+  BSG_REQUIRE(stamps, "diffnet_debug_stack_stamps: null stamps");
+  const int rows = stack_rows(h, B, T, (hipStream_t)stream);
+  BSG_REQUIRE(rows >= B, "diffnet_debug_stack_stamps: (B=%d,T=%d) does not run as one stack launch", B, T);
+  return launch_stack(h, nullptr, t_uniform, B, T, rows, (hipStream_t)stream, (unsigned long long*)stamps);
 }
+
+extern "C" const char* bsg_diffnet_last_path(bsg_diffnet* h) { return h ? h->last_path : "none"; }
 
 extern "C" int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable) {
   BSG_REQUIRE(h, "diffnet_profile: null handle");

@@ -181,7 +181,7 @@ class DiffNet(nn.Module):
     # ------------------------------------------------------------------ hand-off health, checked in the SAME call
     def uses_handoffs(self, B, T):
         """True when launches of shape (B, T) may hand data between workgroups (channel-split launches of small batches,
-        the opt-in persistent launch).  Large batches never do, and then nothing below synchronises."""
+        the on-chip stack launch whose tiles exchange edges every layer).  Otherwise nothing below synchronises."""
         from ctypes import c_int32
         u = c_int32()
         _lib.check(_lib.load().bsg_diffnet_uses_handoffs(self.handle(), B, T, byref(u)), 'bsg_diffnet_uses_handoffs')
@@ -226,29 +226,12 @@ class DiffNet(nn.Module):
         """Record hipEvent pairs around the residual-layer launches of every evaluation (bench.py roofline)."""
         _lib.check(_lib.load().bsg_diffnet_profile(self.handle(), int(enable)), 'bsg_diffnet_profile')
 
-    def check_handoffs_async(self):
-        """Fail loudly, one call late and without a synchronisation, if a launch that hands data between workgroups
-        (channel-split launches at small batch, the opt-in persistent launch) ever gave up waiting for its partner: raises
-        if the counters copied after the PREVIOUS call are non-zero, then enqueues the copy for this call."""
-        if self._h is None or torch.cuda.is_current_stream_capturing():
-            return
-        st = getattr(self, '_hs', None)
-        if st is None:
-            st = self._hs = {'buf': torch.zeros(2, dtype=torch.int32).pin_memory(), 'ev': None}
-        if st['ev'] is not None and st['ev'].query():
-            n = int(st['buf'].sum())
-            st['ev'] = None
-            if n:
-                raise _lib.BsgError(f'{n} inter-workgroup hand-offs timed out (a workgroup of a split / persistent launch was '
-                                    f'not resident): the results of the previous call are invalid')
-        if st['ev'] is None:
-            _lib.check(_lib.load().bsg_diffnet_status_async(self._h, c_void_p(st['buf'].data_ptr()), _lib.stream_ptr()),
-                       'bsg_diffnet_status_async')
-            st['ev'] = torch.cuda.Event()
-            st['ev'].record()
+    def last_path(self):
+        """Form of the last residual-layer launch: 'stack', 'layer', 'split2', 'split4', 'wide', 'bf16' or 'none'."""
+        return _lib.load().bsg_diffnet_last_path(self.handle()).decode()
 
     def handoff_timeouts(self):
-        """Persistent-launch health: spins that gave up (0 unless a workgroup was not resident). Synchronises."""
+        """Hand-off health: spins that gave up and were not yet taken (0 unless a workgroup was not resident). Synchronises."""
         from ctypes import c_int32
         n = c_int32()
         _lib.check(_lib.load().bsg_diffnet_status(self._h, byref(n)), 'bsg_diffnet_status')

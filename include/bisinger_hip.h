@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSG_ABI_VERSION 1
+#define BSG_ABI_VERSION 2
 
 #define BSG_OK 0
 #define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
@@ -134,8 +134,8 @@ int bsg_mel_finish(const float* x, const float* spec_min, const float* spec_max,
 
 /* Live timing of the dominant kernel (bench.py's roofline): while enabled, every DiffNet evaluation records
  * a hipEvent pair around its L fused residual-layer launches on the launch stream.  profile_read waits for the
- * recorded events and returns the summed device time and the number of kernel launches they cover (L per evaluation,
- * or 1 when the L layers run as one persistent launch). */
+ * recorded events and returns the summed device time and the number of layer-equivalents they cover (L per evaluation,
+ * also when the L layers run as one stack launch). */
 int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable);
 int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_layer_launches);
 /* Arithmetic of the fused residual layers (BASELINE config "bf16 diffusion mel-gen"):
@@ -147,8 +147,8 @@ int bsg_diffnet_profile_read(bsg_diffnet* h, double* layer_ms_total, int64_t* n_
 #define BSG_COMPUTE_F32 0
 #define BSG_COMPUTE_BF16 1
 int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode);
-/* Synchronous health check of the launches that hand data between workgroups (the persistent multi-layer launch,
- * BSG_PERSIST=1, and the channel-split launch used for small batches): number of inter-workgroup hand-off spins that
+/* Synchronous health check of the launches that hand data between workgroups (the on-chip stack launch, whose neighbouring
+ * tiles exchange their edges every layer, and the channel-split launch used for small batches): number of inter-workgroup hand-off spins that
  * gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
 int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
 /* Asynchronous form: enqueues copies of the two give-up counters into host_counts[0..1] (pinned host memory, caller-owned)
@@ -166,9 +166,16 @@ int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable);
 /* Fault injection for tests: the next n_launches channel-split launches on the handle give up every hand-off without
  * waiting (counted exactly like a timed-out spin, and their consumers read whatever the exchange tile holds). */
 int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches);
-/* Diagnostic: {s_memtime, s_memrealtime} at the start and end of each workgroup of the LAST persistent launch,
- * out [n_wg][4] uint64 (host).  Shader clock held = d(memtime)/d(memrealtime) x 100 MHz.  Synchronous. */
-int bsg_diffnet_persist_clocks(bsg_diffnet* h, uint64_t* out, int32_t n_wg);
+/* Name of the form the last residual-layer launch on the handle took: "stack" (all L layers in one launch with the residual
+ * stream on chip), "layer" (one launch per layer, one workgroup per tile), "split2" / "split4" (a tile as 2 / 4 workgroups),
+ * "wide" (one 16-wave workgroup per tile), "bf16", or "none".  Static string. */
+const char* bsg_diffnet_last_path(bsg_diffnet* h);
+
+/* Diagnostic run of the stack launch on whatever h->xa holds (timing only): the L layers of the bound batch (which must fit one
+ * launch) at timestep t_uniform, with s_memrealtime (100 MHz) stamps per tile and layer at
+ * {0 xs complete, 1 GEMM1 done, 2 z in LDS, 3 residual half done, 4 skip half done, 5 edges drained, 6 neighbours' flags seen,
+ *  7 halo barrier passed} into stamps [B*ceil(T/32)][L][8] (device, uint64).  Used by tools/stack_stamps.py. */
+int bsg_diffnet_debug_stack_stamps(bsg_diffnet* h, int32_t t_uniform, int32_t B, int32_t T, uint64_t* stamps, void* stream);
 
 /* Diagnostic build of the fused residual layer (separate kernel instantiation; the product kernel executes no
  * stamp): same computation, plus s_memtime stamps per wave at the phase boundaries
