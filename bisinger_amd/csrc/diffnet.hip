@@ -130,10 +130,79 @@ __device__ __forceinline__ void mfma_pipe(f32x16& acc0, f32x16& acc1, f32x4 (&A0
   }
 }
 
-// byte offset of group g's weights inside a row tile of the packed Winograd matrix [comp][32 tiles][16 q][64 lanes][4]
-__device__ __forceinline__ int wino_so(int g) {
-  g = g < 63 ? g : 63;
-  return ((g >> 4) * 512 + (g & 15)) * 1024;
+// ------------------------------------------------------------------------------------------------
+// GEMM1 of the residual block as Winograd F(2,3) over the dilated taps, for one wave: 4 row tiles of 16 (sw[] = their byte
+// offsets in the packed Winograd weights) x 16 output pairs, K = 4 components x 256 channels.
+//   y0 += M0 + M1 + M2   (output frame t of the pair),   y1 += M1 - M2 - M3   (frame t + d),   M_comp = U_comp * V_comp
+//   V0 = x[t-d] - x[t+d],  V1 = x[t] + x[t+d],  V2 = x[t+d] - x[t],  V3 = x[t] - x[t+2d]     (x = the staged, zero-padded xs)
+// The B fragment of group (comp, q) — channels 16 q + 4 jj + lq — is formed in registers: V = x[xo + oa] + sgn * x[xo + ob], one FMA
+// with sgn = +-1 (the exact sum / difference).  Loop structure: components outside, the 16 channel groups inside, so that inside
+// the loop the LDS addresses are two running offsets plus immediates and a group costs NO address arithmetic (the first form
+// of this loop recomputed component, offsets and sign per group: ~15 scalar / vector instructions between two MFMA blocks, which
+// a lone workgroup on a CU — 2 waves per SIMD — could not hide: GEMM1 phase 58 -> 43 us per layer in the stack launch).  The
+// last group of a component prefetches the first of the next one (peeled tail).  One block = 16 MFMAs (v_mfma_f32_16x16x4_f32);
+// the next group's LDS reads are issued before them (their latency passes under the MFMAs), its transform and the weight loads
+// of the group after next behind them; sched_barrier pins that order.  On entry AW[0], AW[1] hold the weights of groups 0, 1.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_gemm1(f32x4 (&y0)[4], f32x4 (&y1)[4], f32x4 (&AW)[2][4], const float* xs, const int xo, const int dil,
+                                           const rsrc_t rs_aw, const int vfrag, const int (&sw)[4]) {
+  constexpr int LDX = 32 + 2 * HALO;
+  f32x4 M[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto offs = [&](int comp, int& oa, int& ob, float& sgn) {
+    oa = xo + ((comp == 2) - (comp == 0)) * dil;
+    ob = xo + ((comp < 2) + 2 * (comp == 3)) * dil;
+    sgn = comp == 1 ? 1.0f : -1.0f;
+  };
+  auto block = [&](f32x4 (&A)[4], const f32x4& Bcur, f32x4& Bnext, int ia, int ib, float sgn, int so) {
+    f32x4 ra, rb;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { ra[jj] = xs[ia + 4 * jj * LDX]; rb[jj] = xs[ib + 4 * jj * LDX]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][jj], Bcur[jj], M[i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) Bnext[jj] = __builtin_fmaf(sgn, rb[jj], ra[jj]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A[i] = ldf4(rs_aw, vfrag, sw[i] + so);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x4 Bw[2];
+  int na, nb;
+  float nsgn;
+  offs(0, na, nb, nsgn);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) Bw[0][jj] = __builtin_fmaf(nsgn, xs[nb + 4 * jj * LDX], xs[na + 4 * jj * LDX]);
+#pragma unroll 1
+  for (int comp = 0; comp < 4; ++comp) {
+    int ia = na + 16 * LDX, ib = nb + 16 * LDX;   // group q + 1 of this component
+    const float sgn = nsgn;
+    offs(comp < 3 ? comp + 1 : 3, na, nb, nsgn);
+    int so = (comp * 512 + 2) * 1024;             // weights of group (comp, q + 2)
+#pragma unroll 1
+    for (int q = 0; q < 14; q += 2) {
+      block(AW[0], Bw[0], Bw[1], ia, ib, sgn, so);
+      block(AW[1], Bw[1], Bw[0], ia + 16 * LDX, ib + 16 * LDX, sgn, so + 1024);
+      ia += 32 * LDX; ib += 32 * LDX; so += 2048;
+    }
+    const int son = ((comp < 3 ? comp + 1 : 3) * 512) * 1024;   // first two groups of the next component (a harmless repeat after the last)
+    block(AW[0], Bw[0], Bw[1], ia, ib, sgn, son);                // (comp, 14): reads (comp, 15)
+    block(AW[1], Bw[1], Bw[0], na, nb, nsgn, son + 1024);        // (comp, 15): reads (comp + 1, 0)
+    // the component is complete (FMAs with 0 / +-1: exact, branch-free)
+    const float c0 = comp < 3 ? 1.0f : 0.0f, c1 = comp == 1 ? 1.0f : comp >= 2 ? -1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        y0[i][r] = __builtin_fmaf(c0, M[i][r], y0[i][r]);
+        y1[i][r] = __builtin_fmaf(c1, M[i][r], y1[i][r]);
+        M[i][r] = 0.f;
+      }
+  }
 }
 
 // One workgroup = 8 waves = one 32-frame tile of one utterance; wave w owns gate rows [32w,32w+32) and filter
@@ -279,60 +348,11 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
     const int p16 = lane & 15, lq = lane >> 4, dil = a.dil;
     const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
     const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
-    f32x4 y0[4], y1[4], M[4];
+    f32x4 y0[4], y1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y0[i] = y1[i] = M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* xb0 = xs + lq * LDX + HALO + tp;
-    auto ldbw = [&](int g) {
-      const int comp = g >> 4, q = g & 15;
-      const int oa = comp == 0 ? -dil : comp == 2 ? dil : 0;
-      const int ob = comp == 0 ? dil : comp == 1 ? dil : comp == 2 ? 0 : 2 * dil;
-      const float* pa = xb0 + 16 * q * LDX + oa;
-      const float* pb = xb0 + 16 * q * LDX + ob;
-      f32x4 v;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float xa = pa[4 * jj * LDX], xb_ = pb[4 * jj * LDX];
-        v[jj] = comp == 1 ? xa + xb_ : xa - xb_;
-      }
-      return v;
-    };
+    for (int i = 0; i < 4; ++i) y0[i] = y1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     BSG_STAMP(2);
-    f32x4 Bw[2];
-    {
-    Bw[0] = ldbw(0);
-
-#pragma unroll 1
-    for (int g = 0; g < 64; g += 2) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int gn = g + s2 + 1 < 64 ? g + s2 + 1 : 63;
-        Bw[(s2 + 1) & 1] = ldbw(gn);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[s2][i][jj], Bw[s2 & 1][jj], M[i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int gr = g + s2 + 2 < 64 ? g + s2 + 2 : 63;
-        const int so = ((gr >> 4) * 512 + (gr & 15)) * 1024;   // comp * (32 tiles * 16 groups) + q
-#pragma unroll
-        for (int i = 0; i < 4; ++i) AW[s2][i] = ldf4(rs_aw, vfrag, sw[i] + so);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if ((g & 15) == 14) {   // a Winograd component is complete: fold it into the two outputs
-        const int comp = g >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (comp == 0) { y0[i] = M[i]; }
-          else if (comp == 1) { y0[i] += M[i]; y1[i] = M[i]; }
-          else if (comp == 2) { y0[i] += M[i]; y1[i] -= M[i]; }
-          else { y1[i] -= M[i]; }
-          M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-    }
+    wino_gemm1(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
     BSG_STAMP(3);
     // ---- (4w) + hoisted conditioner term, gate ----------------------------------------------------
     const int f0c = t0 + tp < T ? t0 + tp : T - 1, f1c = t0 + tp + dil < T ? t0 + tp + dil : T - 1;
@@ -905,63 +925,7 @@ __global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
     // ---- GEMM1 as Winograd F(2,3) over the dilated taps (see residual_tile) ---------------------------
     const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
     const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
-    {
-      f32x4 M[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int xo = lq * LDX + HALO + tp;   // element offset of this lane's B operand in xs
-      // raw operands of group g: V_comp = x[.. + oa] + sgn * x[.. + ob]; offsets and sign by arithmetic on the (wave-uniform) component
-      auto raw = [&](int g, f32x4& ra, f32x4& rb, float& sgn) {
-        const int comp = g >> 4, q = g & 15;
-        const int oa = ((comp == 2) - (comp == 0)) * dil;
-        const int ob = ((comp < 2) + 2 * (comp == 3)) * dil;
-        const int base = xo + 16 * q * LDX;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { ra[jj] = xs[base + oa + 4 * jj * LDX]; rb[jj] = xs[base + ob + 4 * jj * LDX]; }
-        sgn = comp == 1 ? 1.0f : -1.0f;
-      };
-      f32x4 Bw[2];
-      {
-        f32x4 ra, rb;
-        float sgn;
-        raw(0, ra, rb, sgn);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) Bw[0][jj] = __builtin_fmaf(sgn, rb[jj], ra[jj]);
-      }
-#pragma unroll 1
-      for (int g = 0; g < 64; g += 2) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int gn = g + s2 + 1 < 64 ? g + s2 + 1 : 63;
-          f32x4 ra, rb;
-          float sgn;
-          raw(gn, ra, rb, sgn);                       // LDS reads of the NEXT group: their latency passes under the MFMAs below
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[s2][i][jj], Bw[s2 & 1][jj], M[i], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) Bw[(s2 + 1) & 1][jj] = __builtin_fmaf(sgn, rb[jj], ra[jj]);   // xa +/- xb (one rounding)
-          const int so = wino_so(g + s2 + 2);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) AW[s2][i] = ldf4(rs_aw, vfrag, sw[i] + so);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if ((g & 15) == 14) {   // a Winograd component is complete: y(t) = c + M0 + M1 + M2, y(t+d) = c + M1 - M2 - M3
-          const int comp = g >> 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (comp == 0) { y0[i] += M[i]; }
-            else if (comp == 1) { y0[i] += M[i]; y1[i] += M[i]; }
-            else if (comp == 2) { y0[i] += M[i]; y1[i] -= M[i]; }
-            else { y1[i] -= M[i]; }
-            M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-      }
-    }
+    wino_gemm1(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
     STK_STAMP(1);
     // ---- gate: z = sigmoid(gate) * tanh(filter) -> zs (net.py:73-74); first A fragments of GEMM2 fly meanwhile -------
     f32x4 A2[4];
