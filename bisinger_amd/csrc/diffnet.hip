@@ -142,20 +142,27 @@ __device__ __forceinline__ void mfma_pipe(f32x16& acc0, f32x16& acc1, f32x4 (&A0
 // a lone workgroup on a CU — 2 waves per SIMD — could not hide: GEMM1 phase 58 -> 43 us per layer in the stack launch).  The
 // last group of a component prefetches the first of the next one (peeled tail).  One block = 16 MFMAs (v_mfma_f32_16x16x4_f32);
 // the next group's LDS reads are issued before them (their latency passes under the MFMAs), its transform and the weight loads
-// of the group after next behind them; sched_barrier pins that order.  On entry AW[0], AW[1] hold the weights of groups 0, 1.
+// of the group NR ahead behind them; sched_barrier pins that order.  On entry AW[0..NR) hold the weights of groups 0..NR-1.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino_gemm1(f32x4 (&y0)[4], f32x4 (&y1)[4], f32x4 (&AW)[2][4], const float* xs, const int xo, const int dil,
-                                           const rsrc_t rs_aw, const int vfrag, const int (&sw)[4]) {
+template <int NTI, int NR>   // NTI row tiles of 16 per wave (sw[] = their byte offsets), NR = depth of the weight ring (groups in flight)
+__device__ __forceinline__ void wino_gemm1(f32x4 (&y0)[NTI], f32x4 (&y1)[NTI], f32x4 (&AW)[NR][NTI], const float* xs, const int xo, const int dil,
+                                           const rsrc_t rs_aw, const int vfrag, const int (&sw)[NTI]) {
   constexpr int LDX = 32 + 2 * HALO;
-  f32x4 M[4];
+  static_assert(NR == 2 || NR == 4, "ring depth");
+  f32x4 M[NTI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NTI; ++i) M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto offs = [&](int comp, int& oa, int& ob, float& sgn) {
     oa = xo + ((comp == 2) - (comp == 0)) * dil;
     ob = xo + ((comp < 2) + 2 * (comp == 3)) * dil;
     sgn = comp == 1 ? 1.0f : -1.0f;
   };
-  auto block = [&](f32x4 (&A)[4], const f32x4& Bcur, f32x4& Bnext, int ia, int ib, float sgn, int so) {
+  // byte offset of group g's weights inside a row tile of the packed matrix [comp][32 tiles][16 q][64 lanes][4] (clamped: a repeat at the end)
+  auto wso = [](int g) {
+    g = g < 63 ? g : 63;
+    return ((g >> 4) * 512 + (g & 15)) * 1024;
+  };
+  auto block = [&](f32x4 (&A)[NTI], const f32x4& Bcur, f32x4& Bnext, int ia, int ib, float sgn, int so) {
     f32x4 ra, rb;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) { ra[jj] = xs[ia + 4 * jj * LDX]; rb[jj] = xs[ib + 4 * jj * LDX]; }
@@ -163,12 +170,12 @@ __device__ __forceinline__ void wino_gemm1(f32x4 (&y0)[4], f32x4 (&y1)[4], f32x4
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][jj], Bcur[jj], M[i], 0, 0, 0);
+      for (int i = 0; i < NTI; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i][jj], Bcur[jj], M[i], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) Bnext[jj] = __builtin_fmaf(sgn, rb[jj], ra[jj]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) A[i] = ldf4(rs_aw, vfrag, sw[i] + so);
+    for (int i = 0; i < NTI; ++i) A[i] = ldf4(rs_aw, vfrag, sw[i] + so);
     __builtin_amdgcn_sched_barrier(0);
   };
   f32x4 Bw[2];
@@ -182,20 +189,20 @@ __device__ __forceinline__ void wino_gemm1(f32x4 (&y0)[4], f32x4 (&y1)[4], f32x4
     int ia = na + 16 * LDX, ib = nb + 16 * LDX;   // group q + 1 of this component
     const float sgn = nsgn;
     offs(comp < 3 ? comp + 1 : 3, na, nb, nsgn);
-    int so = (comp * 512 + 2) * 1024;             // weights of group (comp, q + 2)
+    int g = comp * 16 + NR;                       // group whose weights the first block requests
 #pragma unroll 1
-    for (int q = 0; q < 14; q += 2) {
-      block(AW[0], Bw[0], Bw[1], ia, ib, sgn, so);
-      block(AW[1], Bw[1], Bw[0], ia + 16 * LDX, ib + 16 * LDX, sgn, so + 1024);
-      ia += 32 * LDX; ib += 32 * LDX; so += 2048;
+    for (int q = 0; q < 16 - NR; q += NR) {
+#pragma unroll
+      for (int s = 0; s < NR; ++s) block(AW[s], Bw[s & 1], Bw[(s + 1) & 1], ia + 16 * s * LDX, ib + 16 * s * LDX, sgn, wso(g + s));
+      ia += 16 * NR * LDX; ib += 16 * NR * LDX; g += NR;
     }
-    const int son = ((comp < 3 ? comp + 1 : 3) * 512) * 1024;   // first two groups of the next component (a harmless repeat after the last)
-    block(AW[0], Bw[0], Bw[1], ia, ib, sgn, son);                // (comp, 14): reads (comp, 15)
-    block(AW[1], Bw[1], Bw[0], na, nb, nsgn, son + 1024);        // (comp, 15): reads (comp + 1, 0)
+#pragma unroll
+    for (int s = 0; s < NR - 1; ++s) block(AW[s], Bw[s & 1], Bw[(s + 1) & 1], ia + 16 * s * LDX, ib + 16 * s * LDX, sgn, wso(g + s));
+    block(AW[NR - 1], Bw[(NR - 1) & 1], Bw[NR & 1], na, nb, nsgn, wso(g + NR - 1));   // (comp, 15) reads (comp + 1, 0)
     // the component is complete (FMAs with 0 / +-1: exact, branch-free)
     const float c0 = comp < 3 ? 1.0f : 0.0f, c1 = comp == 1 ? 1.0f : comp >= 2 ? -1.0f : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NTI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         y0[i][r] = __builtin_fmaf(c0, M[i][r], y0[i][r]);
@@ -352,7 +359,7 @@ __device__ __forceinline__ void residual_tile(const ResArgs& a, const int tile_i
 #pragma unroll
     for (int i = 0; i < 4; ++i) y0[i] = y1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     BSG_STAMP(2);
-    wino_gemm1(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
+    wino_gemm1<4, 2>(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
     BSG_STAMP(3);
     // ---- (4w) + hoisted conditioner term, gate ----------------------------------------------------
     const int f0c = t0 + tp < T ? t0 + tp : T - 1, f1c = t0 + tp + dil < T ? t0 + tp + dil : T - 1;
@@ -538,58 +545,10 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
   const int dil = a.dil;
   const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
   const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
-  f32x4 y0[2], y1[2], M[2];
+  f32x4 y0[2], y1[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) y0[i] = y1[i] = M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* xb0 = xs + lq * LDX + HALO + tp;
-    auto ldbw = [&](int g) {
-      const int comp = g >> 4, q = g & 15;
-      const int oa = comp == 0 ? -dil : comp == 2 ? dil : 0;
-      const int ob = comp == 0 ? dil : comp == 1 ? dil : comp == 2 ? 0 : 2 * dil;
-      const float* pa = xb0 + 16 * q * LDX + oa;
-      const float* pb = xb0 + 16 * q * LDX + ob;
-      f32x4 v;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float xa = pa[4 * jj * LDX], xb_ = pb[4 * jj * LDX];
-        v[jj] = comp == 1 ? xa + xb_ : xa - xb_;
-      }
-      return v;
-    };
-    f32x4 Bw[2];
-    Bw[0] = ldbw(0);
-#pragma unroll 1
-    for (int g = 0; g < 64; g += NR) {
-#pragma unroll
-      for (int s2 = 0; s2 < NR; ++s2) {
-        const int gn = g + s2 + 1 < 64 ? g + s2 + 1 : 63;
-        Bw[(s2 + 1) & 1] = ldbw(gn);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) M[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[s2][i][jj], Bw[s2 & 1][jj], M[i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const int gr = g + s2 + NR < 64 ? g + s2 + NR : 63;
-        const int so = ((gr >> 4) * 512 + (gr & 15)) * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) AW[s2][i] = ldf4(rs_aw, vfrag, sw[i] + so);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if ((g & 15) == 16 - NR) {   // a Winograd component is complete
-        const int comp = g >> 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (comp == 0) { y0[i] = M[i]; }
-          else if (comp == 1) { y0[i] += M[i]; y1[i] = M[i]; }
-          else if (comp == 2) { y0[i] += M[i]; y1[i] -= M[i]; }
-          else { y1[i] -= M[i]; }
-          M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-  }
+  for (int i = 0; i < 2; ++i) y0[i] = y1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wino_gemm1<2, NR>(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
   // ---- (4) + conditioner term, gate --------------------------------------------------------------------
   float z0[4], z1[4];
   {
@@ -644,6 +603,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
       const int row = 16 * gt + 4 * lq + r;
       zs[row * LDZ + tp] = z0[r];
       zs[row * LDZ + tp + dil] = z1[r];
+      if (s.inject && part == 0) continue;   // injected fault: part 0 never publishes, its partners consume whatever the tile held
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z0[r]), rs_zb, vz, (16 * gt + r) * NT * 4, 16);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z1[r]), rs_zb, vz + dil * 4, (16 * gt + r) * NT * 4, 16);
     }
@@ -780,7 +740,6 @@ struct StackArgs {
   int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
-  int stagger;            // 100 MHz ticks the second half of the grid waits before it starts (anti-phase of the two workgroups of a CU)
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
 };
 
@@ -818,15 +777,6 @@ __global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (tile_id >= n_tiles) return;
-  // All workgroups start together and run the same program at the same pace, so the two that share a CU would stage, gate
-  // and wait for their neighbours at the same moments — with nobody using the matrix pipe.  The second half of the grid
-  // (dispatched as the second workgroup of every CU; whole rows of other utterances under the tile order above) starts half a
-  // layer late: while one waits, the other multiplies.  Rows keep their own pace afterwards (only tiles of ONE row wait for
-  // each other), so the offset persists.
-  if (p.stagger > 0 && 2 * (int)blockIdx.x >= (int)gridDim.x) {
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-    while ((long long)(__builtin_amdgcn_s_memrealtime() - t_start) < (long long)p.stagger) __builtin_amdgcn_s_sleep(32);
-  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -925,7 +875,7 @@ __global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
     // ---- GEMM1 as Winograd F(2,3) over the dilated taps (see residual_tile) ---------------------------
     const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
     const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
-    wino_gemm1(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
+    wino_gemm1<4, 2>(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
     STK_STAMP(1);
     // ---- gate: z = sigmoid(gate) * tanh(filter) -> zs (net.py:73-74); first A fragments of GEMM2 fly meanwhile -------
     f32x4 A2[4];
@@ -979,8 +929,10 @@ __global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
       const float* ep = xs + erow * LDX + HALO + (eside ? NT - 8 : 0);
       const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep), e1 = *reinterpret_cast<const f32x4*>(ep + 4);
       const int vh = ((eside ? C * 8 : 0) + erow * 8) * 4;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e0), rs_hx, vh, 0, 16);        // sc1
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e1), rs_hx, vh + 16, 0, 16);   // sc1
+      if (!(p.inject && (tile_id & 1))) {   // injected fault: odd tiles never publish, their neighbours consume stale edges
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e0), rs_hx, vh, 0, 16);        // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e1), rs_hx, vh + 16, 0, 16);   // sc1
+      }
     }
     // ---- GEMM2, skip half (covers the drain of the published edges) ----------------------------------------------------
     mfma_pipe1<4>(accs, A2, rs_a2, vfrag, sb_s, 0, 32, 31, ldbz);
@@ -1883,7 +1835,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
 }
 
 // The on-chip stack launch (residual_stack_kernel): all L layers of `rows` utterances in one launch.  Opt-in (BSG_STACK=1; 2: also for
-// launches of at most one workgroup per CU): measured 121 us per layer at B=16, T=1000 against 108.6 us for two chains of per-layer
+// launches of at most one workgroup per CU): measured 107 us per layer at B=16, T=1000 against 101.9 us for two chains of per-layer
 // launches (DESIGN.md section 9 has the phase timeline and what would have to change).
 static int stack_env() {
   static int v = -1;
@@ -1938,9 +1890,6 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     if (++h->stack_epoch == 0) h->stack_epoch = 1;
     p.fbase = h->stack_epoch * 64u;
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("BSG_STACK_STAGGER"); stagger = e ? atoi(e) : 0; }
-    p.stagger = p.n_tiles > h->num_cus ? stagger : 0;   // only when CUs hold two workgroups
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     hipLaunchKernelGGL(residual_stack_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), kStackLds, st, p);
     BSG_LAUNCH_CHECK();

@@ -163,8 +163,9 @@ int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream)
 int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeouts, void* stream);
 int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, int32_t* uses);
 int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable);
-/* Fault injection for tests: the next n_launches channel-split launches on the handle give up every hand-off without
- * waiting (counted exactly like a timed-out spin, and their consumers read whatever the exchange tile holds). */
+/* Fault injection for tests: in the next n_launches channel-split (or stack) launches on the handle the consumers give up every
+ * hand-off without waiting (counted exactly like a timed-out spin) and one producer per tile (pair) never publishes, so the
+ * consumers deterministically read stale exchange data. */
 int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches);
 /* Name of the form the last residual-layer launch on the handle took: "stack" (all L layers in one launch with the residual
  * stream on chip), "layer" (one launch per layer, one workgroup per tile), "split2" / "split4" (a tile as 2 / 4 workgroups),
