@@ -129,6 +129,296 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One (dilated conv, conv) pair of a ResBlock1, fused (hifigan.py:54-61):
+//     y = x + conv2_{K,1}( lrelu( conv1_{K,d}( lrelu(x) ) ) )        [+ running MRF sum] [/ num_kernels]
+// Un-fused, the pair moves its [B,C,L] tensor through HBM five times (conv1: read + write; conv2: read + residual + write); here
+// the intermediate never leaves the CU: one read of x, one write of y (the residual read is an L2 hit on the lines just staged).
+// Workgroup = 256 threads = P = 256 TT consecutive positions of one utterance, ALL C channels (C TT = 64 accumulators per thread):
+//   A  conv1 at positions [t0 - h2, t0 - h2 + P), h2 = (K-1)/2: raw x staged through LDS in chunks of CI input channels
+//      (span P + (K-1) d, LeakyReLU applied when a lane reads its operand: lrelu(x) = max(x, slope x)); per (ci, tap) a lane
+//      reads TT operands and does C TT FMAs whose weights are wave-uniform (scalar loads of C consecutive floats);
+//   B  t1 = lrelu(conv1 + b1), zero outside [0, L) (conv2 pads ITS input with zeros) -> LDS [C][P] (aliases the x chunks);
+//   C  conv2 (dilation 1) over the LDS image at the P - (K-1) central positions: again C TT FMAs per LDS read;
+//   D  + b2 + x (+ acc_in) (/ out_div) -> y.
+// The (K-1) halo positions of t1 are computed twice (by neighbouring workgroups): 2 % at P = 512.
+// ------------------------------------------------------------------------------------------------
+struct PairArgs {
+  const float* x;       // [B][C][L]
+  const float* w1;      // conv1 packed [C ci][K][C co]
+  const float* b1;
+  const float* w2;      // conv2 packed [C ci][K][C co]
+  const float* b2;
+  float* y;             // [B][C][L]
+  const float* acc_in;  // optional [B][C][L]: y = acc_in + y   (MRF running sum, hifigan.py:161-166)
+  float out_div;        // y /= out_div (num_kernels after the last resblock, :167)
+  float slope;
+  int L, dil;
+};
+
+template <int K, int C, int TT>
+__global__ __launch_bounds__(256) void resblock_pair_kernel(PairArgs a) {
+  constexpr int P = 256 * TT, H2 = (K - 1) / 2, POUT = P - (K - 1);
+  constexpr int CI = C == 16 ? 8 : 4;   // input channels per staged chunk (span <= P + 50 floats each): stays inside the [C][P] image
+  extern __shared__ float lds[];        // [C][P] (+ K-1 floats so that the last row's taps stay inside); phase A uses its first CI * span floats
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * POUT;     // first output position of this workgroup
+  const int b = blockIdx.y;
+  const int h1 = H2 * a.dil, span = P + 2 * h1;
+  const float* __restrict__ xb = a.x + (long long)b * C * a.L;
+  const float slope = a.slope;
+
+  float acc[C][TT];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float bv = a.b1[c];
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[c][j] = bv;
+  }
+  // ---- A: conv1 (dilation d) at u = t0 - H2 + tid + 256 j ---------------------------------------------------------------
+  for (int ci0 = 0; ci0 < C; ci0 += CI) {
+    __syncthreads();
+    for (int idx = tid; idx < CI * span; idx += 256) {
+      const int ci = idx / span, jx = idx - ci * span;
+      const int t = t0 - H2 - h1 + jx;
+      lds[idx] = (t >= 0 && t < a.L) ? xb[(long long)(ci0 + ci) * a.L + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ci = 0; ci < CI; ++ci) {
+      const float* __restrict__ wp = a.w1 + (long long)(ci0 + ci) * (K * C);
+      const float* __restrict__ xr = lds + ci * span + tid;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float xv[TT];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+          const float v = xr[k * a.dil + 256 * j];
+          xv[j] = fmaxf(v, v * slope);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float wv = wp[k * C + c];
+#pragma unroll
+          for (int j = 0; j < TT; ++j) acc[c][j] = fmaf(wv, xv[j], acc[c][j]);
+        }
+      }
+    }
+  }
+  __syncthreads();   // every wave is done with the x chunks
+  // ---- B: t1 = lrelu(conv1), zero outside [0, L) -> LDS [C][P] --------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < TT; ++j) {
+    const int u = t0 - H2 + tid + 256 * j;
+    const bool in = u >= 0 && u < a.L;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float v = acc[c][j];
+      lds[c * P + tid + 256 * j] = in ? fmaxf(v, v * slope) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float bv = a.b2[c];
+#pragma unroll
+    for (int j = 0; j < TT; ++j) acc[c][j] = bv;
+  }
+  __syncthreads();
+  // ---- C: conv2 (dilation 1) at t = t0 + tid + 256 j (positions >= POUT are not outputs of this tile: masked below) ----
+#pragma unroll 1
+  for (int ci = 0; ci < C; ++ci) {
+    const float* __restrict__ wp = a.w2 + (long long)ci * (K * C);
+    const float* __restrict__ tr = lds + ci * P + tid;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float tv[TT];
+#pragma unroll
+      for (int j = 0; j < TT; ++j) tv[j] = tr[256 * j + k];   // the tile's last K-1 positions read into the next row: never stored
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float wv = wp[k * C + c];
+#pragma unroll
+        for (int j = 0; j < TT; ++j) acc[c][j] = fmaf(wv, tv[j], acc[c][j]);
+      }
+    }
+  }
+  // ---- D: residual, MRF sum, store (all loads of a position batch in flight before the first use) ---------------------------
+  const bool has_acc = a.acc_in != nullptr, has_div = a.out_div != 1.0f;
+#pragma unroll
+  for (int j = 0; j < TT; ++j) {
+    const int o = tid + 256 * j, t = t0 + o;
+    if (o >= POUT || t >= a.L) continue;
+    const long long i0 = (long long)b * C * a.L + t;
+    float xr[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xr[c] = a.x[i0 + (long long)c * a.L];
+    if (has_acc) {
+      float ar[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) ar[c] = a.acc_in[i0 + (long long)c * a.L];
+#pragma unroll
+      for (int c = 0; c < C; ++c) xr[c] = ar[c] + (acc[c][j] + xr[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) xr[c] = acc[c][j] + xr[c];
+    }
+    if (has_div) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) xr[c] = xr[c] / a.out_div;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) a.y[i0 + (long long)c * a.L] = xr[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same fused pair on the matrix pipe, for C = 32 and C = 64 channels (stages 1 and 0: two thirds of the generator's FLOPs).
+// fp32 MFMA has the VALU's peak rate, but one v_mfma_f32_32x32x2_f32 replaces 32 wave-wide FMA instructions, so the issue
+// slots the VALU form spends on FMAs (and its scalar weight loads) are free: each conv is an implicit GEMM
+//     out[co][p] = sum_{tap k} sum_{ci} W[co][ci][k] * in[ci][p + k d]          M = C, N = positions, K = C per tap
+// with A = weights pre-packed in fragment order (one 16-byte load per lane = 4 k-steps = 8 input channels of one tap) and
+// B = one conflict-free ds_read_b32 per MFMA (lanes = 32 consecutive positions, the two lane halves = two input channels).
+// Workgroup = 4 waves = PT = 256 positions of the intermediate t1 (POUT = 256 - (K-1) outputs), all C channels: wave w owns
+// positions [64 w, 64 w + 64) = 2 column tiles, and C / 32 row tiles.  LDS: lrelu(x) [C][256 + (K-1) d], then (aliased, after a
+// barrier) t1 [C][272]: 40 KB at C = 32 (4 workgroups per CU), 79 KB at C = 64 (2 per CU).
+// ------------------------------------------------------------------------------------------------
+// out[(((rt*K + k)*(C/8) + g)*64 + lane)*4 + j] = W[co = 32 rt + (lane & 31)][ci = 8 g + 2 j + (lane >> 5)][k],  W = [C][C][K]
+__global__ void pack_conv_mfma_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * C * K) return;
+  const int j = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+  const int G = C / 8;
+  const int g = rest % G, k = (rest / G) % K, rt = rest / (G * K);
+  out[i] = w[((long long)(32 * rt + (lane & 31)) * C + 8 * g + 2 * j + (lane >> 5)) * K + k];
+}
+
+// acc[rt][nb] += W_tap-major * img: img = LDS [C][stride], this wave's positions start at column n0; tap k reads column p + k * dil
+template <int K, int C, int NB>
+__device__ __forceinline__ void conv_mfma(f32x16 (&acc)[C / 32][NB], const float* __restrict__ wpk, const float* img, int stride, int n0,
+                                          int dil, int lane) {
+  constexpr int RT = C / 32, G = C / 8;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wpk) + lane;
+  const float* bp = img + lh * stride + n0 + l31;
+  f32x4 A[2][RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) A[0][rt] = wp[(rt * K * G) * 64];
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const float* bk = bp + k * dil;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      // weights of the next group (the first group of the next tap after the last of this one; a harmless repeat at the very end)
+      const int kn = g + 1 < G ? k : (k + 1 < K ? k + 1 : k), gn = g + 1 < G ? g + 1 : (k + 1 < K ? 0 : g);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) A[(g + 1) & 1][rt] = wp[((rt * K + kn) * G + gn) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = bk[(8 * g + 2 * j) * stride + 32 * nb];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g & 1][rt][j], bv[nb], acc[rt][nb], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int K, int C, int NB>   // NB column tiles of 32 positions per wave: 2 (256 positions per workgroup), or 1 for short inputs (more workgroups)
+__global__ __launch_bounds__(256) void resblock_pair_mfma_kernel(PairArgs a) {
+  constexpr int PT = 128 * NB, H2 = (K - 1) / 2, POUT = PT - (K - 1), RT = C / 32, TS = PT + 16;
+  static_assert(C % 32 == 0 && (C / 8) % 2 == 0, "channel count");
+  extern __shared__ float lds[];   // lrelu(x) [C][XS], then t1 [C][TS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int t0 = blockIdx.x * POUT, b = blockIdx.y;
+  const int h1 = H2 * a.dil, span = PT + 2 * h1, XS = (span + 3) & ~3;
+  const float* __restrict__ xb = a.x + (long long)b * C * a.L;
+  const float slope = a.slope;
+
+  // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L) ---------------------------------------------------
+  for (int idx = tid; idx < C * span; idx += 256) {
+    const int ci = idx / span, jx = idx - ci * span;
+    const int t = t0 - H2 - h1 + jx;
+    float v = (t >= 0 && t < a.L) ? xb[(long long)ci * a.L + t] : 0.f;
+    lds[ci * XS + jx] = fmaxf(v, v * slope);
+  }
+  const int n0 = 32 * NB * wave;
+  f32x16 acc[RT][NB];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bv = a.b1[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb][r] = bv;
+    }
+  __syncthreads();
+  // ---- conv1 (dilation d) at t1 positions u = t0 - H2 + p: reads x column p + k d ------------------------------------------------
+  conv_mfma<K, C, NB>(acc, a.w1, lds, XS, n0, a.dil, lane);
+  __syncthreads();   // every wave is done reading x
+  // ---- t1 = lrelu(conv1), zero outside [0, L) (conv2 pads its input) -> LDS [C][TS] ------------------------------------------
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int pcol = n0 + 32 * nb + l31, u = t0 - H2 + pcol;
+    const bool in = u >= 0 && u < a.L;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[rt][nb][r];
+        lds[(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh) * TS + pcol] = in ? fmaxf(v, v * slope) : 0.f;
+      }
+  }
+  if (tid < C) {   // columns PT .. TS-1 are read by the (masked) last K-1 positions of the tile: keep them finite
+#pragma unroll
+    for (int j = PT; j < TS; ++j) lds[tid * TS + j] = 0.f;
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bv = a.b2[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb][r] = bv;
+    }
+  __syncthreads();
+  // ---- conv2 (dilation 1) at output positions t = t0 + p: reads t1 column p + k ---------------------------------------------
+  conv_mfma<K, C, NB>(acc, a.w2, lds, TS, n0, 1, lane);
+  // ---- residual, MRF sum, store --------------------------------------------------------------------------------------------
+  const bool has_acc = a.acc_in != nullptr, has_div = a.out_div != 1.0f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int pcol = n0 + 32 * nb + l31, t = t0 + pcol;
+    if (pcol >= POUT || t >= a.L) continue;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const long long i0 = ((long long)b * C + 32 * rt + 4 * lh) * a.L + t;
+      float xr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xr[r] = a.x[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L];
+      if (has_acc) {
+        float ar[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ar[r] = a.acc_in[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = ar[r] + (acc[rt][nb][r] + xr[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = acc[rt][nb][r] + xr[r];
+      }
+      if (has_div) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = xr[r] / a.out_div;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a.y[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L] = xr[r];
+    }
+  }
+}
+
 // ConvTranspose1d(Cin -> Cout, K, stride u, padding p) on LeakyReLU(x): y[co][t'] = b[co] + sum over (ci, k, i) with
 // t' = i*u - p + k.  ~3 % of the generator's FLOPs: one thread per output sample, CO_BLK channels, taps gathered.
 struct ConvTArgs {
@@ -251,6 +541,84 @@ int launch_convT(const ConvArgs& a, int B, hipStream_t st) {
   return launch_convT_t<1>(a, B, st);
 }
 
+template <int K, int C, int TT>
+int launch_pair_t(const PairArgs& a, int B, hipStream_t st) {
+  constexpr int P = 256 * TT, POUT = P - (K - 1);
+  const size_t lds = ((size_t)C * P + 16) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)resblock_pair_kernel<K, C, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  hipLaunchKernelGGL((resblock_pair_kernel<K, C, TT>), dim3(cdiv(a.L, POUT), B), dim3(256), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+// positions per thread: as many as the 64-accumulator budget allows (C TT <= 64), fewer while the launch would leave CUs idle
+template <int K, int C>
+int launch_pair_kc(const PairArgs& a, int B, hipStream_t st) {
+  auto wgs = [&](int tt) { return (long long)cdiv(a.L, 256 * tt - (K - 1)) * B; };
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("BSG_HG_ACC"); cap = e ? atoi(e) : 16; }   // accumulators per thread (C TT): 16 measured best (13.6 vs 16.9 ms per forward at 64: occupancy)
+  if constexpr (C * 8 <= 64) { if (C * 8 <= cap && wgs(8) >= 512) return launch_pair_t<K, C, 8>(a, B, st); }
+  if constexpr (C * 4 <= 64) { if (C * 4 <= cap && wgs(4) >= 512) return launch_pair_t<K, C, 4>(a, B, st); }
+  if constexpr (C * 2 <= 64) { if (C * 2 <= cap && wgs(2) >= 512) return launch_pair_t<K, C, 2>(a, B, st); }
+  return launch_pair_t<K, C, 1>(a, B, st);
+}
+template <int K>
+int launch_pair_k(const PairArgs& a, int C, int B, hipStream_t st) {
+  switch (C) {
+    case 8: return launch_pair_kc<K, 8>(a, B, st);
+    case 16: return launch_pair_kc<K, 16>(a, B, st);
+    case 32: return launch_pair_kc<K, 32>(a, B, st);
+    case 64: return launch_pair_kc<K, 64>(a, B, st);
+    default: return BSG_EINVAL;
+  }
+}
+template <int K, int C, int NB>
+int launch_pair_mfma_t(const PairArgs& a, int B, hipStream_t st) {
+  constexpr int PT = 128 * NB, POUT = PT - (K - 1);
+  const int h1 = (K - 1) / 2 * a.dil;
+  const int XS = (PT + 2 * h1 + 3) & ~3;
+  const size_t lds = (size_t)C * (XS > PT + 16 ? XS : PT + 16) * sizeof(float);
+  static size_t attr = 0;
+  if (lds > attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)resblock_pair_mfma_kernel<K, C, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL((resblock_pair_mfma_kernel<K, C, NB>), dim3(cdiv(a.L, POUT), B), dim3(256), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+template <int K, int C>
+int launch_pair_mfma_kc(const PairArgs& a, int B, hipStream_t st) {
+  // 256 positions per workgroup unless that leaves CUs without one (single utterances): then 128
+  if ((long long)cdiv(a.L, 256 - (K - 1)) * B >= 256) return launch_pair_mfma_t<K, C, 2>(a, B, st);
+  return launch_pair_mfma_t<K, C, 1>(a, B, st);
+}
+int launch_pair_mfma(const PairArgs& a, int K, int C, int B, hipStream_t st) {
+  if (C == 32) {
+    if (K == 3) return launch_pair_mfma_kc<3, 32>(a, B, st);
+    if (K == 7) return launch_pair_mfma_kc<7, 32>(a, B, st);
+    if (K == 11) return launch_pair_mfma_kc<11, 32>(a, B, st);
+  } else if (C == 64) {
+    if (K == 3) return launch_pair_mfma_kc<3, 64>(a, B, st);
+    if (K == 7) return launch_pair_mfma_kc<7, 64>(a, B, st);
+    if (K == 11) return launch_pair_mfma_kc<11, 64>(a, B, st);
+  }
+  return BSG_EINVAL;
+}
+bool pair_mfma_supported(int K, int C) { return (K == 3 || K == 7 || K == 11) && (C == 32 || C == 64); }
+bool pair_supported(int K, int C) { return (K == 3 || K == 7 || K == 11) && (C == 8 || C == 16 || C == 32 || C == 64); }
+int launch_pair(const PairArgs& a, int K, int C, int B, hipStream_t st) {
+  switch (K) {
+    case 3: return launch_pair_k<3>(a, C, B, st);
+    case 7: return launch_pair_k<7>(a, C, B, st);
+    case 11: return launch_pair_k<11>(a, C, B, st);
+    default: return BSG_EINVAL;
+  }
+}
+
 int launch_conv(const ConvArgs& a, int K, int B, hipStream_t st) {
   switch (K) {
     case 3: return launch_conv_k<3>(a, B, st);
@@ -280,6 +648,8 @@ using namespace bsg;
 struct ConvW {
   float* w = nullptr;
   float* wpk = nullptr;   // Conv1d only: repacked for conv1d_kernel (CO_BLK = 16 if cout >= 16 else 8)
+  float* wpc = nullptr;   // ResBlock convs: [cin][k][cout] for resblock_pair_kernel
+  float* wpm = nullptr;   // ResBlock convs with 32 / 64 channels: MFMA fragment order for resblock_pair_mfma_kernel
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
 };
@@ -333,12 +703,23 @@ static int take_conv(bsg_hifigan* h, ConvW& c, const void* const*& w, int dim0, 
   return BSG_OK;
 }
 
-static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st) {
+static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st, bool pair = false) {
   const int CO = c.cout >= 16 ? 16 : 8;
   const int n = cdiv(c.cout, CO) * c.cin * c.k * CO;
   TRY(hg_alloc(h, &c.wpk, n));
   hipLaunchKernelGGL(pack_conv_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, c.wpk, c.cout, c.cin, c.k, CO);
   BSG_LAUNCH_CHECK();
+  if (pair && c.cin == c.cout && pair_supported(c.k, c.cout)) {   // one block of all output channels: [cin][k][cout]
+    const int m = c.cin * c.k * c.cout;
+    TRY(hg_alloc(h, &c.wpc, m));
+    hipLaunchKernelGGL(pack_conv_w_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, c.wpc, c.cout, c.cin, c.k, c.cout);
+    BSG_LAUNCH_CHECK();
+    if (pair_mfma_supported(c.k, c.cout)) {
+      TRY(hg_alloc(h, &c.wpm, m));
+      hipLaunchKernelGGL(pack_conv_mfma_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, c.wpm, c.cout, c.k);
+      BSG_LAUNCH_CHECK();
+    }
+  }
   return BSG_OK;
 }
 
@@ -434,7 +815,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
         ConvW& c = (pass == 0 ? h->rb1 : h->rb2)[(size_t)r * cfg->n_dil + m];
         c.cin = c.cout = ch; c.k = k;
         if ((rc = take_conv(h, c, w, ch, ch * k, st)) != BSG_OK) return fail(rc);
-        if ((rc = pack_conv(h, c, st)) != BSG_OK) return fail(rc);
+        if ((rc = pack_conv(h, c, st, true)) != BSG_OK) return fail(rc);
       }
   }
   h->post.cout = 1; h->post.cin = C0 >> cfg->n_ups; h->post.k = 7;
@@ -515,8 +896,30 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
         const bool last = m == c.n_dil - 1;
         const ConvW& c1 = h->rb1[(size_t)r * c.n_dil + m];
         const ConvW& c2 = h->rb2[(size_t)r * c.n_dil + m];
-        TRY(run_conv(c1, y, tmp, B, L, c.resblock_dilations[j][m], slope, nullptr, nullptr, 1.0f, 0, st));     // :56-57
         float* dst = last ? sum : (y == ya ? yb : ya);
+        static int fused_env = -1;
+        if (fused_env < 0) { const char* e = getenv("BSG_HG_FUSED"); fused_env = e ? atoi(e) : 1; }
+        // fused pair (one HBM round trip instead of two and a half) unless the launch would leave most CUs without a workgroup
+        const long long pair_wgs = (long long)cdiv(L, 256 - (c1.k - 1)) * B;
+        static int mfma_env = -1;
+        if (mfma_env < 0) { const char* e = getenv("BSG_HG_MFMA"); mfma_env = e ? atoi(e) : 1; }
+        const bool use_mfma = mfma_env && c1.wpm && c2.wpm;
+        if (fused_env && c1.wpc && c2.wpc && (use_mfma || pair_wgs >= 128 || fused_env == 2)) {
+          PairArgs pa{};
+          pa.x = y; pa.w1 = c1.wpc; pa.b1 = c1.b; pa.w2 = c2.wpc; pa.b2 = c2.b; pa.y = dst;
+          pa.acc_in = (last && j > 0) ? sum : nullptr;
+          pa.out_div = (last && j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f;
+          pa.slope = slope; pa.L = L; pa.dil = c.resblock_dilations[j][m];
+          if (use_mfma) {
+            pa.w1 = c1.wpm; pa.w2 = c2.wpm;
+            TRY(launch_pair_mfma(pa, c1.k, c1.cout, B, st));
+          } else {
+            TRY(launch_pair(pa, c1.k, c1.cout, B, st));
+          }
+          y = dst;
+          continue;
+        }
+        TRY(run_conv(c1, y, tmp, B, L, c.resblock_dilations[j][m], slope, nullptr, nullptr, 1.0f, 0, st));     // :56-57
         TRY(run_conv(c2, tmp, dst, B, L, 1, slope, y, (last && j > 0) ? sum : nullptr,
                      (last && j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f, 0, st));                     // :58-60, :161-167
         y = dst;
