@@ -419,6 +419,77 @@ __global__ __launch_bounds__(256) void resblock_pair_mfma_kernel(PairArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Polyphase ConvTranspose1d (K = 2u, stride u, padding u/2) with coalesced stores: a lane owns ONE input position q and produces
+// all u output phases of CO output channels, i.e. u consecutive output samples per channel (32 B at u = 8): a wave's store
+// instructions cover contiguous 2-KB runs.  (The launch-per-phase form of conv1d_kernel<2,..> stores one float per lane every
+// u floats: the same bytes as 8x the store transactions; it ran at 0.6 TB/s.)
+//   y[co][q u + r - p] = b[co] + sum_ci ( lrelu(x[ci][q-1]) w[ci][co][r + u] + lrelu(x[ci][q]) w[ci][co][r] )
+// weights: the per-phase 2-tap packing of pack_convT_w_kernel with CO-blocks of 8: [r][co-block][ci][2][8].
+// ------------------------------------------------------------------------------------------------
+struct UpArgs {
+  const float* x;     // [B][Cin][Lin]
+  const float* w;     // [u][ceil(Cout/8)][Cin][2][8]
+  const float* bias;
+  float* y;           // [B][Cout][Lin*u]
+  float slope;
+  int Cin, Cout, Lin, p;
+};
+template <int U>
+__global__ __launch_bounds__(256) void upsample_kernel(UpArgs a) {
+  constexpr int CO = 8, CIC = 16;
+  __shared__ float xs[CIC][260];
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.x * 256, q = q0 + tid;     // q in [0, Lin]: position q contributes outputs [q U - p, q U - p + U)
+  const int cb = blockIdx.y, b = blockIdx.z;
+  const int nblk = (a.Cout + CO - 1) / CO;
+  const float* __restrict__ xb = a.x + (long long)b * a.Cin * a.Lin;
+  float acc[CO][U];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float bv = cb * CO + c < a.Cout ? a.bias[cb * CO + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < U; ++r) acc[c][r] = bv;
+  }
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += CIC) {
+    __syncthreads();
+    for (int idx = tid; idx < CIC * 257; idx += 256) {
+      const int ci = idx / 257, j = idx - ci * 257;
+      const int t = q0 - 1 + j;
+      float v = (ci0 + ci < a.Cin && t >= 0 && t < a.Lin) ? xb[(long long)(ci0 + ci) * a.Lin + t] : 0.f;
+      xs[ci][j] = fmaxf(v, v * a.slope);
+    }
+    __syncthreads();
+    const int nci = a.Cin - ci0 < CIC ? a.Cin - ci0 : CIC;
+#pragma unroll 1
+    for (int ci = 0; ci < nci; ++ci) {
+      const float xm = xs[ci][tid], x0 = xs[ci][tid + 1];   // x[q-1], x[q]
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        const float* __restrict__ wp = a.w + (((long long)r * nblk + cb) * a.Cin + ci0 + ci) * (2 * CO);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c][r] = fmaf(wp[CO + c], x0, fmaf(wp[c], xm, acc[c][r]));
+      }
+    }
+  }
+  if (q > a.Lin) return;
+  const int Lout = a.Lin * U;
+  const int o0 = q * U - a.p;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (cb * CO + c >= a.Cout) continue;
+    float* __restrict__ yr = a.y + ((long long)b * a.Cout + cb * CO + c) * Lout;
+    if (o0 >= 0 && o0 + U <= Lout && (U % 4) == 0 && ((o0 & 3) == 0)) {
+#pragma unroll
+      for (int r = 0; r < U; r += 4) *reinterpret_cast<f32x4*>(yr + o0 + r) = f32x4{acc[c][r], acc[c][r + 1], acc[c][r + 2], acc[c][r + 3]};
+    } else {
+#pragma unroll
+      for (int r = 0; r < U; ++r)
+        if (o0 + r >= 0 && o0 + r < Lout) yr[o0 + r] = acc[c][r];
+    }
+  }
+}
+
 // ConvTranspose1d(Cin -> Cout, K, stride u, padding p) on LeakyReLU(x): y[co][t'] = b[co] + sum over (ci, k, i) with
 // t' = i*u - p + k.  ~3 % of the generator's FLOPs: one thread per output sample, CO_BLK channels, taps gathered.
 struct ConvTArgs {
@@ -650,6 +721,7 @@ struct ConvW {
   float* wpk = nullptr;   // Conv1d only: repacked for conv1d_kernel (CO_BLK = 16 if cout >= 16 else 8)
   float* wpc = nullptr;   // ResBlock convs: [cin][k][cout] for resblock_pair_kernel
   float* wpm = nullptr;   // ResBlock convs with 32 / 64 channels: MFMA fragment order for resblock_pair_mfma_kernel
+  float* wpu = nullptr;   // ConvTranspose1d with K = 2u: per-phase 2-tap weights in CO-blocks of 8 for upsample_kernel
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
 };
@@ -731,6 +803,12 @@ static int pack_convT(bsg_hifigan* h, ConvW& c, int u, hipStream_t st) {
   TRY(hg_alloc(h, &c.wpk, n));
   hipLaunchKernelGGL(pack_convT_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, c.wpk, c.cin, c.cout, u, CO);
   BSG_LAUNCH_CHECK();
+  if (u == 8 || u == 2 || u == 4) {
+    const int n8 = u * cdiv(c.cout, 8) * c.cin * 2 * 8;
+    TRY(hg_alloc(h, &c.wpu, n8));
+    hipLaunchKernelGGL(pack_convT_w_kernel, dim3(cdiv(n8, 256)), dim3(256), 0, st, (const float*)c.w, c.wpu, c.cin, c.cout, u, 8);
+    BSG_LAUNCH_CHECK();
+  }
   return BSG_OK;
 }
 
@@ -868,7 +946,18 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
     t.x = cur; t.w = up.w; t.bias = up.b; t.y = (cur == x ? xs : x); t.in_slope = slope; t.Cin = up.cin; t.Cout = up.cout;
     t.Lin = L; t.K = up.k; t.u = c.upsample_rates[i]; t.p = (up.k - c.upsample_rates[i]) / 2;
     const int Lout = L * t.u;
-    if (up.wpk && !getenv("BSG_NO_POLYPHASE")) {
+    static int up_env = -1;
+    if (up_env < 0) { const char* e = getenv("BSG_HG_UP"); up_env = e ? atoi(e) : 1; }
+    if (up.wpu && up_env && t.p * 2 == t.u && (long long)cdiv(L + 1, 256) * cdiv(up.cout, 8) * B >= 512) {   // short inputs: the phase-per-block form has u x the workgroups
+      // all phases of a position in one lane: contiguous stores (upsample_kernel)
+      UpArgs ua{};
+      ua.x = cur; ua.w = up.wpu; ua.bias = up.b; ua.y = t.y; ua.slope = slope; ua.Cin = up.cin; ua.Cout = up.cout; ua.Lin = L; ua.p = t.p;
+      const dim3 grid(cdiv(L + 1, 256), cdiv(up.cout, 8), B);
+      if (t.u == 8) hipLaunchKernelGGL(upsample_kernel<8>, grid, dim3(256), 0, st, ua);
+      else if (t.u == 4) hipLaunchKernelGGL(upsample_kernel<4>, grid, dim3(256), 0, st, ua);
+      else hipLaunchKernelGGL(upsample_kernel<2>, grid, dim3(256), 0, st, ua);
+      BSG_LAUNCH_CHECK();
+    } else if (up.wpk && !getenv("BSG_NO_POLYPHASE")) {
       // polyphase form: u interleaved 2-tap convolutions over the input positions (weights wave-uniform -> scalar loads)
       ConvArgs a{};
       a.x = cur; a.w = up.wpk; a.bias = up.b; a.y = t.y; a.out_div = 1.0f; a.in_slope = slope;
