@@ -264,8 +264,10 @@ __global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) 
     }
   }
   BSG_STAMP(4);
-  // residual rows start from x + b_out, skip rows from b_out  (requesting x before the gate math instead was measured slower:
-  // 99.2 vs 96.4 us per launch — 32 more live registers spill)
+  // residual rows start from x + b_out, skip rows from b_out.  Measured slower (the kernel sits at its 128-register budget, every
+  // prefetch spills): requesting x before the gate math (99.2 vs 96.4 us per launch); requesting the skip quads before GEMM2 (102.5);
+  // staging x in accumulator layout and keeping it for the residual, paid for by running GEMM1 per column tile so that its weights
+  // stream from L2 twice (118.5 us: the weight stream, not the x re-read, is what the layer waits for).
   f32x16 or0, os0, or1, os1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {

@@ -21,7 +21,7 @@ voc = voc.cuda()
 voc.remove_weight_norm()
 B, T = int(os.environ.get('PB', 16)), int(os.environ.get('PT', 1000))
 mel = torch.randn(B, 80, T, device='cuda')
-for _ in range(int(os.environ.get('PN', 5))):
+for _ in range(int(os.environ.get("PN", 5))):
     wav = voc(mel)
 torch.cuda.synchronize()
 print('done', tuple(wav.shape))
