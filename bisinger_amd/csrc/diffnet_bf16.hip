@@ -38,7 +38,7 @@ constexpr int ROWB = 2 * C + 16;          // LDS image row: 256 bf16 + 16 B pad 
 constexpr int XROWS = NT + 2 * HALO;      // 80
 constexpr int XS_BYTES = XROWS * ROWB;    // 42,240
 constexpr int ZS_BYTES = NT * ROWB;       // 33,792
-constexpr int NS = 3;                     // A-fragment ring depth (k-steps)
+constexpr int NS = 4;                     // A-fragment ring depth (k-steps)
 constexpr int KSB = 16 * 1024;            // bytes per k-step slab of a packed weight (16 row tiles x 1 KB)
 
 // out[((ks*(M/32) + rt)*64 + lane)*8 + j] = bf16( W(m = 32*rt + (lane&31), k = 16*ks + 8*(lane>>5) + j) )
