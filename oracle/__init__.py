@@ -2,7 +2,7 @@
 
 This package is the *checker*, never the product: only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
-``bisinger_amd`` never imports ``oracle`` (tests/test_layout.py enforces that), and the
+``bisinger_amd`` never imports ``oracle`` (tests/test_abi.py::test_product_package_never_imports_the_oracle enforces that), and the
 product path raises when the HIP library is missing instead of falling back to this code.
 
 What it is
