@@ -724,24 +724,6 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
 // Every workgroup must be resident (neighbours wait for each other): the host launches at most 2 per CU (80 KB of LDS each)
 // and never inside a stream capture; spins are bounded and counted in `status` like the split launch's.
 // ------------------------------------------------------------------------------------------------
-struct StackArgs {
-  const float* x_in;      // [B][C][T] in-projected x of this launch's rows
-  float* skip;            // [B][C][T] output: skip sum / sqrt(L)
-  const float* condterm;  // layer 0, this launch's rows: [B][2C][T]; + l * ct_stride for layer l
-  const float* dproj;     // [S][L][C]
-  const long long* t_dev; // [B] or null
-  const float* apackw;    // layer 0; + l * aw_stride
-  const float* apack2;    // layer 0; + l * a2_stride
-  const float* bias_out;  // layer 0; + l * 2C
-  long long ct_stride;
-  float* hx;              // [2 parities][n_tiles][2 sides][C][8] edge exchange
-  unsigned* flags;        // [n_tiles]
-  unsigned* status;       // += 1 for every spin that gave up
-  int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
-  unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
-  int inject;             // fault injection: consumers do not wait
-  unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
-};
 
 // one row tile (32 rows) x 32 columns, K = 8 * (q_end - q_begin): A fragments in a ring of NS groups of 4 k-steps
 template <int NS, typename LDB>
@@ -1427,6 +1409,8 @@ struct bsg_diffnet {
   size_t flags_cap = 0;                // tiles the exchange array and the flags are sized for
   unsigned stack_epoch = 0;
   int occ_stack = -1;                  // resident workgroups per CU of residual_stack_kernel (-1: not queried)
+  int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
+  bool skip_is_f32 = false;            // bf16 mode: the last evaluation left the skip sum in h->skip as fp32 (stack launch), not in skip_h
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1805,6 +1789,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     if (ext && !a.first) TRY(f32_to_quad_bf16(skip, h->skip_h, B, C, T, st));
     TRY(launch_residual_layer_bf16(a, st));
     h->last_path = "bf16";
+    h->skip_is_f32 = false;
     if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
     return BSG_OK;
   }
@@ -1898,6 +1883,55 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
   return BSG_OK;
 }
 
+// bf16-operand configuration: the stack launch (opt-in, BSG_STACK_BF16=1).  64-frame tiles, one workgroup per CU (256 registers per
+// wave), whole rows per launch group.  Measured at B=64, T=1000: 247 ms per pass against 243.5 ms for two chains of per-layer
+// launches: 25.9 us per layer and tile, of which 10.2 us are the two GEMMs — with one workgroup per CU nothing overlaps the gate
+// (6 us), the image / publish / flag / acquire / halo chain (9.7 us); DESIGN.md section 9.
+static int stack_rows_bf16(bsg_diffnet* h, int B, int T, hipStream_t st) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("BSG_STACK_BF16"); env = e ? atoi(e) : 0; }
+  if (!env || h->compute != BSG_COMPUTE_BF16 || h->split_off || !h->num_cus || !h->hx) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st) (void)hipStreamIsCapturing(st, &cap);
+  if (cap != hipStreamCaptureStatusNone) return 0;   // a replay would reuse the launch epoch of the flags
+  if (h->occ_stack_h < 0) h->occ_stack_h = stack_bf16_occupancy() >= 1 ? 1 : 0;
+  const int tpr = cdiv(T, 64);
+  const long long slots = (long long)h->occ_stack_h * h->num_cus;
+  if (h->occ_stack_h < 1 || tpr > slots) return 0;
+  int rows = (int)(slots / tpr);
+  if (rows > B) rows = B;
+  return rows;
+}
+
+static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
+                             unsigned long long* stamps = nullptr) {
+  const int tpr = cdiv(T, 64);
+  const size_t bt = (size_t)h->B * T;
+  for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
+    const int nb = B - r0 < rows_per_launch ? B - r0 : rows_per_launch;
+    const size_t row = (size_t)h->row_off + r0;
+    StackArgs p{};
+    p.x_in = h->xa + row * C * T;
+    p.skip = h->skip + row * C * T;
+    p.condterm_h = h->condterm_h + row * 2 * C * T;
+    p.dproj = h->dproj; p.t_dev = t_dev ? t_dev + r0 : nullptr; p.t_uniform = t_uniform;
+    p.apack1h = h->apack1h; p.apack2h = h->apack2h; p.bias_out = h->b_out;
+    p.T = T; p.L = h->L; p.tiles_per_row = tpr;
+    p.ct_stride = (long long)2 * C * (long long)bt;
+    p.n_tiles = nb * tpr; p.cycle = h->cfg.dilation_cycle_length;
+    BSG_REQUIRE((size_t)p.n_tiles <= h->flags_cap && h->L < 64, "bf16 stack launch: %d tiles exceed the exchange array (%zu)", p.n_tiles, h->flags_cap);
+    p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
+    if (++h->stack_epoch == 0) h->stack_epoch = 1;
+    p.fbase = h->stack_epoch * 64u;
+    if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
+    p.stamps = stamps && r0 == 0 ? stamps : nullptr;
+    TRY(launch_residual_stack_bf16(p, st));
+  }
+  h->last_path = "stack_bf16";
+  h->skip_is_f32 = true;
+  return BSG_OK;
+}
+
 static int check_bound(bsg_diffnet* h, int B, int T, const char* who) {
   if (!h) { set_error("%s: null handle", who); return BSG_EINVAL; }
   if (h->cap_bt == 0 || h->B != B || h->T != T) {
@@ -1920,7 +1954,10 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
   const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
   if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   const int srows = stack_rows(h, B, T, st);
-  if (srows) {
+  const int hrows = stack_rows_bf16(h, B, T, st);
+  if (hrows) {
+    TRY(launch_stack_bf16(h, t_dev, t_uniform, B, T, hrows, st));
+  } else if (srows) {
     TRY(launch_stack(h, t_dev, t_uniform, B, T, srows, st));
   } else {
     for (int l = 0; l < h->L; ++l) {
@@ -1933,7 +1970,7 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
     h->prof_used += 2;
     h->prof_launches += h->L;
   }
-  if (h->compute == BSG_COMPUTE_BF16) TRY(quad_bf16_to_f32(h->skip_h, h->skip, B, C, T, st));
+  if (h->compute == BSG_COMPUTE_BF16 && !h->skip_is_f32) TRY(quad_bf16_to_f32(h->skip_h, h->skip, B, C, T, st));
   TRY(conv1x1(h->w_skip, h->b_skip, h->skip, h->hid, C, C, B, T, ACT_RELU, st));   // net.py:127-128
   TRY(conv1x1(h->w_fin, h->b_fin, h->hid, eps, h->M, C, B, T, ACT_NONE, st));      // net.py:129
   return BSG_OK;
@@ -1973,7 +2010,10 @@ static int layers_from_xa(bsg_diffnet* h, int t_uniform, int B, int T, hipStream
   const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
   if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
   const int srows = h->no_split ? 0 : stack_rows(h, B, T, st);
-  if (srows) {
+  const int hrows = stack_rows_bf16(h, B, T, st);
+  if (hrows) {
+    TRY(launch_stack_bf16(h, nullptr, t_uniform, B, T, hrows, st));
+  } else if (srows) {
     TRY(launch_stack(h, nullptr, t_uniform, B, T, srows, st));
   } else {
     for (int l = 0; l < h->L; ++l) {
@@ -2006,7 +2046,7 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
     tail_attr = true;
   }
   const size_t off = (size_t)h->row_off * C * T;
-  a.skip = h->skip + off; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h + off : nullptr;
+  a.skip = h->skip + off; a.skip_h = h->compute == BSG_COMPUTE_BF16 && !h->skip_is_f32 ? h->skip_h + off : nullptr;
   a.x = x; a.xa_next = h->xa + off;
   a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
   a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32);
@@ -2059,7 +2099,7 @@ static int dual_fork(bsg_diffnet* h, int B, int T, hipStream_t st, SubBatch (&su
     }
     small = ok && cus <= (double)h->num_cus;
   }
-  const bool dual = dual_env && B >= 2 && use_wino() && !stack_rows(h, B, T, st) && (big || small);
+  const bool dual = dual_env && B >= 2 && use_wino() && !stack_rows(h, B, T, st) && !stack_rows_bf16(h, B, T, st) && (big || small);
   if (!dual) return 1;
   if (!h->st2) {
     if (hipStreamCreateWithFlags(&h->st2, hipStreamNonBlocking) != hipSuccess ||
@@ -2200,7 +2240,7 @@ extern "C" int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, i
   // conservative: any launch shape for which a channel-split (pair / 4-way) or the stack launch may be chosen
   const long long tiles = (long long)B * cdiv(T, 32);
   const bool split = h->compute == BSG_COMPUTE_F32 && use_wino() && split_env() && !h->split_off && h->num_cus && tiles <= h->num_cus;
-  *uses = (split || stack_rows(h, B, T, nullptr) > 0) ? 1 : 0;
+  *uses = (split || stack_rows(h, B, T, nullptr) > 0 || stack_rows_bf16(h, B, T, nullptr) > 0) ? 1 : 0;
   return BSG_OK;
 }
 
@@ -2228,6 +2268,11 @@ extern "C" int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, vo
 extern "C" int bsg_diffnet_debug_stack_stamps(bsg_diffnet* h, int32_t t_uniform, int32_t B, int32_t T, uint64_t* stamps, void* stream) {
   TRY(check_bound(h, B, T, "diffnet_debug_stack_stamps"));
   BSG_REQUIRE(stamps, "diffnet_debug_stack_stamps: null stamps");
+  if (h->compute == BSG_COMPUTE_BF16) {
+    const int hrows = stack_rows_bf16(h, B, T, (hipStream_t)stream);
+    BSG_REQUIRE(hrows >= B, "diffnet_debug_stack_stamps: (B=%d,T=%d) does not run as one bf16 stack launch", B, T);
+    return launch_stack_bf16(h, nullptr, t_uniform, B, T, hrows, (hipStream_t)stream, (unsigned long long*)stamps);
+  }
   const int rows = stack_rows(h, B, T, (hipStream_t)stream);
   BSG_REQUIRE(rows >= B, "diffnet_debug_stack_stamps: (B=%d,T=%d) does not run as one stack launch", B, T);
   return launch_stack(h, nullptr, t_uniform, B, T, rows, (hipStream_t)stream, (unsigned long long*)stamps);

@@ -317,6 +317,289 @@ __global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) 
 }
 #undef BSG_STAMP
 
+// ------------------------------------------------------------------------------------------------
+// All L layers of the bf16-operand configuration in ONE launch, residual stream on chip (the bf16 sibling of
+// residual_stack_kernel, diffnet.hip — same hand-off protocol, see there).  The per-layer kernel above is bound by bytes and by
+// the latency of its weight stream; here
+//   * x (fp32) lives in 32 registers per lane in accumulator layout — it IS the initial value of GEMM2's residual rows — and as the
+//     bf16 image xs = bf16(x + d_l) in LDS; it is read from HBM once (layer 0) and never written back;
+//   * the running skip sum lives in 32 registers per lane in fp32 (the per-layer kernel rounds it to bf16 in HBM after every
+//     layer) and is stored once;
+//   * the only HBM stream per layer is the conditioner term (bf16, 1 KB per frame), requested into the GEMM1 accumulators while the
+//     workgroup waits for its neighbours; neighbours exchange the two 8-frame edges of the new bf16 image (2 x 4 KB per tile);
+//   * one workgroup per CU with 256 registers per wave: the weight ring is 8 k-steps deep (>= 2000 cycles of cover for the L2
+//     latency of the 1-MB-per-tile weight stream that the per-layer kernel waits for with its 4-deep ring).
+// HBM bytes per frame and layer: 1.25 KB instead of 4.3 KB.  Arithmetic: as the per-layer bf16 kernel, except that the skip sum is
+// never rounded to bf16 and the conditioner term is the accumulators' initial value.
+// ------------------------------------------------------------------------------------------------
+constexpr int NSS = 8;   // weight ring of the stack kernel (k-steps)
+
+template <typename LDB>
+__device__ __forceinline__ void mfma_pipe_bf8(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, bf16x8 (&A0)[NSS], bf16x8 (&A1)[NSS],
+                                              rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks, LDB ldb) {
+  bf16x8 B0[2], B1[2];
+  B0[0] = ldb(0, 0);
+  B1[0] = ldb(0, 1);
+  const int last = n_ks - 1;
+#pragma unroll 1
+  for (int ks = 0; ks < n_ks; ks += NSS) {
+#pragma unroll
+    for (int s = 0; s < NSS; ++s) {
+      const int kn = ks + s + 1 <= last ? ks + s + 1 : last;
+      B0[(s + 1) & 1] = ldb(kn, 0);
+      B1[(s + 1) & 1] = ldb(kn, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      BSG_MFMA_BF(c00, A0[s], B0[s & 1]);
+      BSG_MFMA_BF(c10, A1[s], B0[s & 1]);
+      BSG_MFMA_BF(c01, A0[s], B1[s & 1]);
+      BSG_MFMA_BF(c11, A1[s], B1[s & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kr = ks + s + NSS <= last ? ks + s + NSS : last;
+      A0[s] = lda8(rs, vfrag, sa0 + kr * KSB);
+      A1[s] = lda8(rs, vfrag, sa1 + kr * KSB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;              // [80 frames][528 B]: bf16(x + d_l), frames t0-8 .. t0+71
+  char* zs = lds_raw + XS_BYTES;   // [64 frames][528 B]: gated activation
+
+  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile_id >= n_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tpr = p.tiles_per_row, L = p.L, T = p.T;
+  const int b = tile_id / tpr, j = tile_id - b * tpr;
+  const int t0 = j * NT;
+  const int tb = p.t_dev ? (int)p.t_dev[b] : p.t_uniform;
+  const bool has_left = j > 0, has_right = j + 1 < tpr;
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
+  const int rowT = T * 4, vfrag = lane * 16;
+  int vcol[2], vst[2], vq[2];
+  bool col_ok[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = t0 + 32 * ct + l31;
+    col_ok[ct] = col < T;
+    vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
+    vst[ct] = (lh * 4 * T + col) * 4;
+    vq[ct] = (lh * T + (col_ok[ct] ? col : T - 1)) * 8;
+  }
+  const int sa_g = wave * 1024, sa_f = (8 + wave) * 1024;   // gate / filter row tile inside a k-step slab
+  const int sb_r = wave * 1024, sb_s = (8 + wave) * 1024;   // residual / skip row tile
+
+  float xr[2][16];        // x, accumulator layout: registers 4g..4g+3 = channels 32w + 8g + 4 lh + (0..3) of frame 32 ct + l31
+  float sk[2][16];        // running skip sum (fp32), same layout (skip rows C + 32w + ..)
+  f32x16 yg0, yf0, yg1, yf1;   // GEMM1 accumulators; they start from the conditioner term
+
+  auto load_cond = [&](int l) {
+    const rsrc_t rs_ct = mk_rsrc(p.condterm_h + (long long)l * p.ct_stride + (long long)b * 2 * C * T, plane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 g0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (8 * wave + 2 * g) * T * 8, 0));
+      const u32x2 f0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+      const u32x2 g1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (8 * wave + 2 * g) * T * 8, 0));
+      const u32x2 f1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+      yg0[4 * g] = bf16_lo(g0[0]); yg0[4 * g + 1] = bf16_hi(g0[0]); yg0[4 * g + 2] = bf16_lo(g0[1]); yg0[4 * g + 3] = bf16_hi(g0[1]);
+      yf0[4 * g] = bf16_lo(f0[0]); yf0[4 * g + 1] = bf16_hi(f0[0]); yf0[4 * g + 2] = bf16_lo(f0[1]); yf0[4 * g + 3] = bf16_hi(f0[1]);
+      yg1[4 * g] = bf16_lo(g1[0]); yg1[4 * g + 1] = bf16_hi(g1[0]); yg1[4 * g + 2] = bf16_lo(g1[1]); yg1[4 * g + 3] = bf16_hi(g1[1]);
+      yf1[4 * g] = bf16_lo(f1[0]); yf1[4 * g + 1] = bf16_hi(f1[0]); yf1[4 * g + 2] = bf16_lo(f1[1]); yf1[4 * g + 3] = bf16_hi(f1[1]);
+    }
+  };
+  // xs core (frames t0 .. t0+63, this wave's 32 channels) = bf16(x + d_l), zero beyond T (the conv pads x + d)
+  auto write_core = [&](int l) {
+    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + l) * C, C * 4);
+    float dv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = ldf(rs_dp, lh * 16, (32 * wave + acc_row0(r)) * 4);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w2 = u32x2{pack2(xr[ct][4 * g] + dv[4 * g], xr[ct][4 * g + 1] + dv[4 * g + 1]),
+                         pack2(xr[ct][4 * g + 2] + dv[4 * g + 2], xr[ct][4 * g + 3] + dv[4 * g + 3])};
+        if (!col_ok[ct]) w2 = u32x2{0u, 0u};
+        *reinterpret_cast<u32x2*>(xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) = w2;
+      }
+  };
+
+  // ---- layer 0: x from HBM (the whole input exists, halo included) ------------------------------------------------------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xr[ct][r] = ldf(rs_x, vcol[ct], (32 * wave + acc_row0(r)) * rowT);
+      sk[ct][r] = 0.f;
+    }
+  {
+    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
+    const int hf = tid & 15, hc = tid >> 4;   // 16 halo frames x 32 chunks of 8 channels
+    const int th = hf < 8 ? t0 - HALO + hf : t0 + NT - 8 + hf;
+    const int hrow = hf < 8 ? hf : NT + hf;
+    const bool hok = th >= 0 && th < T;
+    float hv[8], hd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0);
+      hd[k] = ldf(rs_dp, (8 * hc + k) * 4, 0);
+    }
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = hok ? pack2(hv[2 * k] + hd[2 * k], hv[2 * k + 1] + hd[2 * k + 1]) : 0u;
+    *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = w;
+  }
+  load_cond(0);
+  write_core(0);
+
+#define STK_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int dil = 1 << (l % p.cycle);
+    const rsrc_t rs_a1 = mk_rsrc(p.apack1h + (long long)l * (2 * C * 3 * C), 2 * C * 3 * C * 2);
+    const rsrc_t rs_a2 = mk_rsrc(p.apack2h + (long long)l * (2 * C * C), 2 * C * C * 2);
+    const rsrc_t rs_bo = mk_rsrc(p.bias_out + (long long)l * (2 * C), 2 * C * 4);
+    bf16x8 Ag[NSS], Af[NSS];
+#pragma unroll
+    for (int k = 0; k < NSS; ++k) {
+      Ag[k] = lda8(rs_a1, vfrag, sa_g + k * KSB);
+      Af[k] = lda8(rs_a1, vfrag, sa_f + k * KSB);
+    }
+    __syncthreads();   // (A) xs of layer l complete (core + halo)
+    STK_STAMP(0);
+    // ---- GEMM1: 48 k-steps, tap-major --------------------------------------------------------------------------------
+    {
+      const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
+      auto ldb = [&](int ks, int ct) {
+        const int tap = ks >> 4, kc = ks & 15;
+        return *reinterpret_cast<const bf16x8*>(xb + ((tap - 1) * dil + 32 * ct) * ROWB + kc * 32);
+      };
+      mfma_pipe_bf8(yg0, yf0, yg1, yf1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 48, ldb);
+    }
+    STK_STAMP(1);
+    // ---- gate -> zs; GEMM2's first weights fly meanwhile -------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NSS; ++k) {
+      Ag[k] = lda8(rs_a2, vfrag, sb_r + k * KSB);
+      Af[k] = lda8(rs_a2, vfrag, sb_s + k * KSB);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const f32x16& yg = ct ? yg1 : yg0;
+      const f32x16& yf = ct ? yf1 : yf0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float z0 = fast_sigmoid(yg[4 * g]) * fast_tanh(yf[4 * g]), z1 = fast_sigmoid(yg[4 * g + 1]) * fast_tanh(yf[4 * g + 1]);
+        const float z2 = fast_sigmoid(yg[4 * g + 2]) * fast_tanh(yf[4 * g + 2]), z3 = fast_sigmoid(yg[4 * g + 3]) * fast_tanh(yf[4 * g + 3]);
+        *reinterpret_cast<u32x2*>(zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) = u32x2{pack2(z0, z1), pack2(z2, z3)};
+      }
+    }
+    // residual rows start from x + b_out, skip rows from b_out (the accumulators of GEMM1 are free now)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float br = ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
+      const float bs = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
+      yg0[r] = xr[0][r] + br;
+      yg1[r] = xr[1][r] + br;
+      yf0[r] = bs;
+      yf1[r] = bs;
+    }
+    __syncthreads();   // (B) zs complete; every wave is done reading xs
+    STK_STAMP(2);
+    // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows -----------------------------------------------------------
+    {
+      const char* zb = zs + l31 * ROWB + lh * 16;
+      auto ldb = [&](int ks, int ct) { return *reinterpret_cast<const bf16x8*>(zb + 32 * ct * ROWB + ks * 32); };
+      mfma_pipe_bf8(yg0, yf0, yg1, yf1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, ldb);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xr[0][r] = yg0[r] / 1.41421356237309504880f;   // (x + residual) / sqrt(2), net.py:78
+      xr[1][r] = yg1[r] / 1.41421356237309504880f;
+      sk[0][r] += yf0[r];
+      sk[1][r] += yf1[r];
+    }
+    STK_STAMP(3);
+    if (l + 1 == L) break;
+
+    // ---- next layer's image, edges for the neighbours, hand-off -----------------------------------------------------------
+    write_core(l + 1);
+    __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
+    STK_STAMP(4);
+    {
+      // publish the first and the last 8 frames (rows HALO .. HALO+7 and HALO+56 .. HALO+63): 2 x 8 x 512 B = 512 x 16 B, write-through
+      unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (2 * 8 * C);
+      const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (HALO + (side ? NT - 8 : 0) + f) * ROWB + c16 * 16);
+      if (!(p.inject && (tile_id & 1))) {
+        const rsrc_t rs_hx = mk_rsrc(hx_t, 2 * 8 * C * 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_hx, ((side * 8 + f) * C + c16 * 8) * 2, 0, 16);   // sc1
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (C)
+    STK_STAMP(5);
+    load_cond(l + 1);   // 64 KB per tile, independent of the neighbours: lands while we wait
+    if (tid == 0) {
+      const unsigned want = p.fbase + (unsigned)(l + 1);
+      __hip_atomic_store(p.flags + tile_id, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !has_left : !has_right) continue;
+        const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
+        if (p.inject) { atomicAdd(p.status, 1u); continue; }
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
+            atomicAdd(p.status, 1u);
+            break;
+          }
+        }
+      }
+      if (p.stamps) p.stamps[((long long)tile_id * L + l) * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // neighbours' flags seen
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();   // (D)
+    STK_STAMP(7);
+    {
+      // halo rows of the next layer: rows 0..7 = the left neighbour's last 8 frames, rows 72..79 = the right neighbour's first 8
+      const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+      const bool have = side == 0 ? has_left : has_right;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (have) {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(p.hx) +
+                                    ((long long)((l + 1) & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (2 * 8 * C) +
+                                    ((side == 0 ? 8 : 0) + f) * C + c16 * 8;
+        v = *reinterpret_cast<const u32x4*>(src);
+      }
+      *reinterpret_cast<u32x4*>(xs + ((side ? HALO + NT : 0) + f) * ROWB + c16 * 16) = v;
+    }
+  }
+#undef STK_STAMP
+  // ---- the skip sum / sqrt(L) (net.py:126), fp32, stored once -------------------------------------------------------------
+  {
+    const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
+    const float div = sqrtf((float)L);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+      if (col_ok[ct]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stf(sk[ct][r] / div, rs_sk, vst[ct], (32 * wave + acc_row0(r)) * rowT);
+      }
+  }
+}
+
 __global__ void f32_to_quad_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int rows, int T) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y, b = blockIdx.z;
   if (t >= T) return;
@@ -349,6 +632,22 @@ int pack_a_frag_bf16(const float* src, unsigned short* out, int M, int K, int Kc
   const long long total = (long long)M * K;
   hipLaunchKernelGGL(pack_a_frag_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, reinterpret_cast<__bf16*>(out), M, K,
                      Kc, sm, sc, stp);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+int stack_bf16_occupancy() {
+  const size_t lds = XS_BYTES + ZS_BYTES;
+  int o = 0;
+  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel, 512, lds) != hipSuccess)
+    return 0;
+  return o;
+}
+
+int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st) {
+  const size_t lds = XS_BYTES + ZS_BYTES;
+  hipLaunchKernelGGL(residual_stack_bf16_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

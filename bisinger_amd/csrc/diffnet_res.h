@@ -31,6 +31,34 @@ struct ResArgs {
   unsigned long long* stamps;  // diagnostic build only (STAMP = true): [workgroup][wave][8] s_memtime values
 };
 
+// arguments of the stack launches (all L layers of a group of rows in one launch, residual stream on chip):
+// residual_stack_kernel (diffnet.hip, fp32) and residual_stack_bf16_kernel (diffnet_bf16.hip)
+struct StackArgs {
+  const float* x_in;      // [B][C][T] in-projected x of this launch's rows
+  float* skip;            // [B][C][T] output: skip sum / sqrt(L)
+  const float* condterm;  // layer 0, this launch's rows: [B][2C][T]; + l * ct_stride for layer l
+  const float* dproj;     // [S][L][C]
+  const long long* t_dev; // [B] or null
+  const float* apackw;    // layer 0; + l * aw_stride
+  const unsigned short* apack1h;     // bf16 form: dilated conv fragments, layer 0; + l * 2C*3C
+  const unsigned short* apack2h;     // bf16 form: output projection fragments, layer 0; + l * 2C*C
+  const unsigned short* condterm_h;  // bf16 form: conditioner term in channel-quad order, layer 0 / this launch's rows; + l * ct_stride
+  const float* apack2;    // layer 0; + l * a2_stride
+  const float* bias_out;  // layer 0; + l * 2C
+  long long ct_stride;
+  float* hx;              // [2 parities][n_tiles][2 sides][C][8] edge exchange
+  unsigned* flags;        // [n_tiles]
+  unsigned* status;       // += 1 for every spin that gave up
+  int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
+  unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
+  int inject;             // fault injection: consumers do not wait
+  unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
+};
+
+// bf16 stack launch: 64-frame tiles, one workgroup per CU (see diffnet_bf16.hip); grid = p.n_tiles rounded up to 8
+int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st);
+int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf16_kernel (0 on error)
+
 // bf16-operand form of the residual layer (diffnet_bf16.hip); same tensors, 64-frame tiles
 int launch_residual_layer_bf16(const ResArgs& a, hipStream_t st);
 // fp32 [M][K] weights -> bf16 A fragments of v_mfma_f32_32x32x16_bf16 (see diffnet_bf16.hip)

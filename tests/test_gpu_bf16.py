@@ -115,3 +115,49 @@ def test_sampler_bf16_deviation():
     print(f'100-step sampler, bf16 operands vs fp32: max abs {dev:.3e}, rms {rms:.3e} (normalised mel in [-1, 1])')
     assert torch.isfinite(res['bf16']).all()
     assert dev <= 0.1 and rms <= 0.02
+
+
+def test_bf16_stack_launch_matches_per_layer_launches(tmp_path):
+    """BSG_STACK_BF16=1: all 20 layers of the bf16 configuration in one launch (x in registers, fp32 skip sum, edges exchanged
+    between neighbour tiles) against one launch per layer.  The stack form never rounds the running skip sum to bf16, so
+    the two differ by that rounding (not bit-identical); both must sit within bf16 noise of each other, repeat bit for bit,
+    and report no hand-off give-ups.  Two launch groups at (40, 640): 10 tiles per row, 25 rows per group."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, hashlib, torch, numpy as np
+sys.path.insert(0, %r)
+from tests.util import load_formula_weights, use_config
+from bisinger_amd import synth
+torch.set_grad_enabled(False)
+use_config()
+from bisinger_amd.diffnet import DiffNet
+net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+net.set_compute('bf16')
+out = {}
+for B, T in ((16, 1000), (40, 640), (3, 77)):
+    g = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 1, 80, T, generator=g).cuda(); cond = torch.randn(B, 256, T, generator=g).cuda()
+    t = (torch.arange(B) * 7 %% 100).cuda()
+    e1 = net(x, t, cond).clone(); e2 = net(x, t, cond).clone()
+    out[f'{B}x{T}'] = {'same': bool(torch.equal(e1, e2)), 'path': net.last_path(), 'finite': bool(torch.isfinite(e1).all())}
+    np.save(sys.argv[1] + f'.{B}x{T}.npy', e1.cpu().numpy())
+out['timeouts'] = net.handoff_timeouts()
+print(json.dumps(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for mode in ('0', '1'):
+        env = dict(os.environ, BSG_STACK_BF16=mode)
+        o = subprocess.run([sys.executable, '-c', code, str(tmp_path / f'm{mode}')], env=env, capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        res[mode] = json.loads(o.stdout.strip().splitlines()[-1])
+    assert res['1']['timeouts'] == 0
+    for k in ('16x1000', '40x640', '3x77'):
+        assert res['1'][k]['path'] == 'stack_bf16' and res['0'][k]['path'] == 'bf16'
+        assert res['1'][k]['same'] and res['1'][k]['finite'] and res['0'][k]['same']
+        a = np.load(str(tmp_path / f'm0.{k}.npy')); b = np.load(str(tmp_path / f'm1.{k}.npy'))
+        dev, rms = float(np.abs(a - b).max()), float(np.sqrt(((a - b) ** 2).mean()))
+        print(f'bf16 stack vs per-layer {k}: max-abs {dev:.2e}, rms {rms:.2e}')
+        assert dev <= 2e-2 and rms <= 2e-3

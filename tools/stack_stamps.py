@@ -19,20 +19,24 @@ B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 1000)
 dev = torch.device('cuda', 0)
 m = bench.build_model(dev)
 net = m.denoise_fn
+DT = os.environ.get('PD', 'fp32')
+net.set_compute(DT)
+NTILE = 64 if DT == 'bf16' else 32
 cond = torch.randn(B, 256, T, device=dev)
 x = torch.randn(B, 1, 80, T, device=dev)
 t = torch.full((B,), 50, device=dev, dtype=torch.long)
 for _ in range(3):
     net(x, t, cond)          # binds, fills xa, warms up
 torch.cuda.synchronize()
-tiles, L = B * ((T + 31) // 32), 20
+tiles, L = B * ((T + NTILE - 1) // NTILE), 20
 st = torch.zeros(tiles * L * 8, dtype=torch.int64, device=dev)
 for rep in range(3):
     st.zero_()
     _lib.check(_lib.load().bsg_diffnet_debug_stack_stamps(net._h, 50, B, T, _lib.ptr(st), _lib.stream_ptr()), 'stamps')
     torch.cuda.synchronize()
 s = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64) / 100.0      # us
-names = ['GEMM1 (A->1)', 'gate+z+barrier (1->2)', 'GEMM2 residual (2->3)', 'publish+GEMM2 skip (3->4)', 'drain+barrier C (4->5)',
+names = ['GEMM1 (A->1)', 'gate+z+barrier (1->2)', 'GEMM2 residual (2->3)' if DT != 'bf16' else 'GEMM2 (2->3)',
+         'publish+GEMM2 skip (3->4)' if DT != 'bf16' else 'core image + barrier C1 (3->4)', 'drain+barrier C (4->5)',
          'flag wait (5->6)', 'acquire+barrier D (6->7)', 'halo load+barrier A (7->0 next)']
 inner = s[:, 1:L - 1]                                                          # layers with all 8 stamps and a successor
 d = [inner[:, :, i + 1] - inner[:, :, i] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
@@ -44,7 +48,7 @@ for n, v in zip(names, d):
 a10 = s[:, 10, 0] - s[:, 10, 0].min()
 print(f'  start of layer 10 over tiles: spread {a10.max():.1f} us, std {a10.std():.1f}; first half of the grid {a10[:tiles // 2].mean():.1f}, '
       f'second half {a10[tiles // 2:].mean():.1f}')
-tpr = (T + 31) // 32
+tpr = (T + NTILE - 1) // NTILE
 rows = s[:, 10, 0].reshape(B, tpr) - s[:, 10, 0].min()
 print('  per-row start of layer 10 (us):', ' '.join(f'{v:.0f}' for v in rows.mean(1)))
 print('  per-row end of last layer (us): ', ' '.join(f'{v:.0f}' for v in (s[:, L - 1, 4].reshape(B, tpr) - s[:, 0, 0].min()).mean(1)))
