@@ -43,6 +43,10 @@ FLOP_PER_FRAME_LAYER_EXEC = 2 * (4 * 256 * 256 + 512 * 256)   # Winograd F(2,3):
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0                                 # MI355X_MICROARCH.md, HBM3E spec (achievable ~6.3 TB/s)
 HBM_BYTES_PER_FRAME_LAYER_BF16 = 4 * 256 * 4          # bf16 config: x in + x out fp32 (2 KB), conditioner term bf16 (1 KB), skip sum bf16 r+w (1 KB)
+# the stack launch (all 20 layers in one kernel, x and skip on chip): conditioner term bf16 (1 KB) + x in and skip out fp32 once per 20
+# layers (2 KB / 20) + the two 8-frame bf16 edges written and read per 64-frame tile (2 x 8 KB / 64)
+HBM_BYTES_PER_FRAME_LAYER_BF16_STACK = 1024 + 2048 / 20 + 2 * 8192 / 64
+PEAK_BF16_MFMA_TFLOPS = 2516.0                         # MI355X_MICROARCH.md, dense bf16
 HIFIGAN_FLOP_PER_FRAME = 38.51e6
 B_CFG1, B_CFG3_TOTAL, T_FRAMES, T_TXT, N_MEL, N_DIFF_STEPS = 16, 64, 1000, 100, 80, 100
 
@@ -217,7 +221,7 @@ def traffic_from_profiles(bf16, frames_per_launch):
     return None
 
 
-def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu):
+def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
     """Roofline object of the dominant kernel from the live HIP-event timing of its launches."""
     if not n_layer:
         return None
@@ -234,6 +238,18 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu):
               'concurrent_launches': concurrent, 'traffic': traffic,
               'traffic_condition': 'solo-launch PMC: rocprofv3 --pmc serialises kernels, so these are the HBM-side bytes (2 x FETCH_SIZE + '
                                    'WRITE_SIZE, MI355X_MICROARCH.md) of one launch running alone, not of two chains in flight'}
+    if bf16 and path == 'stack_bf16':
+        # one launch = all 20 layers of up to 256 64-frame tiles; the timed region is the launch group of one DiffNet evaluation and
+        # n_layer counts its layers, so avg_ms is the time of one layer over all rows.  1,048,576 FLOP / 1.38 KB = 760 FLOP/B is
+        # above the ridge (312 FLOP/B): matrix-pipe bound
+        by = HBM_BYTES_PER_FRAME_LAYER_BF16_STACK * frames_per_launch
+        return dict(common, kernel='residual_stack_bf16_kernel (20 fused DiffNet residual blocks per launch, bf16 MFMA operands; figures per layer)',
+                    bound='mfma', achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_BF16_MFMA_TFLOPS,
+                    flop_per_layer=FLOP_PER_FRAME_LAYER * frames_per_launch, hbm_bytes_per_layer=by,
+                    hbm_gbs=by * concurrent / (avg_ms * 1e-3) / 1e9, hbm_frac=by * concurrent / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    traffic_over_algorithmic=traffic / by if traffic else None,
+                    note='achieved = algorithmic FLOPs of one layer over the batch / (launch-group duration / 20 layers), HIP events around '
+                         'the launch group on its own stream')
     if bf16:
         # 16x the fp32 MFMA rate moves the layer under the HBM roof: AI = 1,048,576 FLOP / 4 KB = 256 FLOP/B against a
         # ridge of 2,500 TFLOP/s / 8 TB/s = 312 FLOP/B
@@ -242,7 +258,7 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu):
                     achieved=ach_gbs, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach_gbs / PEAK_HBM_GBS,
                     bytes_per_launch=HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch,
                     traffic_over_algorithmic=traffic / (HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch) if traffic else None,
-                    mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2516.0,
+                    mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / PEAK_BF16_MFMA_TFLOPS,
                     note='achieved = algorithmic bytes of one launch / its average duration (HIP events on its own stream) x launches in flight')
     wino = os.environ.get('BSG_WINO', '1') != '0'
     executed = achieved * (FLOP_PER_FRAME_LAYER_EXEC / FLOP_PER_FRAME_LAYER if wino else 1.0)
@@ -307,6 +323,7 @@ def secondary_bf16(model, device, fence):
         wl = Workload(model, device, 64, 0, 1)
         dt, layer_ms, n_layer, mel = timed(wl, 3, 1, fence)
         ok = bool(torch.isfinite(mel).all())
+        path = net.last_path()
     finally:
         net.set_compute('fp32')
     del wl
@@ -314,7 +331,8 @@ def secondary_bf16(model, device, fence):
     return {'config': {'workload': 'BASELINE.json configs[2]: B=64 x T=1000 x 80-mel, FS2-MIDI enc+dec + 100-step DDPM sampler, bf16 MFMA '
                                    'operands / fp32 accumulate in the residual layers (FS2, projections, sampler fp32)'},
             'dtype': 'bf16', 'metric': 'mel_frames_per_sec', 'value': 64 * T_FRAMES * 3 / dt, 'unit': 'mel-frames/s',
-            'steps': 3, 'warmup': 1, 'ms_per_step': dt / 3 * 1e3, 'finite': ok, 'roofline': roofline(True, layer_ms, n_layer, 3, 64)}
+            'steps': 3, 'warmup': 1, 'ms_per_step': dt / 3 * 1e3, 'finite': ok, 'path': path,
+            'roofline': roofline(True, layer_ms, n_layer, 3, 64, path)}
 
 
 def secondary_e2e(model, device, fence):
@@ -503,7 +521,7 @@ def main():
                                       if bf16 else 'fp32') + ', formula weights',
                        'global_batch': B_total, 'utterances_per_gpu': wl.b_local, 'frames_per_utt': T_FRAMES, 'diffusion_steps': N_DIFF_STEPS,
                        'parallelism': f'utterance-sharded x{world}, one RCCL all-gather of the mels per pass' if world > 1 else 'single GPU'},
-            'roofline': roofline(bf16, layer_ms, n_layer, args.steps, wl.b_local),
+            'roofline': roofline(bf16, layer_ms, n_layer, args.steps, wl.b_local, model.denoise_fn.last_path()),
             'handoff_timeouts': timeouts,
         }
         if use_dist:

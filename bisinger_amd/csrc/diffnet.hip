@@ -28,6 +28,7 @@
 
 #include "bsg_common.h"
 #include "diffnet_res.h"
+#include "diffnet_tail.h"
 
 namespace bsg {
 
@@ -982,39 +983,6 @@ __global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
 // ------------------------------------------------------------------------------------------------
 // sampler: one ancestral step, elementwise over [B][M][T]   (shallow_diffusion_tts.py:134-166)
 // ------------------------------------------------------------------------------------------------
-struct Philox {
-  unsigned c[4];
-};
-__device__ __forceinline__ Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53ull;
-    const unsigned long long p1 = (unsigned long long)c2 * 0xCD9E8D57ull;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
-    const unsigned n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
-    const unsigned n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return Philox{{c0, c1, c2, c3}};
-}
-// element i of stream `stream` = lane i%4 of counter (i/4, stream, 0, 0); Box-Muller on (0,1),(2,3)
-// — the layout bisinger_amd/synth.py:philox_normal reproduces on the host.
-__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned stream, unsigned long long quad) {
-  const Philox r = philox4x32_10((unsigned)quad, stream, 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32));
-  float u[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = fminf(((float)r.c[i] + 1.0f) * 2.3283064365386963e-10f, 1.0f);
-  const float r0 = sqrtf(-2.0f * logf(u[0])), r1 = sqrtf(-2.0f * logf(u[2]));
-  const float a0 = 6.283185307179586f * u[1], a1 = 6.283185307179586f * u[3];
-  return f32x4{r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
-}
-
-struct StepCoef {
-  float recip, recipm1, pc1, pc2, sigma;
-};
-
 __global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                                  StepCoef k, long long n4, unsigned long long seed, unsigned stream,
                                  unsigned long long quad0) {
@@ -1047,62 +1015,6 @@ __global__ void ddpm_step_kernel(float* __restrict__ x, const float* __restrict_
 // Replaces three GEMM launches + the sampler launch per step (~150 us -> ~20 us at B=16, T=1000): the three
 // projections are too small (0.04-0.13 MFLOP/frame) to fill the chip as separate 128x128-tile GEMMs.
 // ------------------------------------------------------------------------------------------------
-struct PlmsCoef {
-  float a_t, a_prev;
-  float w0, w1, w2, w3, inv;  // eps' = (w0*e0 + w1*e1 + w2*e2 + w3*e3) / inv
-};
-
-// p_sample_plms update of one element, shared by plms_step_kernel and the fused tail (same rounding sequence in both)
-__device__ __forceinline__ float plms_update(float x, float e0, float e1, float e2, float e3, int n_hist, const PlmsCoef& k, float* ep_out) {
-  float ep = e0;
-  if (n_hist > 0) {   // multistep blends, evaluated left to right like the reference expressions
-    if (n_hist >= 3) ep = __fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0), __fmul_rn(-k.w1, e1)), __fmul_rn(k.w2, e2)), __fmul_rn(-k.w3, e3));
-    else if (n_hist == 2) ep = __fadd_rn(__fsub_rn(__fmul_rn(k.w0, e0), __fmul_rn(-k.w1, e1)), __fmul_rn(k.w2, e2));
-    else if (k.w0 == 1.0f) ep = __fadd_rn(e0, e1);                       // (eps + eps_prev) / 2
-    else ep = __fsub_rn(__fmul_rn(k.w0, e0), e1);                        // (3*eps - h[-1]) / 2
-    ep = ep / k.inv;
-  }
-  const float a_t = k.a_t, a_prev = k.a_prev;
-  const float a_t_sq = sqrtf(a_t), a_prev_sq = sqrtf(a_prev);
-  const float cx = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(a_t_sq, a_prev_sq));
-  const float ce = 1.0f / __fmul_rn(a_t_sq, __fadd_rn(sqrtf(__fmul_rn(__fsub_rn(1.0f, a_prev), a_t)),
-                                                       sqrtf(__fmul_rn(__fsub_rn(1.0f, a_t), a_prev))));
-  const float xd = __fmul_rn(__fsub_rn(a_prev, a_t), __fsub_rn(__fmul_rn(cx, x), __fmul_rn(ce, ep)));
-  if (ep_out) *ep_out = ep;
-  return __fadd_rn(x, xd);
-}
-
-struct TailArgs {
-  const float* skip;    // [B][C][T]
-  const unsigned short* skip_h;  // bf16 mode: [B][C/4][T][4] instead of `skip`
-  float* x;             // [B][M][T] in/out
-  const float* noise;   // [B][M][T] or null (Philox)
-  float* xa_next;       // [B][C][T]
-  const float* ws_pack; // [8][32][64][4]
-  const float* wo_pack; // [3][32][64][4]  (rows >= M are zero)
-  const float* wi_pack; // [8][MP/8][64][4]
-  const float* b_skip;  // [C]
-  const float* b_fin;   // [96] (zero padded)
-  const float* b_in;    // [C]
-  StepCoef k;
-  unsigned long long seed, quad_row0;   // Philox: key, and the flat element index of this shard's row 0
-  unsigned stream;
-  int B, T, M, tiles_per_row, do_head;
-  // PLMS form (plms_hist > 0): eps is stored to e_new and x <- p_sample_plms(x, eps, history)   (shallow_diffusion_tts.py:168-201)
-  int plms_hist;          // 0: DDPM ancestral update; 1..3: number of history entries blended
-  PlmsCoef pk;
-  float* e_new;           // [B][M][T]
-  const float* h1;        // newest history entry, then older
-  const float* h2;
-  const float* h3;
-};
-
-__device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigned stream, unsigned long long idx) {
-  const f32x4 z = philox_normal4(seed, stream, idx >> 2);
-  const int s = (int)(idx & 3);
-  return s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3];
-}
-
 #define BSG_MFMA4(ACC, A_, B_)                                                \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[0], B_[0], ACC, 0, 0, 0);      \
   ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[1], B_[1], ACC, 0, 0, 0);      \
@@ -1368,6 +1280,7 @@ struct bsg_diffnet {
   float* apackw = nullptr;  // [L][4*2C*C]  Winograd form of the dilated conv
   unsigned short* apack1h = nullptr;  // [L][2C*3C] bf16 fragments (bf16-operand form, diffnet_bf16.hip)
   unsigned short* apack2h = nullptr;  // [L][2C*C]
+  unsigned short* tail_h = nullptr;   // bf16 step tail (step_tail_bf16_kernel): skip projection [C*C], output projection [96*C], input projection [C*96]
   int compute = BSG_COMPUTE_F32;      // bsg_diffnet_set_compute
   unsigned short* condterm_h = nullptr;  // [L][B][2C/4][T][4] bf16 (bf16 mode only)
   unsigned short* skip_h = nullptr;      // [B][C/4][T][4] bf16
@@ -1410,7 +1323,6 @@ struct bsg_diffnet {
   unsigned stack_epoch = 0;
   int occ_stack = -1;                  // resident workgroups per CU of residual_stack_kernel (-1: not queried)
   int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
-  bool skip_is_f32 = false;            // bf16 mode: the last evaluation left the skip sum in h->skip as fp32 (stack launch), not in skip_h
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1459,6 +1371,7 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->condterm_h) (void)hipFree(h->condterm_h);
   if (h->skip_h) (void)hipFree(h->skip_h);
   if (h->apack2h) (void)hipFree(h->apack2h);
+  if (h->tail_h) (void)hipFree(h->tail_h);
   delete h;
 }
 
@@ -1550,7 +1463,7 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   if (rc == BSG_OK) rc = copy_dev(h->b_skip, tw[1], C, st);
   if (rc == BSG_OK) rc = copy_dev(h->w_fin, tw[2], (size_t)M * C, st);
   if (rc == BSG_OK) rc = copy_dev(h->b_fin, tw[3], M, st);
-  float *wo_pad = nullptr, *wi_pad = nullptr;
+  float *wo_pad = nullptr, *wi_pad = nullptr, *wi_pad96 = nullptr;
   if (rc == BSG_OK && M <= 96) {
     const int MP = (M + 7) / 8 * 8;
     h->MP = MP;
@@ -1569,12 +1482,25 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
       hipLaunchKernelGGL(pad_rows_kernel, dim3(1), dim3(256), 0, st, (const float*)tw[3], h->b_fin96, M, 96, 1, 1);
       if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: tail pack kernels failed"); rc = BSG_EHIP; }
     }
+    // the same three projections as bf16 fragments (bf16-operand configuration); the input projection's K is padded to 96
+    if (rc == BSG_OK) rc = dev_alloc(&wi_pad96, (size_t)C * 96);
+    if (rc == BSG_OK && hipMalloc((void**)&h->tail_h, (size_t)(C * C + 96 * C + C * 96) * sizeof(unsigned short)) != hipSuccess) {
+      set_error("diffnet_create: out of device memory");
+      rc = BSG_EHIP;
+    }
+    if (rc == BSG_OK) {
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(cdiv(C * 96, 256)), dim3(256), 0, st, (const float*)w[0], wi_pad96, C, C, M, 96);
+      rc = pack_a_frag_bf16((const float*)tw[0], h->tail_h, C, C, C, (long long)C, 1LL, 0LL, st);
+      if (rc == BSG_OK) rc = pack_a_frag_bf16(wo_pad, h->tail_h + C * C, 96, C, C, (long long)C, 1LL, 0LL, st);
+      if (rc == BSG_OK) rc = pack_a_frag_bf16(wi_pad96, h->tail_h + C * C + 96 * C, C, 96, 96, 96LL, 1LL, 0LL, st);
+    }
   }
   hipError_t e = hipStreamSynchronize(st);
   dev_free(hid);
   dev_free(dtab);
   dev_free(wo_pad);
   dev_free(wi_pad);
+  dev_free(wi_pad96);
   if (rc != BSG_OK) return rc;
   BSG_HIP(e);
   return BSG_OK;
@@ -1789,7 +1715,6 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     if (ext && !a.first) TRY(f32_to_quad_bf16(skip, h->skip_h, B, C, T, st));
     TRY(launch_residual_layer_bf16(a, st));
     h->last_path = "bf16";
-    h->skip_is_f32 = false;
     if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
     return BSG_OK;
   }
@@ -1883,13 +1808,13 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
   return BSG_OK;
 }
 
-// bf16-operand configuration: the stack launch (opt-in, BSG_STACK_BF16=1).  64-frame tiles, one workgroup per CU (256 registers per
-// wave), whole rows per launch group.  Measured at B=64, T=1000: 247 ms per pass against 243.5 ms for two chains of per-layer
-// launches: 25.9 us per layer and tile, of which 10.2 us are the two GEMMs — with one workgroup per CU nothing overlaps the gate
-// (6 us), the image / publish / flag / acquire / halo chain (9.7 us); DESIGN.md section 9.
+// bf16-operand configuration: the stack launch (the default; BSG_STACK_BF16=0 selects per-layer launches).  64-frame tiles, one
+// workgroup per CU (256 registers per wave), whole rows per launch group.  Measured on one box, ms per 100-step pass at T=1000,
+// stack / per-layer: B=1 43.2 / 56.4, B=16 58.2 / 87.8, B=32 109.7 / 133.3, B=64 213.8 / 237.3 (tools/bench_small.py with
+// BSG_DTYPE=bf16).  Per layer and tile ~21.5 us, of which the two GEMMs' MFMAs are ~7.
 static int stack_rows_bf16(bsg_diffnet* h, int B, int T, hipStream_t st) {
   static int env = -1;
-  if (env < 0) { const char* e = getenv("BSG_STACK_BF16"); env = e ? atoi(e) : 0; }
+  if (env < 0) { const char* e = getenv("BSG_STACK_BF16"); env = e ? atoi(e) : 1; }
   if (!env || h->compute != BSG_COMPUTE_BF16 || h->split_off || !h->num_cus || !h->hx) return 0;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (st) (void)hipStreamIsCapturing(st, &cap);
@@ -1913,6 +1838,7 @@ static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_unifo
     StackArgs p{};
     p.x_in = h->xa + row * C * T;
     p.skip = h->skip + row * C * T;
+    p.skip_h = h->skip_h + row * C * T;
     p.condterm_h = h->condterm_h + row * 2 * C * T;
     p.dproj = h->dproj; p.t_dev = t_dev ? t_dev + r0 : nullptr; p.t_uniform = t_uniform;
     p.apack1h = h->apack1h; p.apack2h = h->apack2h; p.bias_out = h->b_out;
@@ -1928,7 +1854,6 @@ static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_unifo
     TRY(launch_residual_stack_bf16(p, st));
   }
   h->last_path = "stack_bf16";
-  h->skip_is_f32 = true;
   return BSG_OK;
 }
 
@@ -1970,7 +1895,7 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
     h->prof_used += 2;
     h->prof_launches += h->L;
   }
-  if (h->compute == BSG_COMPUTE_BF16 && !h->skip_is_f32) TRY(quad_bf16_to_f32(h->skip_h, h->skip, B, C, T, st));
+  if (h->compute == BSG_COMPUTE_BF16) TRY(quad_bf16_to_f32(h->skip_h, h->skip, B, C, T, st));
   TRY(conv1x1(h->w_skip, h->b_skip, h->skip, h->hid, C, C, B, T, ACT_RELU, st));   // net.py:127-128
   TRY(conv1x1(h->w_fin, h->b_fin, h->hid, eps, h->M, C, B, T, ACT_NONE, st));      // net.py:129
   return BSG_OK;
@@ -2046,10 +1971,15 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
     tail_attr = true;
   }
   const size_t off = (size_t)h->row_off * C * T;
-  a.skip = h->skip + off; a.skip_h = h->compute == BSG_COMPUTE_BF16 && !h->skip_is_f32 ? h->skip_h + off : nullptr;
+  a.skip = h->skip + off; a.skip_h = h->compute == BSG_COMPUTE_BF16 ? h->skip_h + off : nullptr;
   a.x = x; a.xa_next = h->xa + off;
   a.ws_pack = h->ws_pack; a.wo_pack = h->wo_pack; a.wi_pack = h->wi_pack; a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
   a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32);
+  const char* tail_env = getenv("BSG_TAIL_BF16");   // "0": the fp32 tail also in the bf16-operand configuration
+  if (h->compute == BSG_COMPUTE_BF16 && !(tail_env && atoi(tail_env) == 0) && h->tail_h) {   // bf16-operand configuration: the projections on bf16 MFMAs too
+    a.ws_h = h->tail_h; a.wo_h = h->tail_h + C * C; a.wi_h = h->tail_h + C * C + 96 * C;
+    return launch_step_tail_bf16(a, st);
+  }
   const dim3 grid(B * a.tiles_per_row), block(512);
   if (a.plms_hist) {
     if (h->MP == 80) hipLaunchKernelGGL((step_tail_kernel<80, true>), grid, block, tail_lds, st, a);

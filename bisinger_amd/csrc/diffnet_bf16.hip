@@ -25,6 +25,7 @@
 //   GEMM2  o = W_out * z, 16 k-steps; residual rows start from x + b_out, skip rows from b_out
 //   out    x_out = (x + res)/sqrt(2), skip += o_skip   (fp32, 128-B coalesced rows as in the fp32 kernel)
 #include "diffnet_res.h"
+#include "diffnet_tail.h"
 
 namespace bsg {
 
@@ -64,6 +65,14 @@ __device__ __forceinline__ bf16x8 lda8(rsrc_t r, int voff, int soff) {
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
   return __builtin_bit_cast(unsigned, bf16x2{(__bf16)lo, (__bf16)hi});
+}
+
+// sigmoid(g) * tanh(f) with two exponentials and ONE reciprocal: (1 - e^{-2f}) / ((1 + e^{-g}) (1 + e^{-2f})); f is clamped to +-15
+// (tanh = +-1 to 1e-13 there) so that e^{-2f} stays finite.  Used where the result is rounded to bf16 anyway.
+__device__ __forceinline__ float gate1(float g, float f) {
+  f = fminf(fmaxf(f, -15.0f), 15.0f);
+  const float eg = __expf(-g), ef = __expf(-2.0f * f);
+  return (1.0f - ef) * __frcp_rn((1.0f + eg) * (1.0f + ef));
 }
 
 #define BSG_MFMA_BF(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
@@ -334,27 +343,44 @@ __global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) 
 // ------------------------------------------------------------------------------------------------
 constexpr int NSS = 8;   // weight ring of the stack kernel (k-steps)
 
-template <typename LDB>
+// i-th executed k-step -> k-step index: GEMM1 (ROT = 16, 48 k-steps, tap-major) starts with the CENTRE tap, whose B operand is
+// the tile's own 64 frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
+template <int ROT>
+__device__ __forceinline__ int kmap(int i, int n_ks) {
+  if (ROT == 0) return i;
+  return i < ROT ? i + ROT : (i < 2 * ROT ? i - ROT : i);
+}
+// `mid()` runs after the first ROT k-steps have been issued (ROT = 0: never): the hand-off with the neighbours sits there, under
+// the centre tap's MFMAs; the ring keeps prefetching across it.
+template <int ROT, typename LDB, typename MID>
 __device__ __forceinline__ void mfma_pipe_bf8(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, bf16x8 (&A0)[NSS], bf16x8 (&A1)[NSS],
-                                              rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks, LDB ldb) {
+                                              rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks, LDB ldb, MID mid) {
   bf16x8 B0[2], B1[2];
-  B0[0] = ldb(0, 0);
-  B1[0] = ldb(0, 1);
+  B0[0] = ldb(kmap<ROT>(0, n_ks), 0);
+  B1[0] = ldb(kmap<ROT>(0, n_ks), 1);
   const int last = n_ks - 1;
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += NSS) {
+    if (ROT > 0 && ks == ROT) {
+      mid();
+      // the B operand of the next k-step was read before the halo rows arrived: read it again
+      B0[0] = ldb(kmap<ROT>(ks, n_ks), 0);
+      B1[0] = ldb(kmap<ROT>(ks, n_ks), 1);
+    }
 #pragma unroll
     for (int s = 0; s < NSS; ++s) {
-      const int kn = ks + s + 1 <= last ? ks + s + 1 : last;
-      B0[(s + 1) & 1] = ldb(kn, 0);
-      B1[(s + 1) & 1] = ldb(kn, 1);
+      const int in = ks + s + 1 <= last ? ks + s + 1 : last;
+      // never read across the hand-off: the k-step after the centre tap is re-read above
+      B0[(s + 1) & 1] = ldb(kmap<ROT>(in, n_ks), 0);
+      B1[(s + 1) & 1] = ldb(kmap<ROT>(in, n_ks), 1);
       __builtin_amdgcn_sched_barrier(0);
       BSG_MFMA_BF(c00, A0[s], B0[s & 1]);
       BSG_MFMA_BF(c10, A1[s], B0[s & 1]);
       BSG_MFMA_BF(c01, A0[s], B1[s & 1]);
       BSG_MFMA_BF(c11, A1[s], B1[s & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      const int kr = ks + s + NSS <= last ? ks + s + NSS : last;
+      const int ir = ks + s + NSS <= last ? ks + s + NSS : last;
+      const int kr = kmap<ROT>(ir, n_ks);
       A0[s] = lda8(rs, vfrag, sa0 + kr * KSB);
       A1[s] = lda8(rs, vfrag, sa1 + kr * KSB);
       __builtin_amdgcn_sched_barrier(0);
@@ -366,6 +392,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* xs = lds_raw;              // [80 frames][528 B]: bf16(x + d_l), frames t0-8 .. t0+71
   char* zs = lds_raw + XS_BYTES;   // [64 frames][528 B]: gated activation
+  float* dtab = reinterpret_cast<float*>(lds_raw + XS_BYTES + ZS_BYTES);   // [256]: d_{l+1} per channel, fetched a layer ahead
+  float* btab = dtab + C;                                                     // [512]: output-projection bias of the current layer
 
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -399,14 +427,23 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
   float sk[2][16];        // running skip sum (fp32), same layout (skip rows C + 32w + ..)
   f32x16 yg0, yf0, yg1, yf1;   // GEMM1 accumulators; they start from the conditioner term
 
-  auto load_cond = [&](int l) {
+  // the conditioner term of a layer: requested (16 x 8 B per lane) a phase before it is needed, unpacked into the accumulators at the
+  // top of the layer — the unpack is the first use, so no wait for HBM sits between the request and the barriers that follow it
+  u32x2 cr[16];
+  auto cond_request = [&](int l) {
     const rsrc_t rs_ct = mk_rsrc(p.condterm_h + (long long)l * p.ct_stride + (long long)b * 2 * C * T, plane);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x2 g0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (8 * wave + 2 * g) * T * 8, 0));
-      const u32x2 f0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
-      const u32x2 g1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (8 * wave + 2 * g) * T * 8, 0));
-      const u32x2 f1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+      cr[4 * g + 0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (8 * wave + 2 * g) * T * 8, 0));
+      cr[4 * g + 1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+      cr[4 * g + 2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (8 * wave + 2 * g) * T * 8, 0));
+      cr[4 * g + 3] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+    }
+  };
+  auto cond_unpack = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 g0 = cr[4 * g], f0 = cr[4 * g + 1], g1 = cr[4 * g + 2], f1 = cr[4 * g + 3];
       yg0[4 * g] = bf16_lo(g0[0]); yg0[4 * g + 1] = bf16_hi(g0[0]); yg0[4 * g + 2] = bf16_lo(g0[1]); yg0[4 * g + 3] = bf16_hi(g0[1]);
       yf0[4 * g] = bf16_lo(f0[0]); yf0[4 * g + 1] = bf16_hi(f0[0]); yf0[4 * g + 2] = bf16_lo(f0[1]); yf0[4 * g + 3] = bf16_hi(f0[1]);
       yg1[4 * g] = bf16_lo(g1[0]); yg1[4 * g + 1] = bf16_hi(g1[0]); yg1[4 * g + 2] = bf16_lo(g1[1]); yg1[4 * g + 3] = bf16_hi(g1[1]);
@@ -414,11 +451,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
     }
   };
   // xs core (frames t0 .. t0+63, this wave's 32 channels) = bf16(x + d_l), zero beyond T (the conv pads x + d)
-  auto write_core = [&](int l) {
-    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + l) * C, C * 4);
+  auto write_core = [&]() {   // d of the layer being prepared is in dtab (written a phase earlier, behind a barrier)
     float dv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dv[r] = ldf(rs_dp, lh * 16, (32 * wave + acc_row0(r)) * 4);
+    for (int r = 0; r < 16; ++r) dv[r] = dtab[32 * wave + acc_row(r, lh)];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -455,8 +491,23 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
     for (int k = 0; k < 4; ++k) w[k] = hok ? pack2(hv[2 * k] + hd[2 * k], hv[2 * k + 1] + hd[2 * k + 1]) : 0u;
     *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = w;
   }
-  load_cond(0);
-  write_core(0);
+  if (tid < C) dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
+  btab[tid] = p.bias_out[tid];
+  cond_request(0);
+  __syncthreads();
+  write_core();
+  // weight ring, shared by both GEMMs.  GEMM1's first k-steps (it starts with the centre tap: kmap) are requested a phase ahead —
+  // right behind the previous layer's GEMM2 — so that the L2 latency of the weight stream is never on the layer's critical path
+  bf16x8 Ag[NSS], Af[NSS];
+  auto prefetch_a1 = [&](int l) {
+    const rsrc_t rs = mk_rsrc(p.apack1h + (long long)l * (2 * C * 3 * C), 2 * C * 3 * C * 2);
+#pragma unroll
+    for (int k = 0; k < NSS; ++k) {
+      Ag[k] = lda8(rs, vfrag, sa_g + kmap<16>(k, 48) * KSB);
+      Af[k] = lda8(rs, vfrag, sa_f + kmap<16>(k, 48) * KSB);
+    }
+  };
+  prefetch_a1(0);
 
 #define STK_STAMP(i)                                                                                              \
   do {                                                                                                            \
@@ -467,74 +518,115 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
     const int dil = 1 << (l % p.cycle);
     const rsrc_t rs_a1 = mk_rsrc(p.apack1h + (long long)l * (2 * C * 3 * C), 2 * C * 3 * C * 2);
     const rsrc_t rs_a2 = mk_rsrc(p.apack2h + (long long)l * (2 * C * C), 2 * C * C * 2);
-    const rsrc_t rs_bo = mk_rsrc(p.bias_out + (long long)l * (2 * C), 2 * C * 4);
-    bf16x8 Ag[NSS], Af[NSS];
-#pragma unroll
-    for (int k = 0; k < NSS; ++k) {
-      Ag[k] = lda8(rs_a1, vfrag, sa_g + k * KSB);
-      Af[k] = lda8(rs_a1, vfrag, sa_f + k * KSB);
-    }
-    __syncthreads();   // (A) xs of layer l complete (core + halo)
+    const float dnext = (tid < C && l + 1 < L) ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;   // lands during GEMM1
+    const float bnext = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
+    cond_unpack();
+    if (l == 0) __syncthreads();   // layer 0: the staged image (core + halo rows); later layers: barrier (C) below covers the core rows
     STK_STAMP(0);
-    // ---- GEMM1: 48 k-steps, tap-major --------------------------------------------------------------------------------
+    // ---- GEMM1: 48 k-steps.  The centre tap (16 k-steps) reads the tile's own frames only, so it runs while the neighbours'
+    // edges of this layer are still in flight; the wait for them, and the copy of the halo rows, sit behind it (mid) -------------
     {
       const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
       auto ldb = [&](int ks, int ct) {
         const int tap = ks >> 4, kc = ks & 15;
         return *reinterpret_cast<const bf16x8*>(xb + ((tap - 1) * dil + 32 * ct) * ROWB + kc * 32);
       };
-      mfma_pipe_bf8(yg0, yf0, yg1, yf1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 48, ldb);
+      auto mid = [&]() {
+        if (l == 0) return;   // layer 0 staged its halo rows from HBM
+        if (tid == 0) {
+          const unsigned want = p.fbase + (unsigned)l;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? !has_left : !has_right) continue;
+            const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
+            if (p.inject) { atomicAdd(p.status, 1u); continue; }
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
+                atomicAdd(p.status, 1u);
+                break;
+              }
+            }
+          }
+        }
+        __syncthreads();   // (D) the polling wave has seen both flags
+        STK_STAMP(1);
+        {
+          // halo rows of this layer: rows 0..7 = the left neighbour's last 8 frames, rows 72..79 = the right neighbour's first 8
+          const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+          const bool have = side == 0 ? has_left : has_right;
+          u32x4 v = u32x4{0u, 0u, 0u, 0u};
+          if (have) {
+            // write-through (sc1) stores, drained before the flag, one workgroup per CU, and EVERY load of the handed-off bytes an
+            // sc1 buffer load to registers: the hand-off form that needs no agent-scope acquire (MI355X_MICROARCH.md, "Valid
+            // forms") — an acquire would invalidate the CU's L1 (the weight stream's) every layer
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(p.hx) +
+                                        ((long long)(l & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (2 * 8 * C);
+            const rsrc_t rs_h = mk_rsrc(src, 2 * 8 * C * 2);
+            v = __builtin_amdgcn_raw_buffer_load_b128(rs_h, (((side == 0 ? 8 : 0) + f) * C + c16 * 8) * 2, 0, 16);   // sc1
+          }
+          *reinterpret_cast<u32x4*>(xs + ((side ? HALO + NT : 0) + f) * ROWB + c16 * 16) = v;
+        }
+        __syncthreads();   // (A) halo rows in place
+        STK_STAMP(2);
+      };
+      mfma_pipe_bf8<16>(yg0, yf0, yg1, yf1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid);
     }
-    STK_STAMP(1);
+    STK_STAMP(3);
     // ---- gate -> zs; GEMM2's first weights fly meanwhile -------------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < NSS; ++k) {
       Ag[k] = lda8(rs_a2, vfrag, sb_r + k * KSB);
       Af[k] = lda8(rs_a2, vfrag, sb_s + k * KSB);
     }
+    if (tid < C) dtab[tid] = dnext;   // read by write_core() behind barrier (B)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const f32x16& yg = ct ? yg1 : yg0;
       const f32x16& yf = ct ? yf1 : yf0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float z0 = fast_sigmoid(yg[4 * g]) * fast_tanh(yf[4 * g]), z1 = fast_sigmoid(yg[4 * g + 1]) * fast_tanh(yf[4 * g + 1]);
-        const float z2 = fast_sigmoid(yg[4 * g + 2]) * fast_tanh(yf[4 * g + 2]), z3 = fast_sigmoid(yg[4 * g + 3]) * fast_tanh(yf[4 * g + 3]);
+        const float z0 = gate1(yg[4 * g], yf[4 * g]), z1 = gate1(yg[4 * g + 1], yf[4 * g + 1]);
+        const float z2 = gate1(yg[4 * g + 2], yf[4 * g + 2]), z3 = gate1(yg[4 * g + 3], yf[4 * g + 3]);
         *reinterpret_cast<u32x2*>(zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) = u32x2{pack2(z0, z1), pack2(z2, z3)};
       }
     }
     // residual rows start from x + b_out, skip rows from b_out (the accumulators of GEMM1 are free now)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float br = ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
-      const float bs = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
+      const float br = btab[32 * wave + acc_row(r, lh)], bs = btab[C + 32 * wave + acc_row(r, lh)];
       yg0[r] = xr[0][r] + br;
       yg1[r] = xr[1][r] + br;
       yf0[r] = bs;
       yf1[r] = bs;
     }
-    __syncthreads();   // (B) zs complete; every wave is done reading xs
-    STK_STAMP(2);
+    __syncthreads();   // (B) zs complete; every wave is done reading xs and this layer's biases
+    btab[tid] = bnext;
+    STK_STAMP(4);
     // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows -----------------------------------------------------------
     {
       const char* zb = zs + l31 * ROWB + lh * 16;
       auto ldb = [&](int ks, int ct) { return *reinterpret_cast<const bf16x8*>(zb + 32 * ct * ROWB + ks * 32); };
-      mfma_pipe_bf8(yg0, yf0, yg1, yf1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, ldb);
+      mfma_pipe_bf8<0>(yg0, yf0, yg1, yf1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {});
     }
+    if (l + 1 < L) prefetch_a1(l + 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      xr[0][r] = yg0[r] / 1.41421356237309504880f;   // (x + residual) / sqrt(2), net.py:78
-      xr[1][r] = yg1[r] / 1.41421356237309504880f;
+      xr[0][r] = yg0[r] / 1.41421356237309504880f;   // (x + residual) / sqrt(2), net.py:78 (a product instead measured no faster: this
+      xr[1][r] = yg1[r] / 1.41421356237309504880f;   // phase waits for the SIMD's other wave to finish its MFMAs)
       sk[0][r] += yf0[r];
       sk[1][r] += yf1[r];
     }
-    STK_STAMP(3);
+    STK_STAMP(5);
     if (l + 1 == L) break;
 
-    // ---- next layer's image, edges for the neighbours, hand-off -----------------------------------------------------------
-    write_core(l + 1);
+    // ---- next layer: its conditioner term (64 KB per tile, the only big HBM stream) is requested into the free accumulators NOW, so
+    // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
+    cond_request(l + 1);
+    write_core();
     __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
-    STK_STAMP(4);
+    STK_STAMP(6);
     {
       // publish the first and the last 8 frames (rows HALO .. HALO+7 and HALO+56 .. HALO+63): 2 x 8 x 512 B = 512 x 16 B, write-through
       unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (2 * 8 * C);
@@ -545,58 +637,204 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
         __builtin_amdgcn_raw_buffer_store_b128(v, rs_hx, ((side * 8 + f) * C + c16 * 8) * 2, 0, 16);   // sc1
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores (and has its conditioner term)
     __syncthreads();   // (C)
-    STK_STAMP(5);
-    load_cond(l + 1);   // 64 KB per tile, independent of the neighbours: lands while we wait
-    if (tid == 0) {
-      const unsigned want = p.fbase + (unsigned)(l + 1);
-      __hip_atomic_store(p.flags + tile_id, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        if (side == 0 ? !has_left : !has_right) continue;
-        const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
-        if (p.inject) { atomicAdd(p.status, 1u); continue; }
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
-            atomicAdd(p.status, 1u);
-            break;
-          }
-        }
-      }
-      if (p.stamps) p.stamps[((long long)tile_id * L + l) * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // neighbours' flags seen
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();   // (D)
+    if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STK_STAMP(7);
-    {
-      // halo rows of the next layer: rows 0..7 = the left neighbour's last 8 frames, rows 72..79 = the right neighbour's first 8
-      const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
-      const bool have = side == 0 ? has_left : has_right;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (have) {
-        const unsigned short* src = reinterpret_cast<const unsigned short*>(p.hx) +
-                                    ((long long)((l + 1) & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (2 * 8 * C) +
-                                    ((side == 0 ? 8 : 0) + f) * C + c16 * 8;
-        v = *reinterpret_cast<const u32x4*>(src);
-      }
-      *reinterpret_cast<u32x4*>(xs + ((side ? HALO + NT : 0) + f) * ROWB + c16 * 16) = v;
-    }
   }
 #undef STK_STAMP
-  // ---- the skip sum / sqrt(L) (net.py:126), fp32, stored once -------------------------------------------------------------
+  // ---- the skip sum / sqrt(L) (net.py:126): rounded to bf16 ONCE (the per-layer kernel rounds the running sum after every layer) and
+  // stored in channel-quad order, the layout the bf16 step tail stages with 8-byte loads -----------------------------------------
   {
-    const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
+    const rsrc_t rs_sk = mk_rsrc(p.skip_h + (long long)b * C * T, plane / 2);
     const float div = sqrtf((float)L);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
       if (col_ok[ct]) {
+        const int vqs = (lh * T + t0 + 32 * ct + l31) * 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stf(sk[ct][r] / div, rs_sk, vst[ct], (32 * wave + acc_row0(r)) * rowT);
+        for (int g = 0; g < 4; ++g)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(sk[ct][4 * g] / div, sk[ct][4 * g + 1] / div), pack2(sk[ct][4 * g + 2] / div, sk[ct][4 * g + 3] / div)},
+                                                rs_sk, vqs, (8 * wave + 2 * g) * T * 8, 0);
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Step tail of the bf16-operand configuration, one 64-frame tile per workgroup (the fp32 tail, diffnet.hip step_tail_kernel, is the
+// model; same sampler arithmetic, shared through diffnet_tail.h):
+//   h    = relu(W_skip s + b)     s = skip sum / sqrt(L) as bf16 channel quads (written by the last layer)      (net.py:126-128)
+//   eps  = W_out h + b                                                                                          (net.py:129)
+//   x   <- p_sample(x, eps, noise) or p_sample_plms(x, eps, history), fp32                   (shallow_diffusion_tts.py:149-201)
+//   xa   = relu(W_in x + b)       the next evaluation's input projection, fp32 in HBM                           (net.py:116-118)
+// The three projections run on v_mfma_f32_32x32x16_bf16 with bf16 operands (weights rounded once at create; s, h and the updated
+// x rounded when they are staged) and fp32 accumulation; the sampler state x itself stays fp32.  At B=64, T=1000 the fp32 tail took
+// 214 us per step (64 TFLOP/s of fp32 MFMA, 10 % of the configuration's device time); this form is bound by its 2.2 KB per frame.
+// ------------------------------------------------------------------------------------------------
+constexpr int XIN_ROWB = 2 * 96 + 16;   // updated-x image row: 96 bf16 + 16 B pad = 208 B (52 dwords: conflict-free ds_read_b128)
+constexpr int TAIL_LDS = NT * ROWB + NT * XIN_ROWB;
+
+template <bool PLMS>
+__global__ __launch_bounds__(512, 4) void step_tail_bf16_kernel(TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* ss = lds_raw;               // [64 frames][528 B]: s, then h
+  char* xin = lds_raw + NT * ROWB;  // [64 frames][208 B]: updated x (rows >= M zero)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / a.tiles_per_row;
+  const int t0 = (blockIdx.x - b * a.tiles_per_row) * NT;
+  const int T = a.T, M = a.M;
+  const rsrc_t rs_ws = mk_rsrc(a.ws_h, C * C * 2);
+  const rsrc_t rs_wo = mk_rsrc(a.wo_h, 96 * C * 2);
+  const rsrc_t rs_wi = mk_rsrc(a.wi_h, C * 96 * 2);
+  const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
+  const rsrc_t rs_bf = mk_rsrc(a.b_fin, 96 * 4);
+  const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
+  const int vfrag = lane * 16, rowT = T * 4;
+
+  // ---- the skip projection's first weights fly while the skip tile is staged ---------------------------------------------------
+  bf16x8 A[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) A[k] = lda8(rs_ws, vfrag, wave * 1024 + k * 8 * 1024);
+  {
+    const rsrc_t rs_sh = mk_rsrc(a.skip_h + (long long)b * C * T, (unsigned)C * T * 2);
+    u32x2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {   // 64 quads x 64 frames, one 8-byte load per item, lanes = consecutive frames
+      const int q = 8 * k + wave, t = t0 + lane;
+      v[k] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_sh, t < T ? t * 8 : 0, q * T * 8, 0));
+      if (t >= T) v[k] = u32x2{0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) *reinterpret_cast<u32x2*>(ss + lane * ROWB + (8 * k + wave) * 8) = v[k];
+  }
+  f32x16 h0, h1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h0[r] = h1[r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4);
+  __syncthreads();
+  // ---- h = relu(W_skip s + b): 16 k-steps, this wave's 32 rows x 64 frames -------------------------------------------------------
+  {
+    const char* sb = ss + l31 * ROWB + lh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(sb + ks * 32);
+      const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(sb + 32 * ROWB + ks * 32);
+      BSG_MFMA_BF(h0, A[ks & 7], B0);
+      BSG_MFMA_BF(h1, A[ks & 7], B1);
+      if (ks + 8 < 16) A[ks & 7] = lda8(rs_ws, vfrag, wave * 1024 + (ks + 8) * 8 * 1024);
+    }
+  }
+  // the other two projections' weights: requested now, used after the barriers below
+  const int rt = wave % 3, ct2 = wave / 3;   // output projection: 3 row tiles x 2 column tiles on waves 0..5
+  bf16x8 Ao[8];
+  if (wave < 6) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Ao[k] = lda8(rs_wo, vfrag, rt * 1024 + k * 3 * 1024);
+  }
+  __syncthreads();   // every wave is done reading s
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const f32x16& hh = ct ? h1 : h0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<u32x2*>(ss + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) =
+          u32x2{pack2(fmaxf(hh[4 * g], 0.f), fmaxf(hh[4 * g + 1], 0.f)), pack2(fmaxf(hh[4 * g + 2], 0.f), fmaxf(hh[4 * g + 3], 0.f))};
+  }
+  __syncthreads();
+  // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins -----------------------------
+  if (wave < 6) {
+    const int col = t0 + 32 * ct2 + l31;
+    const bool col_ok = col < T;
+    const int vcol = (lh * 4 * T + (col_ok ? col : T - 1)) * 4, vst = (lh * 4 * T + col) * 4;
+    const rsrc_t rs_x = mk_rsrc(a.x + (long long)b * M * T, (unsigned)M * T * 4);
+    const rsrc_t rs_n = mk_rsrc(a.noise ? a.noise + (long long)b * M * T : a.x, a.noise ? (unsigned)M * T * 4 : 0u);
+    f32x16 e;
+    float xv[16], nv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // the lane's row is m0 + 4 lh; rows >= M fall outside the descriptor's range and read as 0, and are never stored
+      const int m0 = 32 * rt + acc_row0(r);
+      e[r] = ldf(rs_bf, lh * 16, m0 * 4);
+      xv[r] = ldf(rs_x, vcol, m0 * rowT);
+      nv[r] = a.noise ? ldf(rs_n, vcol, m0 * rowT) : 0.f;
+    }
+    float h1v[PLMS ? 16 : 1], h2v[PLMS ? 16 : 1], h3v[PLMS ? 16 : 1];
+    if constexpr (PLMS) {
+      const unsigned hb = (unsigned)M * T * 4;
+      const rsrc_t rs_h1 = mk_rsrc(a.h1 + (long long)b * M * T, hb);
+      const rsrc_t rs_h2 = mk_rsrc(a.plms_hist > 1 ? a.h2 + (long long)b * M * T : a.x, a.plms_hist > 1 ? hb : 0u);
+      const rsrc_t rs_h3 = mk_rsrc(a.plms_hist > 2 ? a.h3 + (long long)b * M * T : a.x, a.plms_hist > 2 ? hb : 0u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int so = (32 * rt + acc_row0(r)) * rowT;
+        h1v[r] = ldf(rs_h1, vcol, so);
+        h2v[r] = ldf(rs_h2, vcol, so);   // zero-size descriptors read as 0
+        h3v[r] = ldf(rs_h3, vcol, so);
+      }
+    }
+    const char* hb_ = ss + (32 * ct2 + l31) * ROWB + lh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(hb_ + ks * 32);
+      BSG_MFMA_BF(e, Ao[ks & 7], B0);
+      if (ks + 8 < 16) Ao[ks & 7] = lda8(rs_wo, vfrag, rt * 1024 + (ks + 8) * 3 * 1024);
+    }
+    const rsrc_t rs_en = mk_rsrc(PLMS ? a.e_new + (long long)b * M * T : a.x, PLMS ? (unsigned)M * T * 4 : 0u);
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * rt + acc_row(r, lh);
+      o[r] = 0.f;
+      if (m < M) {
+        if constexpr (PLMS) {
+          o[r] = plms_update(xv[r], e[r], h1v[r], h2v[r], h3v[r], a.plms_hist, a.pk, nullptr);
+          if (col_ok) stf(e[r], rs_en, vst, (32 * rt + acc_row0(r)) * rowT);
+        } else {
+          float nz = nv[r];
+          if (!a.noise && a.k.sigma != 0.f)
+            nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + (col_ok ? col : T - 1));
+          float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, e[r]));
+          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
+          o[r] = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
+        }
+        if (col_ok) stf(o[r], rs_x, vst, (32 * rt + acc_row0(r)) * rowT);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<u32x2*>(xin + (32 * ct2 + l31) * XIN_ROWB + (32 * rt + 8 * g + 4 * lh) * 2) =
+          u32x2{pack2(o[4 * g], o[4 * g + 1]), pack2(o[4 * g + 2], o[4 * g + 3])};
+  }
+  if (!a.do_head) return;
+  // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded) --------------------------------
+  bf16x8 Ai[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Ai[k] = lda8(rs_wi, vfrag, wave * 1024 + k * 8 * 1024);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h0[r] = h1[r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4);
+  __syncthreads();
+  {
+    const char* xb = xin + l31 * XIN_ROWB + lh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(xb + ks * 32);
+      const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(xb + 32 * XIN_ROWB + ks * 32);
+      BSG_MFMA_BF(h0, Ai[ks], B0);
+      BSG_MFMA_BF(h1, Ai[ks], B1);
+    }
+  }
+  const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, (unsigned)C * T * 4);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = t0 + 32 * ct + l31;
+    if (col < T) {
+      const f32x16& hh = ct ? h1 : h0;
+      const int vst = (lh * 4 * T + col) * 4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stf(fmaxf(hh[r], 0.f), rs_xa, vst, (32 * wave + acc_row0(r)) * rowT);
+    }
   }
 }
 
@@ -636,8 +874,18 @@ int pack_a_frag_bf16(const float* src, unsigned short* out, int M, int K, int Kc
   return BSG_OK;
 }
 
+int launch_step_tail_bf16(const TailArgs& a_in, hipStream_t st) {
+  TailArgs a = a_in;
+  a.tiles_per_row = cdiv(a.T, NT);
+  const dim3 grid(a.B * a.tiles_per_row), block(512);
+  if (a.plms_hist) hipLaunchKernelGGL(step_tail_bf16_kernel<true>, grid, block, TAIL_LDS, st, a);
+  else hipLaunchKernelGGL(step_tail_bf16_kernel<false>, grid, block, TAIL_LDS, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
 int stack_bf16_occupancy() {
-  const size_t lds = XS_BYTES + ZS_BYTES;
+  const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
   int o = 0;
   if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel, 512, lds) != hipSuccess)
@@ -646,7 +894,7 @@ int stack_bf16_occupancy() {
 }
 
 int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st) {
-  const size_t lds = XS_BYTES + ZS_BYTES;
+  const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
   hipLaunchKernelGGL(residual_stack_bf16_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;

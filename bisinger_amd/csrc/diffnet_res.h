@@ -36,6 +36,7 @@ struct ResArgs {
 struct StackArgs {
   const float* x_in;      // [B][C][T] in-projected x of this launch's rows
   float* skip;            // [B][C][T] output: skip sum / sqrt(L)
+  unsigned short* skip_h; // bf16 form: the same as bf16 channel quads [B][C/4][T][4]
   const float* condterm;  // layer 0, this launch's rows: [B][2C][T]; + l * ct_stride for layer l
   const float* dproj;     // [S][L][C]
   const long long* t_dev; // [B] or null

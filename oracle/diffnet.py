@@ -63,23 +63,35 @@ def residual_block(sd, p, x, cond, d, dilation, dtype=torch.float32, operand_bf1
     return (x + res) / math.sqrt(2.0), skip
 
 
-def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=torch.float32, operand_bf16=False):
+def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=torch.float32, operand_bf16=False,
+                    skip_rounding='running', tail_bf16=False, in_bf16=False):
     """spec [B,1,M,T], t [B] int64, cond [B,H,T] -> eps [B,1,M,T]   (net.py:107-130).
-    operand_bf16: emulate the build's bf16 configuration end to end — residual_block's operand roundings plus the RUNNING
-    skip sum stored as bf16 after every layer (s_0 = bf16(o_0), s_i = bf16(s_{i-1} + o_i), last layer bf16((s + o)/sqrt(L)));
-    the in/skip/out projections stay fp32, as in the build."""
+    operand_bf16: emulate the build's bf16 configuration end to end — residual_block's operand roundings plus the skip sum
+    stored as bf16: skip_rounding='running' after every layer (s_0 = bf16(o_0), s_i = bf16(s_{i-1} + o_i), last layer
+    bf16((s + o)/sqrt(L)): the build's per-layer launches), 'final' once (bf16(sum / sqrt(L)): the build's stack launch, which
+    keeps the sum in fp32 registers).
+    tail_bf16: the skip and output projections with bf16 operands too (weights, the skip sum, relu(h)), fp32 accumulation —
+    the build's fused bf16 step tail; in_bf16: the input projection likewise (x and its weight rounded) — the build's tail
+    computes the NEXT evaluation's input projection, so every evaluation of a sampler run but the first.  Without them the
+    in/skip/out projections are fp32 (the build's bsg_diffnet_forward)."""
     g = lambda k: sd[prefix + k].to(dtype)
     spec = spec.to(dtype)
     cond = cond.to(dtype)
     x = spec[:, 0]
-    x = F.relu(F.conv1d(x, g('input_projection.weight'), g('input_projection.bias')))
+    if in_bf16:
+        x = F.relu(F.conv1d(_bf16(x), _bf16(g('input_projection.weight')), g('input_projection.bias')))
+    else:
+        x = F.relu(F.conv1d(x, g('input_projection.weight'), g('input_projection.bias')))
     d = step_embedding(sd, t, x.shape[1], prefix, dtype)
     if operand_bf16:
         run = None
         for i in range(n_layers):
             x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype, True)
             run = s if run is None else run + s
-            run = _bf16(run / math.sqrt(n_layers) if i == n_layers - 1 else run)
+            if skip_rounding == 'running':
+                run = _bf16(run / math.sqrt(n_layers) if i == n_layers - 1 else run)
+        if skip_rounding != 'running':
+            run = _bf16(run / math.sqrt(n_layers))
         x = run
     else:
         skips = []
@@ -87,6 +99,10 @@ def diffnet_forward(sd, spec, t, cond, prefix='', n_layers=20, cycle=4, dtype=to
             x, s = residual_block(sd, f'{prefix}residual_layers.{i}.', x, cond, d, 2 ** (i % cycle), dtype)
             skips.append(s)
         x = torch.sum(torch.stack(skips), dim=0) / math.sqrt(n_layers)
-    x = F.relu(F.conv1d(x, g('skip_projection.weight'), g('skip_projection.bias')))
-    x = F.conv1d(x, g('output_projection.weight'), g('output_projection.bias'))
+    if tail_bf16:
+        x = F.relu(F.conv1d(_bf16(x), _bf16(g('skip_projection.weight')), g('skip_projection.bias')))
+        x = F.conv1d(_bf16(x), _bf16(g('output_projection.weight')), g('output_projection.bias'))
+    else:
+        x = F.relu(F.conv1d(x, g('skip_projection.weight'), g('skip_projection.bias')))
+        x = F.conv1d(x, g('output_projection.weight'), g('output_projection.bias'))
     return x[:, None, :, :]

@@ -117,8 +117,105 @@ def test_sampler_bf16_deviation():
     assert dev <= 0.1 and rms <= 0.02
 
 
+def _sampler_model():
+    use_config()
+    from bisinger_amd.diffnet import DiffNet
+    from bisinger_amd.diffusion import GaussianDiffusion
+    from bisinger_amd.hparams import hparams
+
+    class Enc:
+        def __len__(self):
+            return 65
+
+        def pad(self):
+            return 0
+
+    m = GaussianDiffusion(Enc(), 80, DiffNet(80), timesteps=100, K_step=100, spec_min=hparams['spec_min'], spec_max=hparams['spec_max'])
+    load_formula_weights(m, 0, synth.DIFFNET_GAIN)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize('B,T', [(3, 77), (2, 200)])
+def test_bf16_step_tail_vs_emulating_oracle(B, T):
+    """The bf16 step tail (step_tail_bf16_kernel: skip projection, output projection, p_sample, next input projection on bf16
+    MFMAs) inside the fused DDPM loop: 3 steps with supplied noise against the oracle with the same roundings emulated —
+    evaluation 1 takes an fp32 input projection (bsg_diffnet's first in-projection), evaluations 2, 3 the tail's bf16 one;
+    skip sum rounded once (stack launch); skip / output projection with bf16 operands.  Partial tiles, T < 2 tiles."""
+    from oracle import diffusion as odf
+    m = _sampler_model()
+    sd = cpu_sd(m)
+    rs = np.random.RandomState(B * 1000 + T)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32))
+    noise = T_(synth.synth_noise(3, B, 80, T, seed=5))
+    x0 = noise[0][:, None].contiguous()
+    m.denoise_fn.set_compute('bf16')
+    try:
+        got = m.sample(cond.cuda(), x0.clone().cuda(), noise=noise[1:].cuda(), n_steps=3).cpu()
+        path = m.denoise_fn.last_path()
+    finally:
+        m.denoise_fn.set_compute('fp32')
+    ref32 = m.sample(cond.cuda(), x0.clone().cuda(), noise=noise[1:].cuda(), n_steps=3).cpu()
+    assert path == 'stack_bf16'
+    sch = odf.make_schedule(100, 'linear', 0.06)
+    def emulate(tail):
+        calls = []
+
+        def denoise(x, t):
+            calls.append(1)
+            return odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.', operand_bf16=True, skip_rounding='final', tail_bf16=tail,
+                                       in_bf16=tail and len(calls) > 1)
+        x = x0
+        for k, i in enumerate((99, 98, 97)):
+            x = odf.p_sample(sch, denoise, x, torch.full((B,), i, dtype=torch.long), noise[1 + k][:, None])
+        return x
+    x, x_f32tail = emulate(True), emulate(False)
+    rms_alt = float((got - x_f32tail).pow(2).mean().sqrt())
+    e, q = maxabs(got, x), maxabs(x, ref32)
+    rms = float((got - x).pow(2).mean().sqrt())
+    rms_q = float((x - ref32).pow(2).mean().sqrt())
+    print(f'bf16 tail B={B} T={T}, 3 fused steps: HIP vs bf16-emulating oracle max-abs {e:.2e} rms {rms:.2e} (rms {rms_alt:.2e} against '
+          f'the emulation WITHOUT the roundings of the tail); the roundings cost {q:.2e} / {rms_q:.2e} vs the fp32 path')
+    # 1-ulp bf16 flips (a 1e-7 summation-order difference ahead of a rounding) are carried forward: statistical agreement, far
+    # closer to the emulation than the emulation is to fp32; a wrong weight tile or row order shows as O(1)
+    assert rms <= 0.8 * rms_q and e <= q + 1e-4
+    assert rms < 0.9 * rms_alt          # the tail's own roundings are what the kernel does
+
+
+def test_bf16_step_tail_switch_and_plms(monkeypatch):
+    """BSG_TAIL_BF16=0 keeps the fp32 tail in the bf16 configuration; both give finite, close results over 12 DDPM steps
+    (supplied noise and Philox) and over a PLMS run (the tail's multistep form)."""
+    from bisinger_amd.hparams import hparams
+    m = _sampler_model()
+    B, T = 3, 77
+    cond = torch.randn(B, 256, T, generator=torch.Generator().manual_seed(5)).cuda()
+    noise = T_(synth.synth_noise(12, B, 80, T, seed=2)).cuda()
+    x0 = noise[0][:, None].contiguous()
+    m.denoise_fn.set_compute('bf16')
+    try:
+        res = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('BSG_TAIL_BF16', mode)
+            a = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=12).clone()
+            b = m.sample(cond, x0.clone(), seed=9, n_steps=12).clone()
+            hparams['pndm_speedup'] = 5
+            try:
+                c = m.sample(cond, x0.clone()).clone()
+            finally:
+                hparams['pndm_speedup'] = 0
+            res[mode] = (a, b, c)
+    finally:
+        m.denoise_fn.set_compute('fp32')
+    for i, name in enumerate(('ddpm, supplied noise', 'ddpm, philox', 'plms/5')):
+        a, b = res['1'][i], res['0'][i]
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+        dev, rms = maxabs(a, b), float((a - b).pow(2).mean().sqrt())
+        print(f'bf16 tail vs fp32 tail, {name}: max-abs {dev:.2e} rms {rms:.2e}')
+        assert not torch.equal(a, b)
+        assert dev <= 0.1 and rms <= 0.01
+
+
 def test_bf16_stack_launch_matches_per_layer_launches(tmp_path):
-    """BSG_STACK_BF16=1: all 20 layers of the bf16 configuration in one launch (x in registers, fp32 skip sum, edges exchanged
+    """The default bf16 path (BSG_STACK_BF16=0 turns it off): all 20 layers of the bf16 configuration in one launch (x in registers, fp32 skip sum, edges exchanged
     between neighbour tiles) against one launch per layer.  The stack form never rounds the running skip sum to bf16, so
     the two differ by that rounding (not bit-identical); both must sit within bf16 noise of each other, repeat bit for bit,
     and report no hand-off give-ups.  Two launch groups at (40, 640): 10 tiles per row, 25 rows per group."""

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Small-batch latency: ms per 100-step mel-generation pass at B = 1..16, T = 1000 (the channel-split launch paths)."""
+"""Latency sweep: ms per 100-step mel-generation pass at T = 1000 for a list of batch sizes (the channel-split launch paths at
+B = 1..16; BSG_DTYPE=bf16 sweeps the bf16-operand configuration, e.g. the stack launch against per-layer launches)."""
 import json
 import os
 import sys
@@ -14,6 +15,7 @@ import bench  # noqa: E402
 torch.set_grad_enabled(False)
 dev = torch.device('cuda', 0)
 model = bench.build_model(dev)
+model.denoise_fn.set_compute('bf16' if os.environ.get('BSG_DTYPE') == 'bf16' else 'fp32')
 out = {}
 for B in [int(v) for v in (sys.argv[1:] or ['1', '2', '3', '4', '6', '8', '12', '16'])]:
     wl = bench.Workload(model, dev, B, 0, 1)

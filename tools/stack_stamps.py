@@ -38,6 +38,9 @@ s = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64) / 100.0      # us
 names = ['GEMM1 (A->1)', 'gate+z+barrier (1->2)', 'GEMM2 residual (2->3)' if DT != 'bf16' else 'GEMM2 (2->3)',
          'publish+GEMM2 skip (3->4)' if DT != 'bf16' else 'core image + barrier C1 (3->4)', 'drain+barrier C (4->5)',
          'flag wait (5->6)', 'acquire+barrier D (6->7)', 'halo load+barrier A (7->0 next)']
+if DT == 'bf16':   # stamps in time order: 0 start, 1 flags seen, 2 halo rows in place, 3 GEMM1 done, 4 gate done, 5 GEMM2 done, 6 image, 7 flag stored
+    names = ['centre tap + flag wait (0->1)', 'halo copy (1->2)', 'outer taps (2->3)', 'gate+z+barrier (3->4)', 'GEMM2 + x/skip update (4->5)',
+             'cond request + image + barrier C1 (5->6)', 'publish + drain + barrier C (6->7)', 'loop top (7->0 next)']
 inner = s[:, 1:L - 1]                                                          # layers with all 8 stamps and a successor
 d = [inner[:, :, i + 1] - inner[:, :, i] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
 period = s[:, 2:L, 0] - s[:, 1:L - 1, 0]
