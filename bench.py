@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_FRAME_LAYER = 2 * (512 * 768 + 512 * 256)   # dilated conv + output projection, algorithmic
 FLOP_PER_FRAME_LAYER_EXEC = 2 * (4 * 256 * 256 + 512 * 256)   # Winograd F(2,3): 4 K=256 products on half the columns + out-proj
+FLOP_PER_FRAME_LAYER_EXEC_F43 = 2 * (3 * 256 * 256 + 512 * 256)   # Winograd F(4,3): 6 K=256 products on a quarter of the columns + out-proj
 PEAK_F32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0                                 # MI355X_MICROARCH.md, HBM3E spec (achievable ~6.3 TB/s)
 HBM_BYTES_PER_FRAME_LAYER_BF16 = 4 * 256 * 4          # bf16 config: x in + x out fp32 (2 KB), conditioner term bf16 (1 KB), skip sum bf16 r+w (1 KB)
@@ -260,7 +261,20 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
                     traffic_over_algorithmic=traffic / (HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch) if traffic else None,
                     mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / PEAK_BF16_MFMA_TFLOPS,
                     note='achieved = algorithmic bytes of one launch / its average duration (HIP events on its own stream) x launches in flight')
-    wino = os.environ.get('BSG_WINO', '1') != '0'
+    if path == 'stack_f43':
+        # one launch = all 20 layers of up to 256 64-frame tiles, one workgroup per CU; the timed region is the launch group of one
+        # DiffNet evaluation and n_layer counts its layers, so avg_ms is the time of one layer over all rows
+        executed = achieved * FLOP_PER_FRAME_LAYER_EXEC_F43 / FLOP_PER_FRAME_LAYER
+        return dict(common, kernel='residual_stack_f43_kernel (20 fused DiffNet residual blocks per launch, Winograd F(4,3) GEMM1, x on chip; '
+                                   'figures per layer)', bound='mfma',
+                    achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_F32_MFMA_TFLOPS,
+                    executed_tflops=executed, frac_executed=executed / PEAK_F32_MFMA_TFLOPS,
+                    flop_per_launch=FLOP_PER_FRAME_LAYER * frames_per_launch, achieved_per_launch=per_launch,
+                    note='achieved = algorithmic FLOPs (direct conv, SURVEY §8d) of one layer over the batch / (launch-group duration / 20 '
+                         'layers), HIP events around the launch group on its own stream; frac_executed prices the FLOPs the F(4,3) form '
+                         'issues (5/8 of the direct form) = matrix-pipe busy share.  The algorithmic rate exceeds the fp32 MFMA peak '
+                         'because the Winograd transforms remove 3/8 of the multiplications')
+    wino = os.environ.get('BSG_WINO', '2') != '0'
     executed = achieved * (FLOP_PER_FRAME_LAYER_EXEC / FLOP_PER_FRAME_LAYER if wino else 1.0)
     return dict(common, kernel='residual_layer_kernel<false,true> (fused DiffNet residual block, Winograd GEMM1)', bound='mfma',
                 achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_F32_MFMA_TFLOPS,

@@ -1278,6 +1278,7 @@ struct bsg_diffnet {
   float* apack1 = nullptr;  // [L][2C*3C]
   float* apack2 = nullptr;  // [L][2C*C]
   float* apackw = nullptr;  // [L][4*2C*C]  Winograd form of the dilated conv
+  float* apackw43 = nullptr;  // [L][6*2C*C]  Winograd F(4,3) form (diffnet_f43.hip)
   unsigned short* apack1h = nullptr;  // [L][2C*3C] bf16 fragments (bf16-operand form, diffnet_bf16.hip)
   unsigned short* apack2h = nullptr;  // [L][2C*C]
   unsigned short* tail_h = nullptr;   // bf16 step tail (step_tail_bf16_kernel): skip projection [C*C], output projection [96*C], input projection [C*96]
@@ -1323,6 +1324,8 @@ struct bsg_diffnet {
   unsigned stack_epoch = 0;
   int occ_stack = -1;                  // resident workgroups per CU of residual_stack_kernel (-1: not queried)
   int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
+  int occ_stack43 = -1;                // the same for residual_stack_f43_kernel
+  bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1356,7 +1359,7 @@ static void dev_free(float*& p) {
 
 extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (!h) return;
-  float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->apackw, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
+  float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->apackw, &h->apackw43, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
                    &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->apack2w, &h->zbuf, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
@@ -1411,6 +1414,7 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&h->apack1, (size_t)L * 2 * C * 3 * C));
   TRY(dev_alloc(&h->apack2, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->apackw, (size_t)L * 4 * 2 * C * C));
+  TRY(dev_alloc(&h->apackw43, (size_t)L * 6 * 2 * C * C));
   TRY(dev_alloc(&h->apack2w, (size_t)L * 2 * C * C));
   BSG_HIP(hipMalloc((void**)&h->apack1h, (size_t)L * 2 * C * 3 * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->apack2h, (size_t)L * 2 * C * C * sizeof(unsigned short)));
@@ -1445,7 +1449,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
       hipLaunchKernelGGL(pack_a_frag_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)lw[6],
                          h->apack2 + (size_t)l * total, 2 * C, C, C, (long long)C, 1LL, 0LL);
     }
-    rc = pack_a_frag_bf16((const float*)lw[0], h->apack1h + (size_t)l * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, st);
+    rc = pack_wino43((const float*)lw[0], h->apackw43 + (size_t)l * 6 * 2 * C * C, st);
+    if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[0], h->apack1h + (size_t)l * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, st);
     if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[6], h->apack2h + (size_t)l * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, st);
     if (rc != BSG_OK) break;
     hipLaunchKernelGGL(pack_a16_kernel, dim3(cdiv(2 * C * C, 256)), dim3(256), 0, st, (const float*)lw[6], h->apack2w + (size_t)l * 2 * C * C,
@@ -1612,12 +1617,15 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   return BSG_OK;
 }
 
-// GEMM1 of the residual block as Winograd F(2,3) (BSG_WINO=0 selects the direct K=768 form)
-static bool use_wino() {
+// GEMM1 of the residual block: BSG_WINO unset = 2: Winograd F(2,3) kernels, and the F(4,3) stack launch (diffnet_f43.hip) for launches
+// that fill the chip with 64-frame tiles (stack_rows); 1: F(2,3) only; 43: F(4,3) wherever it applies (stack launch, else the per-layer
+// F(4,3) kernel for launches that are not channel-split); 0: the direct K=768 form
+static int wino_env() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("BSG_WINO"); v = e ? atoi(e) : 1; }
-  return v != 0;
+  if (v < 0) { const char* e = getenv("BSG_WINO"); v = e ? atoi(e) : 2; }
+  return v;
 }
+static bool use_wino() { return wino_env() != 0; }
 
 // A pair of workgroups per tile pays (a z exchange through L2) only when single workgroups would leave CUs idle: measured on
 // MI355X at T=1000, B = 1 / 2 / 4 (32 / 64 / 128 tiles): 63 -> 41, 64 -> 42, 65 -> 47 us per layer; B = 6 (192 tiles): 68 -> 70.
@@ -1675,6 +1683,7 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   a.apack1 = h->apack1 + (size_t)layer * 2 * C * 3 * C;
   a.apack2 = h->apack2 + (size_t)layer * 2 * C * C;
   a.apackw = h->apackw + (size_t)layer * 4 * 2 * C * C;
+  a.apackw43 = h->apackw43 + (size_t)layer * 6 * 2 * C * C;
   a.apack1h = h->apack1h + (size_t)layer * 2 * C * 3 * C;
   a.apack2h = h->apack2h + (size_t)layer * 2 * C * C;
   a.bias_out = h->b_out + (size_t)layer * 2 * C;
@@ -1718,6 +1727,11 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
     return BSG_OK;
   }
+  if (wino_env() == 43) {
+    TRY(launch_residual_layer_f43(a, st));
+    h->last_path = "layer_f43";
+    return BSG_OK;
+  }
   // 32-frame tiles: 48 KB of LDS -> 3 workgroups per CU.  (Wider tiles of 64 / 128 frames were built and
   // measured in round 1: 0-50 % slower at every batch size, because fewer workgroups per CU hide less of the
   // L2 latency of the weight stream.)
@@ -1758,6 +1772,30 @@ static constexpr size_t kStackLds = (size_t)C * (32 + 2 * HALO + 32) * sizeof(fl
 // each other, and every workgroup of a launch must be resident: at most occ x CUs workgroups, whole rows only.  It pays when a
 // launch has more workgroups than CUs (two per CU overlap each other's waits); smaller launches keep the channel-split kernels.
 static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
+  h->stack_is_f43 = false;
+  if (wino_env() == 43 || wino_env() == 2) {
+    // F(4,3) form (diffnet_f43.hip): 64-frame tiles, one workgroup per CU, whole rows per launch group; BSG_STACK43=0 keeps per-layer
+    // launches.  A launch group takes the same time whatever part of the chip it fills, so the form is taken when the groups are
+    // >= 90 % full (B = 15, 16, 29..32, .. at T = 1000): it is ~6 % faster than two chains of per-layer F(2,3) launches, not more.
+    static int env43 = -1;
+    if (env43 < 0) { const char* e = getenv("BSG_STACK43"); env43 = e ? atoi(e) : 1; }
+    hipStreamCaptureStatus cap43 = hipStreamCaptureStatusNone;
+    if (st) (void)hipStreamIsCapturing(st, &cap43);
+    if (env43 && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && cap43 == hipStreamCaptureStatusNone) {
+      if (h->occ_stack43 < 0) h->occ_stack43 = stack_f43_occupancy() >= 1 ? 1 : 0;
+      const int tpr43 = cdiv(T, 64);
+      if (h->occ_stack43 >= 1 && tpr43 <= h->num_cus) {
+        int rows43 = h->num_cus / tpr43;
+        if (rows43 > B) rows43 = B;
+        const int groups = cdiv(B, rows43);
+        if (env43 == 2 || (long long)B * tpr43 * 10 >= (long long)groups * h->num_cus * 9) {   // BSG_STACK43=2: any shape (tests)
+          h->stack_is_f43 = true;
+          return rows43;
+        }
+      }
+    }
+    if (wino_env() == 43) return 0;
+  }
   if (!stack_env() || h->compute != BSG_COMPUTE_F32 || !use_wino() || h->split_off || !h->num_cus || !h->hx) return 0;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
@@ -1781,7 +1819,8 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
 
 static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
                         unsigned long long* stamps = nullptr) {
-  const int tpr = cdiv(T, 32);
+  const bool f43 = h->stack_is_f43;   // the decision of the stack_rows() call that returned rows_per_launch
+  const int tpr = cdiv(T, f43 ? 64 : 32);
   const size_t bt = (size_t)h->B * T;   // bound batch: per-layer stride of the conditioner term
   for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
     const int nb = B - r0 < rows_per_launch ? B - r0 : rows_per_launch;
@@ -1801,10 +1840,15 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.fbase = h->stack_epoch * 64u;
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
-    hipLaunchKernelGGL(residual_stack_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), kStackLds, st, p);
-    BSG_LAUNCH_CHECK();
+    if (f43) {
+      p.apackw43 = h->apackw43;
+      TRY(launch_residual_stack_f43(p, st));
+    } else {
+      hipLaunchKernelGGL(residual_stack_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), kStackLds, st, p);
+      BSG_LAUNCH_CHECK();
+    }
   }
-  h->last_path = "stack";
+  h->last_path = f43 ? "stack_f43" : "stack";
   return BSG_OK;
 }
 

@@ -18,6 +18,7 @@ struct ResArgs {
   const float* apack1;   // dilated conv, packed  [16][96][64][4]
   const float* apack2;   // output projection     [16][32][64][4]
   const float* apackw;   // dilated conv in Winograd F(2,3) form, packed for 16x16x4 MFMAs [4][32][16][64][4]
+  const float* apackw43; // dilated conv in Winograd F(4,3) form (diffnet_f43.hip) [6][32][16][64][4]
   const unsigned short* apack1h;  // bf16 operand path: dilated conv packed for 32x32x16 bf16 MFMAs [16][48][64][8]
   const unsigned short* apack2h;  // bf16 operand path: output projection                           [16][16][64][8]
   // bf16-operand path: conditioner term and running skip sum are STORED as bf16 in channel-quad order
@@ -41,6 +42,7 @@ struct StackArgs {
   const float* dproj;     // [S][L][C]
   const long long* t_dev; // [B] or null
   const float* apackw;    // layer 0; + l * aw_stride
+  const float* apackw43;  // F(4,3) form (diffnet_f43.hip), layer 0; + l * 6*2C*C
   const unsigned short* apack1h;     // bf16 form: dilated conv fragments, layer 0; + l * 2C*3C
   const unsigned short* apack2h;     // bf16 form: output projection fragments, layer 0; + l * 2C*C
   const unsigned short* condterm_h;  // bf16 form: conditioner term in channel-quad order, layer 0 / this launch's rows; + l * ct_stride
@@ -59,6 +61,13 @@ struct StackArgs {
 // bf16 stack launch: 64-frame tiles, one workgroup per CU (see diffnet_bf16.hip); grid = p.n_tiles rounded up to 8
 int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st);
 int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf16_kernel (0 on error)
+
+// fp32 residual layer with GEMM1 as Winograd F(4,3) (diffnet_f43.hip); same tensors, 64-frame tiles, one workgroup per CU
+int launch_residual_layer_f43(const ResArgs& a, hipStream_t st);
+int pack_wino43(const float* w, float* out, hipStream_t st);   // [2C][C][3] -> [6][32][16][64][4]
+// F(4,3) stack launch: all L layers of 64-frame tiles, one workgroup per CU (diffnet_f43.hip); grid = p.n_tiles rounded up to 8
+int launch_residual_stack_f43(const StackArgs& p, hipStream_t st);
+int stack_f43_occupancy();
 
 // bf16-operand form of the residual layer (diffnet_bf16.hip); same tensors, 64-frame tiles
 int launch_residual_layer_bf16(const ResArgs& a, hipStream_t st);

@@ -4,10 +4,15 @@ The oracle takes minutes at these sizes, so beyond one DiffNet evaluation checke
 properties the domain offers:
   * locality   - 20 dilated-conv layers (dilations 1,2,4,8 x 5) see +-75 frames: perturbing x beyond that leaves eps
                  bit-identical, and rows of a batch never interact (this is what catches tiling / halo / tile-order bugs
-                 at sizes where every tile class occurs: first, interior, last partial, all 8 XCD runs);
+                 at sizes where every tile class occurs: first, interior, last partial, all 8 XCD runs).  The F(4,3)
+                 stack launch (the fp32 default at this size) computes quads of frames t, t+d, t+2d, t+3d from the six
+                 inputs t-d .. t+4d; the terms outside an output's own +-d cancel in exact arithmetic, in fp32 they leave
+                 rounding noise: bit-identity holds outside 4 x 75 frames, and between 75 and 300 the leak is < 1e-5;
   * permutation equivariance of the sampler over the rows of a batch (supplied noise permuted alike), bit-exact;
   * shard invariance - rows [r0, r1) generated alone (Philox noise indexed by global row) equal the same rows of the
-                 unsharded run, bit-exact; same seed -> same bits, other seed -> other result.
+                 unsharded run; same seed -> same bits, other seed -> other result.  Bit-exact when both runs take the same
+                 GEMM1 form (always under BSG_WINO=1); by default B=16 runs the F(4,3) stack launch and a shard of 8 rows
+                 the F(2,3) kernels — two roundings of the same sums — and the rows agree to 1e-5 instead.
 """
 import numpy as np
 import pytest
@@ -68,24 +73,27 @@ def test_locality_and_row_independence(model, data, mode):
     net.set_compute(mode)
     try:
         base = net(x, t, cond).clone()
+        rf = 4 * RF if net.last_path() == 'stack_f43' else RF       # bit-exact locality radius (module docstring)
         # (a) frames >= 600 of row 3 perturbed: only row 3, frames >= 600 - RF may change
         x2 = x.clone()
         x2[3, :, :, 600:] += 1.0
         e2 = net(x2, t, cond).clone()
         keep = torch.ones(B, T, dtype=torch.bool, device='cuda')
-        keep[3, 600 - RF:] = False
+        keep[3, 600 - rf:] = False
         same = (e2 == base).all(dim=(1, 2))              # [B, T]
         assert bool(same[keep].all()), 'a perturbation leaked outside the receptive field / into another row'
         assert not bool(same[3, 600:].all())
+        assert maxabs(e2[3, :, :, :600 - RF], base[3, :, :, :600 - RF]) < 1e-5
         # (b) the same for the condition, at a tile boundary of both tilings (frame 64*k) and at the very first frames
         c2 = cond.clone()
         c2[7, :, :64] *= 0.5
         e3 = net(x, t, c2).clone()
         keep = torch.ones(B, T, dtype=torch.bool, device='cuda')
-        keep[7, :64 + RF] = False
+        keep[7, :64 + rf] = False
         same = (e3 == base).all(dim=(1, 2))
         assert bool(same[keep].all())
         assert not bool(same[7, :64].all())
+        assert maxabs(e3[7, :, :, 64 + RF:], base[7, :, :, 64 + RF:]) < 1e-5
     finally:
         net.set_compute('fp32')
 
@@ -109,12 +117,16 @@ def test_full_size_shard_invariance_and_seed(model):
     try:
         run = lambda **k: model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], infer=True, **kw, **k)['mel_out'].clone()
         full = run(seed=5)
+        full_path = model.denoise_fn.last_path()
         assert full.shape == (B, T, 80) and bool(torch.isfinite(full).all())
         assert torch.equal(full, run(seed=5))
         assert maxabs(full, run(seed=6)) > 1e-2
         for r0, r1 in ((0, 8), (8, 16), (5, 7)):
             part = run(seed=5, rows=slice(r0, r1))
-            assert torch.equal(part, full[r0:r1]), f'rows [{r0},{r1}) differ from the unsharded run'
+            if full_path == 'stack_f43' and model.denoise_fn.last_path() != 'stack_f43':
+                assert maxabs(part, full[r0:r1]) <= 1e-5, f'rows [{r0},{r1}) differ from the unsharded run'
+            else:
+                assert torch.equal(part, full[r0:r1]), f'rows [{r0},{r1}) differ from the unsharded run'
     finally:
         model.K_step = 100
 
@@ -145,6 +157,12 @@ def test_split_launch_equals_regular_launch(model, data):
     x, cond, t = data
     net = model.denoise_fn
     full = net(x, t, cond).clone()
+    f43 = net.last_path() == 'stack_f43'
     one = net(x[3:4].contiguous(), t[3:4].contiguous(), cond[3:4].contiguous()).clone()
-    assert torch.equal(one[0], full[3])
+    if f43:     # the default at B=16: F(4,3) transforms against the split kernels' F(2,3) — two roundings of the same sums
+        assert maxabs(one[0], full[3]) <= 1e-5
+    else:
+        assert torch.equal(one[0], full[3])
+    half = net(x[:8].contiguous(), t[:8].contiguous(), cond[:8].contiguous()).clone()      # 256 tiles of 32 frames, one workgroup per tile
+    assert torch.equal(one[0], half[3])
     assert net.handoff_timeouts() == 0

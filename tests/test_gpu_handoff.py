@@ -84,6 +84,44 @@ def test_injected_giveup_self_heals_in_the_same_call(B):
     assert torch.equal(again, want_x) and net.handoff_timeouts() == 0
 
 
+def test_injected_giveup_self_heals_f43_stack_launch():
+    """B=16, T=1000 runs the F(4,3) stack launch (256 tiles, neighbours exchange edges every layer).  An injected give-up
+    (odd tiles do not publish, nobody waits) must be noticed in the same call; the repeat runs per-layer F(2,3) launches —
+    another rounding, so the healed result agrees to 1e-5 instead of bit for bit — and the handle stays healed."""
+    B, T = 16, 1000
+    rs = np.random.RandomState(9)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    noise = T_(synth.synth_noise(3, B, 80, T, seed=4)).cuda()
+    x0 = noise[0][:, None].contiguous()
+    good = _model()
+    want = good.sample(cond, x0.clone(), noise=noise[1:], n_steps=3).clone()
+    assert good.denoise_fn.last_path() == 'stack_f43' and good.denoise_fn.uses_handoffs(B, T)
+    assert good.denoise_fn.handoff_timeouts() == 0
+    m = _model()
+    net = m.denoise_fn
+    net.prepare(cond)
+    net.debug_inject_giveup(1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=3).clone()
+    assert any('hand-offs gave up' in str(x.message) for x in w), 'the give-up went unnoticed'
+    assert maxabs(got, want) <= 1e-5, 'a tensor computed from a given-up hand-off left the call'
+    assert not net.uses_handoffs(B, T) and net.last_path() != 'stack_f43' and net.handoff_timeouts() == 0
+    # the injection is a real fault: the same launch without the guard gives another result
+    from bisinger_amd import _lib
+    from ctypes import c_int32, byref
+    bad = _model().denoise_fn
+    t = torch.full((B,), 42, device='cuda', dtype=torch.long)
+    ref = bad(x0, t, cond).clone()
+    bad.debug_inject_giveup(1)
+    eps = torch.empty(B, 80, T, device='cuda')
+    _lib.check(_lib.load().bsg_diffnet_forward(bad._h, _lib.ptr(x0[:, 0].contiguous()), _lib.ptr(t), _lib.ptr(eps), B, T, _lib.stream_ptr()), 'fwd')
+    torch.cuda.synchronize()
+    n = c_int32()
+    _lib.check(_lib.load().bsg_diffnet_handoff_take(bad._h, byref(n), _lib.stream_ptr()), 'take')
+    assert n.value > 0 and maxabs(eps[:, None], ref) > 1e-4
+
+
 def test_injection_really_corrupts_without_the_guard():
     """the fault injection is a real fault: with the check bypassed the result differs (otherwise the test above proves nothing)"""
     B, T = 1, 320

@@ -132,14 +132,31 @@ def test_fused_plms_tail_matches_separate_kernels(model, monkeypatch):
     assert maxabs(fused, sep) <= 2e-5
 
 
-@pytest.mark.parametrize('B,T,stack', [(16, 1000, '1'), (9, 1000, '1'), (40, 640, '1'), (3, 77, '2'), (5, 333, '2'), (2, 31, '2')])
-def test_stack_launch_matches_per_layer_launches(B, T, stack, tmp_path):
-    """The on-chip stack launch (all 20 layers in one launch, x and the skip sum on chip, neighbour tiles exchanging 8-frame
-    edges every layer) against one launch per layer.  Same arithmetic except that the conditioner term is the GEMM1
-    accumulators' initial value instead of being added after the products: agreement to fp32 rounding (1e-5 after 10 sampler
-    steps), bit-identical from run to run, no hand-off give-ups.  Child process per mode (the switch is read once per
-    process).  (40,640): 800 tiles = two launch groups of whole rows; BSG_STACK=2 forces it for small / ragged shapes
-    (a single tile per row, T % 4 != 0, T < one tile)."""
+F23 = {'BSG_WINO': '1'}
+F43 = {'BSG_WINO': '2'}
+
+
+@pytest.mark.parametrize('B,T,base,stack,path,tol', [
+    (16, 1000, dict(F23, BSG_STACK='0'), dict(F23, BSG_STACK='1'), 'stack', 1e-5),
+    (9, 1000, dict(F23, BSG_STACK='0'), dict(F23, BSG_STACK='1'), 'stack', 1e-5),
+    (40, 640, dict(F23, BSG_STACK='0'), dict(F23, BSG_STACK='1'), 'stack', 1e-5),
+    (3, 77, dict(F23, BSG_STACK='0'), dict(F23, BSG_STACK='2'), 'stack', 1e-5),
+    (5, 333, dict(F23, BSG_STACK='0'), dict(F23, BSG_STACK='2'), 'stack', 1e-5),
+    (2, 31, dict(F23, BSG_STACK='0'), dict(F23, BSG_STACK='2'), 'stack', 1e-5),
+    # the F(4,3) stack launch (the default for launches that fill the chip) against per-layer F(2,3) launches: another rounding
+    (16, 1000, F23, F43, 'stack_f43', 1e-5),
+    (32, 997, F23, F43, 'stack_f43', 1e-5),                              # two launch groups of whole rows, T % 4 != 0, partial last tile
+    (3, 77, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),         # forced: a few tiles, partial tile
+    (5, 333, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),
+    (2, 31, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),         # T < one tile
+])
+def test_stack_launch_matches_per_layer_launches(B, T, base, stack, path, tol, tmp_path):
+    """The on-chip stack launches (all 20 layers in one launch, x on chip, neighbour tiles exchanging 8-frame edges every
+    layer) against one launch per layer: bit-identical from run to run, no hand-off give-ups, agreement to rounding after 10
+    sampler steps + one evaluation with per-row timesteps.  F(2,3) stack (opt-in, BSG_STACK): same arithmetic except that the
+    conditioner term is the GEMM1 accumulators' initial value: 1e-5.  F(4,3) stack (diffnet_f43.hip, the default at these
+    sizes): Winograd F(4,3) transforms instead of F(2,3) and x recovered as image - d: measured 7e-7, bar 1e-5.  Child process per mode (the
+    switches are read once per process).  BSG_STACK=2 / BSG_STACK43=2 force the form for small / ragged shapes."""
     import json
     import os
     import subprocess
@@ -175,19 +192,18 @@ print(json.dumps({'hashes': hs, 'timeouts': m.denoise_fn.handoff_timeouts(), 'fi
                   'path': m.denoise_fn.last_path()}))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), B, T)
     res, arr = {}, {}
-    for mode in ('0', stack):
+    for mode, extra in (('base', base), ('stack', stack)):
         f = str(tmp_path / f'x{mode}.npy')
-        env = dict(os.environ, BSG_STACK=mode)
-        out = subprocess.run([sys.executable, '-c', code, f], env=env, capture_output=True, text=True, timeout=600)
+        out = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
         arr[mode] = np.load(f)
-    assert res[stack]['path'] == 'stack' and res['0']['path'] != 'stack'
-    assert res[stack]['timeouts'] == 0 and res[stack]['finite']
-    assert len(set(res['0']['hashes'])) == 1 and len(set(res[stack]['hashes'])) == 1
-    dev = float(np.abs(arr['0'] - arr[stack]).max())
-    print(f'stack launch vs per-layer launches B={B} T={T}: max-abs {dev:.2e} after 10 sampler steps + one evaluation')
-    assert dev <= 1e-5
+    assert res['stack']['path'] == path and not res['base']['path'].startswith('stack')
+    assert res['stack']['timeouts'] == 0 and res['stack']['finite']
+    assert len(set(res['base']['hashes'])) == 1 and len(set(res['stack']['hashes'])) == 1
+    dev = float(np.abs(arr['base'] - arr['stack']).max())
+    print(f'{path} launch vs per-layer launches B={B} T={T}: max-abs {dev:.2e} after 10 sampler steps + one evaluation')
+    assert dev <= tol
 
 
 @pytest.mark.parametrize('B,T,n', [(2, 96, 12), (10, 900, 4)])

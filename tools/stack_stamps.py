@@ -21,13 +21,14 @@ m = bench.build_model(dev)
 net = m.denoise_fn
 DT = os.environ.get('PD', 'fp32')
 net.set_compute(DT)
-NTILE = 64 if DT == 'bf16' else 32
 cond = torch.randn(B, 256, T, device=dev)
 x = torch.randn(B, 1, 80, T, device=dev)
 t = torch.full((B,), 50, device=dev, dtype=torch.long)
 for _ in range(3):
     net(x, t, cond)          # binds, fills xa, warms up
 torch.cuda.synchronize()
+F43 = net.last_path() == 'stack_f43'
+NTILE = 64 if DT == 'bf16' or F43 else 32
 tiles, L = B * ((T + NTILE - 1) // NTILE), 20
 st = torch.zeros(tiles * L * 8, dtype=torch.int64, device=dev)
 for rep in range(3):
@@ -41,6 +42,9 @@ names = ['GEMM1 (A->1)', 'gate+z+barrier (1->2)', 'GEMM2 residual (2->3)' if DT 
 if DT == 'bf16':   # stamps in time order: 0 start, 1 flags seen, 2 halo rows in place, 3 GEMM1 done, 4 gate done, 5 GEMM2 done, 6 image, 7 flag stored
     names = ['centre tap + flag wait (0->1)', 'halo copy (1->2)', 'outer taps (2->3)', 'gate+z+barrier (3->4)', 'GEMM2 + x/skip update (4->5)',
              'cond request + image + barrier C1 (5->6)', 'publish + drain + barrier C (6->7)', 'loop top (7->0 next)']
+if F43:   # 0 start, 1 GEMM1 done (wave 0), 2 barrier B passed, 3 residual rows done, 4 image + publish + flag, 5 skip rows stored, 6 flags seen, 7 halo copied
+    names = ['GEMM1, wave 0 (0->1)', 'gate + x recovery + barrier B (1->2)', 'GEMM2 residual rows (2->3)', 'image + barrier + publish + drain + flag (3->4)',
+             'GEMM2 skip rows + skip RMW (4->5)', 'd tables + flag wait + barrier D (5->6)', 'halo copy (6->7)', 'barrier A (7->0 next)']
 inner = s[:, 1:L - 1]                                                          # layers with all 8 stamps and a successor
 d = [inner[:, :, i + 1] - inner[:, :, i] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
 period = s[:, 2:L, 0] - s[:, 1:L - 1, 0]
