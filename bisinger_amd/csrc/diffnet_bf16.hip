@@ -67,14 +67,6 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, bf16x2{(__bf16)lo, (__bf16)hi});
 }
 
-// sigmoid(g) * tanh(f) with two exponentials and ONE reciprocal: (1 - e^{-2f}) / ((1 + e^{-g}) (1 + e^{-2f})); f is clamped to +-15
-// (tanh = +-1 to 1e-13 there) so that e^{-2f} stays finite.  Used where the result is rounded to bf16 anyway.
-__device__ __forceinline__ float gate1(float g, float f) {
-  f = fminf(fmaxf(f, -15.0f), 15.0f);
-  const float eg = __expf(-g), ef = __expf(-2.0f * f);
-  return (1.0f - ef) * __frcp_rn((1.0f + eg) * (1.0f + ef));
-}
-
 #define BSG_MFMA_BF(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
 
 // k-step pipeline over two row tiles x two column tiles.  A fragments (global, L2) live in a ring of NS k-steps and are

@@ -62,9 +62,16 @@ __global__ void pack_wino43_kernel(const float* __restrict__ w, float* __restric
 
 // GEMM1 of one layer: y[j][i] += (output j of this lane's quad, row tile i) over the 6 components x 256 channels.  On entry AW holds
 // the weights of step 0 and component a of step 1 (f43_prefetch); xo = this lane's float4 offset of (row lq, frame of d1).
-template <int DBG>
+// FAIR: the two waves of a SIMD take turns at issue priority in slices of 8192 shader cycles (s_memtime bit 13 against the wave's
+// half of the workgroup).  The SIMD's arbiter favours the older wave: left alone, waves 0-3 finish GEMM1 ~30 % before waves 4-7, which
+// then run alone with nobody to fill the issue bubbles of their loads (a lone wave multiplies at ~75 %).
+struct F43NoOp {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `pre_last()` runs before the last pair of components (a third of GEMM1 still to go): loads requested there land under its MFMAs
+template <int DBG, int FAIR = 0, typename PRE = F43NoOp>
 __device__ __forceinline__ void f43_gemm1(f32x4 (&y)[4][4], f32x4 (&AW)[2][2][4], const float* xs, const int xo, const int dil,
-                                          const rsrc_t rs_aw, const int vfrag, const int (&sw)[4]) {
+                                          const rsrc_t rs_aw, const int vfrag, const int (&sw)[4], const int half = 0, PRE pre_last = PRE()) {
   f32x4 Ma[4], Mb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) Ma[i] = Mb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -118,6 +125,11 @@ __device__ __forceinline__ void f43_gemm1(f32x4 (&y)[4][4], f32x4 (&AW)[2][2][4]
   auto step = [&](auto slot_c, auto tp_c, auto rp_c, int o2, int wb1, int wa2) {
     constexpr int sl = decltype(slot_c)::value, tpp = decltype(tp_c)::value, rpp = decltype(rp_c)::value;
     f32x4 nBa, nBb;
+    if (FAIR) {
+      const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+      if (((tnow >> 13) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     // ---- block a.  The raw values are re-defined here by empty volatile asm statements: instruction selection otherwise places
     // the (chain-free) transform FMAs right behind the LDS reads of the previous block b, where they wait for the LDS latency
 #pragma unroll
@@ -218,6 +230,7 @@ __device__ __forceinline__ void f43_gemm1(f32x4 (&y)[4][4], f32x4 (&AW)[2][2][4]
   using I2 = std::integral_constant<int, 2>;
   run_pass(I0{}, I1{});
   run_pass(I1{}, I2{});
+  pre_last();
   run_pass(I2{}, I2{});
 }
 
@@ -466,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void residual_layer_f43_kernel(ResArgs a) {
 constexpr int XS4_FLOATS = 64 * FS6 * 4;                        // 22,528
 constexpr size_t STACK43_LDS = (size_t)(XS4_FLOATS + C * LDZ6 + 2 * C) * sizeof(float);   // 88 KB + 64 KB + 2 KB = 157,696 B
 
+template <int FAIR>
 __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                       // image x + d_l, layout [g][lq][frame 0..79 (+8)][jj] (residual_layer_f43_kernel)
@@ -566,25 +580,51 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
     for (int jo = 0; jo < 4; ++jo)
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[jo][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f43_gemm1<0>(y, AW, xs, lq * FS6 + HALO + tp, dil, rs_aw, vfrag, sw);
+    // the gate rows' conditioner term (this wave's 32 rows x 64 frames) goes straight into the z tile by LDS-DMA while GEMM1 runs: the
+    // gate then reads it where it writes z, and only the filter rows' term is loaded from HBM behind GEMM1 (T % 4 == 0: 16-byte pieces)
+    const bool dma = (T & 3) == 0;
+    if (dma) {
+      const int voff = (((lane >> 4) * T) + t0 + 4 * (lane & 15)) * 4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ct, (__attribute__((address_space(3))) void*)(zs + (32 * wave + 4 * k) * LDZ6), 16, voff,
+                                                 (32 * wave + 4 * k) * rowT, 0, 0);
+    }
+    // the filter rows' conditioner term: requested before the last third of GEMM1 (32 registers), so that the gate does not wait for HBM
+    float cfv[4][8];
+    auto cond_f = [&](int i) {
+#pragma unroll
+      for (int jo = 0; jo < 4; ++jo) {
+        const int f = t0 + tp + jo * dil;
+        const int vc = (lq * 4 * T + (f < T ? f : T - 1)) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cfv[jo][4 * i + r] = ldf(rs_ct, vc, (C + 32 * wave + 16 * i + r) * rowT);
+      }
+    };
+    f43_gemm1<0, FAIR>(y, AW, xs, lq * FS6 + HALO + tp, dil, rs_aw, vfrag, sw, wave >> 2, [&]() { cond_f(0); });   // half of them: registers
+    cond_f(1);   // the other half: 16 loads that fly across the barrier and the first half of the gate
+    if (dma) {   // LDS-DMA data is ordered for a ds_read by the issuing wave's vmcnt followed by a barrier the reader has passed
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // everything older than those 16 loads, the LDS-DMA pieces included
+      __builtin_amdgcn_s_barrier();
+    }
     STK_STAMP(1);
     // ---- gate -> zs (its own region: no barrier before the stores); GEMM2's first weights fly meanwhile ---------------------------
     f32x4 Ag[2], Af[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) Ag[k] = ldf4(rs_a2, vfrag, sb_r + k * 1024);
 #pragma unroll
-    for (int jo = 0; jo < 4; ++jo) {
-      const int f = t0 + tp + jo * dil;
-      const int vc = (lq * 4 * T + (f < T ? f : T - 1)) * 4;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int jo = 0; jo < 4; ++jo) {
+        const int f = t0 + tp + jo * dil;
+        const int vc = (lq * 4 * T + (f < T ? f : T - 1)) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int so_g = (32 * wave + 16 * i + r) * rowT;
-          const float cg = ldf(rs_ct, vc, so_g), cf = ldf(rs_ct, vc, so_g + C * rowT);
-          zs[(32 * wave + 16 * i + 4 * lq + r) * LDZ6 + tp + jo * dil] = fast_sigmoid(y[jo][i][r] + cg) * fast_tanh(y[jo][2 + i][r] + cf);
+          float* zp = zs + (32 * wave + 16 * i + 4 * lq + r) * LDZ6 + tp + jo * dil;
+          const float cg = dma ? *zp : ldf(rs_ct, vc, (32 * wave + 16 * i + r) * rowT);
+          *zp = gate1(y[jo][i][r] + cg, y[jo][2 + i][r] + cfv[jo][4 * i + r]);
         }
-    }
+      }
     // residual rows start from x + b_out with x = image - d_l (this wave's own 32 channels)
     f32x16 r0, r1;
 #pragma unroll
@@ -740,14 +780,18 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
 
 int stack_f43_occupancy() {
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_f43_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STACK43_LDS) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_f43_kernel, 512, STACK43_LDS) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)residual_stack_f43_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STACK43_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_f43_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STACK43_LDS) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_f43_kernel<1>, 512, STACK43_LDS) != hipSuccess)
     return 0;
   return o;
 }
 
 int launch_residual_stack_f43(const StackArgs& p, hipStream_t st) {
-  hipLaunchKernelGGL(residual_stack_f43_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), STACK43_LDS, st, p);
+  static int fair = -1;
+  if (fair < 0) { const char* e = getenv("BSG_F43_FAIR"); fair = e ? atoi(e) : 1; }
+  if (fair) hipLaunchKernelGGL(residual_stack_f43_kernel<1>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), STACK43_LDS, st, p);
+  else hipLaunchKernelGGL(residual_stack_f43_kernel<0>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), STACK43_LDS, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

@@ -86,6 +86,15 @@ __device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast
 // versions cost ~60 VALU instructions per element and the gate phase runs with the MFMA pipe idle.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// sigmoid(g) * tanh(f) with two exponentials and ONE reciprocal: (1 - e^{-2f}) / ((1 + e^{-g}) (1 + e^{-2f})); f is clamped to +-15
+// (tanh = +-1 to 1e-13 there) so that e^{-2f} stays finite.  Relative error ~2e-7 (two v_exp_f32, one v_rcp_f32): used where the result is rounded to bf16
+// anyway, and by the F(4,3) stack launch, whose rounding differs from the other fp32 kernels' already.
+__device__ __forceinline__ float gate1(float g, float f) {
+  f = fminf(fmaxf(f, -15.0f), 15.0f);
+  const float eg = __expf(-g), ef = __expf(-2.0f * f);
+  return (1.0f - ef) * __frcp_rn((1.0f + eg) * (1.0f + ef));
+}
+
 
 // Buffer (SRSRC) addressing: one wave-uniform 128-bit descriptor per tensor, a per-lane 32-bit byte offset that
 // is computed once, and a wave-uniform SGPR offset per access — the 32 row-strided loads of an accumulator tile
