@@ -344,15 +344,20 @@ __device__ __forceinline__ int kmap(int i, int n_ks) {
 }
 // `mid()` runs after the first ROT k-steps have been issued (ROT = 0: never): the hand-off with the neighbours sits there, under
 // the centre tap's MFMAs; the ring keeps prefetching across it.
-template <int ROT, typename LDB, typename MID>
+template <int ROT, bool FAIRB, typename LDB, typename MID>
 __device__ __forceinline__ void mfma_pipe_bf8(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, bf16x8 (&A0)[NSS], bf16x8 (&A1)[NSS],
-                                              rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks, LDB ldb, MID mid) {
+                                              rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
   bf16x8 B0[2], B1[2];
   B0[0] = ldb(kmap<ROT>(0, n_ks), 0);
   B1[0] = ldb(kmap<ROT>(0, n_ks), 1);
   const int last = n_ks - 1;
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += NSS) {
+    if (FAIRB) {   // the two waves of a SIMD take turns at issue priority (2048-cycle slices): see f43_gemm1, diffnet_f43.hip
+      const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+      if (((tnow >> 11) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     if (ROT > 0 && ks == ROT) {
       mid();
       // the B operand of the next k-step was read before the halo rows arrived: read it again
@@ -380,6 +385,7 @@ __device__ __forceinline__ void mfma_pipe_bf8(f32x16& c00, f32x16& c10, f32x16& 
   }
 }
 
+template <bool FAIRB>
 __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* xs = lds_raw;              // [80 frames][528 B]: bf16(x + d_l), frames t0-8 .. t0+71
@@ -563,7 +569,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
         __syncthreads();   // (A) halo rows in place
         STK_STAMP(2);
       };
-      mfma_pipe_bf8<16>(yg0, yf0, yg1, yf1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid);
+      mfma_pipe_bf8<16, FAIRB>(yg0, yf0, yg1, yf1, Ag, Af, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
+      if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
     // ---- gate -> zs; GEMM2's first weights fly meanwhile -------------------------------------------------------------------
@@ -600,7 +607,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
     {
       const char* zb = zs + l31 * ROWB + lh * 16;
       auto ldb = [&](int ks, int ct) { return *reinterpret_cast<const bf16x8*>(zb + 32 * ct * ROWB + ks * 32); };
-      mfma_pipe_bf8<0>(yg0, yf0, yg1, yf1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {});
+      mfma_pipe_bf8<0, FAIRB>(yg0, yf0, yg1, yf1, Ag, Af, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
+      if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (l + 1 < L) prefetch_a1(l + 1);
 #pragma unroll
@@ -879,15 +887,19 @@ int launch_step_tail_bf16(const TailArgs& a_in, hipStream_t st) {
 int stack_bf16_occupancy() {
   const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel, 512, lds) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel<true>, 512, lds) != hipSuccess)
     return 0;
   return o;
 }
 
 int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st) {
   const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
-  hipLaunchKernelGGL(residual_stack_bf16_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
+  static int fair = -1;
+  if (fair < 0) { const char* e = getenv("BSG_BF16_FAIR"); fair = e ? atoi(e) : 1; }
+  if (fair) hipLaunchKernelGGL(residual_stack_bf16_kernel<true>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL(residual_stack_bf16_kernel<false>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

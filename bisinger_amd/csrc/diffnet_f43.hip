@@ -564,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
   do {                                                                                                            \
     if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+  const unsigned long long clk0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;   // shader clock, to price the phases in cycles
 #pragma unroll 1
   for (int l = 0; l < L; ++l) {
     const int dil = 1 << (l % p.cycle);
@@ -728,7 +729,13 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
         }
     }
     STK_STAMP(5);
-    if (l + 1 == L) break;
+    if (l + 1 == L) {
+      if (p.stamps && tid == 0) {   // slots 6, 7 of the last layer: shader cycles from the first layer's start to here
+        p.stamps[((long long)tile_id * L + l) * 8 + 6] = clk0;
+        p.stamps[((long long)tile_id * L + l) * 8 + 7] = __builtin_amdgcn_s_memtime();
+      }
+      break;
+    }
     // ---- wait for the neighbours' edges of layer l+1, copy them into the halo rows ------------------------------------------------------
     if (tid < C) {   // d tables: every reader of d_l / d_{l+1} is behind barrier (C)
       dcur[tid] = dnxt[tid];
