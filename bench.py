@@ -212,11 +212,15 @@ def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps, repeats=3):
 # ------------------------------------------------------------------------------------------------------------------
 # rooflines
 # ------------------------------------------------------------------------------------------------------------------
-def traffic_from_profiles(bf16, frames_per_launch):
+def traffic_from_profiles(bf16, frames_per_launch, path=None):
+    """HBM-side bytes of the dominant kernel from the committed PMC summary (profiles/traffic*.json, written by
+    tools/summarize_profiles.py) — only when that summary describes the launch form that just ran (`path`) at this size."""
     tpath = os.path.join(ROOT, 'profiles', 'traffic_bf16.json' if bf16 else 'traffic.json')
     if not os.path.exists(tpath):
         return None
     tj = json.load(open(tpath))
+    if tj.get('path', 'bf16' if bf16 else 'layer') != (path or ('bf16' if bf16 else 'layer')):
+        return None
     if abs(tj.get('frames_per_launch', 16000) - frames_per_launch) < 1:
         return tj.get('residual_layer_kernel_hbm_bytes_per_launch')
     return None
@@ -234,11 +238,14 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
     concurrent = max(1, round(b_per_gpu * T_FRAMES / frames_per_launch))
     per_launch = FLOP_PER_FRAME_LAYER * frames_per_launch / (avg_ms * 1e-3) / 1e12
     achieved = per_launch * concurrent
-    traffic = traffic_from_profiles(bf16, frames_per_launch)
+    traffic = traffic_from_profiles(bf16, frames_per_launch, path)
     common = {'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer, 'frames_per_launch': frames_per_launch,
               'concurrent_launches': concurrent, 'traffic': traffic,
-              'traffic_condition': 'solo-launch PMC: rocprofv3 --pmc serialises kernels, so these are the HBM-side bytes (2 x FETCH_SIZE + '
-                                   'WRITE_SIZE, MI355X_MICROARCH.md) of one launch running alone, not of two chains in flight'}
+              'traffic_condition': ('PMC passes of the same command (profiles/traffic*.json): HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, '
+                                    'MI355X_MICROARCH.md) of the stack launch / 20 layers x launch groups; the stack path has one launch in '
+                                    'flight, so the serialised PMC run is the timed condition') if (path or '').startswith('stack') else
+                                   ('solo-launch PMC: rocprofv3 --pmc serialises kernels, so these are the HBM-side bytes (2 x FETCH_SIZE + '
+                                    'WRITE_SIZE, MI355X_MICROARCH.md) of one launch running alone, not of two chains in flight')}
     if bf16 and path == 'stack_bf16':
         # one launch = all 20 layers of up to 256 64-frame tiles; the timed region is the launch group of one DiffNet evaluation and
         # n_layer counts its layers, so avg_ms is the time of one layer over all rows.  1,048,576 FLOP / 1.38 KB = 760 FLOP/B is
@@ -270,6 +277,8 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
                     achieved=achieved, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_F32_MFMA_TFLOPS,
                     executed_tflops=executed, frac_executed=executed / PEAK_F32_MFMA_TFLOPS,
                     flop_per_launch=FLOP_PER_FRAME_LAYER * frames_per_launch, achieved_per_launch=per_launch,
+                    algorithmic_bytes_per_layer=6 * 256 * 4 * frames_per_launch,
+                    traffic_over_algorithmic=traffic / (6 * 256 * 4 * frames_per_launch) if traffic else None,
                     note='achieved = algorithmic FLOPs (direct conv, SURVEY §8d) of one layer over the batch / (launch-group duration / 20 '
                          'layers), HIP events around the launch group on its own stream; frac_executed prices the FLOPs the F(4,3) form '
                          'issues (5/8 of the direct form) = matrix-pipe busy share.  The algorithmic rate exceeds the fp32 MFMA peak '

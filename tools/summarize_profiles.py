@@ -69,15 +69,36 @@ for cfg in ('f32', 'bf16', 'voc'):
         if e:
             per_kernel[k] = e
     summ = {'configuration': cfg, 'per_kernel': per_kernel}
-    dom = {'f32': 'residual_layer_kernel<false, true>', 'bf16': 'residual_layer_bf16_kernel<false>'}.get(cfg)
-    if dom and dom in per_kernel and 'hbm_bytes_per_launch' in per_kernel[dom]:
+    # dominant kernel of the configuration: a stack launch (all 20 layers of a launch group in one kernel) or a per-layer launch.
+    # Figures are normalised to ONE LAYER OVER THE WHOLE BATCH for the stack forms (launch bytes x launch groups / 20), which is the unit
+    # bench.py's roofline uses for them; for per-layer launches they are per launch.
+    batch_frames = 64000 if cfg == 'bf16' else 16000
+    cands = {'f32': [('residual_stack_f43_kernel<1>', 'stack_f43'), ('residual_stack_f43_kernel<0>', 'stack_f43'),
+                     ('residual_layer_kernel<false, true>', 'layer')],
+             'bf16': [('residual_stack_bf16_kernel<true>', 'stack_bf16'), ('residual_stack_bf16_kernel<false>', 'stack_bf16'),
+                      ('residual_layer_bf16_kernel<false>', 'bf16')]}.get(cfg, [])
+    for dom, path in cands:
+        if dom not in per_kernel or 'hbm_bytes_per_launch' not in per_kernel[dom]:
+            continue
         n = out[dom]['FETCH_SIZE']['n']
-        frames = (64000 if cfg == 'bf16' else 16000) * 2000 // max(n, 1)   # one pass = 100 steps x 20 layers; more launches = half-batch chains
-        alg = (4 if cfg == 'bf16' else 6) * 256 * 4 * frames
-        summ['traffic'] = {'kernel': dom, 'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg,
-                           'residual_layer_kernel_hbm_bytes_per_launch': per_kernel[dom]['hbm_bytes_per_launch'],
-                           'traffic_over_algorithmic': round(per_kernel[dom]['hbm_bytes_per_launch'] / alg, 3),
+        by = per_kernel[dom]['hbm_bytes_per_launch']
+        if path.startswith('stack'):
+            groups = max(1, n // 100)                     # the PMC passes run one 100-step pass: launches per DiffNet evaluation
+            frames, by = batch_frames, by * groups / 20   # one layer over the batch
+            # what the on-chip form must move per frame and layer: conditioner term (fp32 2 KB / bf16 1 KB) + running skip sum r+w
+            # (fp32 2 KB; bf16 form: in registers) + x in / skip out once per 20 layers + edges through L2
+            alg_form = (2048 + 2048 + 1024 / 20) * frames if cfg == 'f32' else (1024 + 2048 / 20 + 2 * 8192 / 64) * frames
+        else:
+            frames = batch_frames * 2000 // max(n, 1)     # one pass = 100 steps x 20 layers; more launches = half-batch chains
+            alg_form = (4 if cfg == 'bf16' else 6) * 256 * 4 * frames
+        alg = (4 if cfg == 'bf16' else 6) * 256 * 4 * frames   # one fused kernel per layer
+        summ['traffic'] = {'kernel': dom, 'path': path, 'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg,
+                           'algorithmic_bytes_of_this_form': alg_form,
+                           'residual_layer_kernel_hbm_bytes_per_launch': by,
+                           'traffic_over_algorithmic': round(by / alg, 3),
                            'mfma_pipe_utilisation': per_kernel[dom].get('mfma_pipe_utilisation'),
+                           'unit': 'one layer over the whole batch (launch bytes x launch groups / 20)' if path.startswith('stack') else 'one launch',
                            'condition': 'solo launch (PMC passes serialise kernels)'}
+        break
     json.dump(summ, open(f'{dst}/bench_{cfg}_pmc_summary.json', 'w'), indent=1)
     print(cfg, json.dumps(summ.get('traffic', {k: v for k, v in list(per_kernel.items())[:3]}), indent=1)[:1500])
