@@ -268,6 +268,22 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
                     traffic_over_algorithmic=traffic / (HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch) if traffic else None,
                     mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / PEAK_BF16_MFMA_TFLOPS,
                     note='achieved = algorithmic bytes of one launch / its average duration (HIP events on its own stream) x launches in flight')
+    if path == 'stack_h2':
+        # split-fp16 stack launch (diffnet_h2.hip): every fp32 product as 3 fp16 MFMA products (hi hi, hi lo, lo hi), fp32 accumulate, so
+        # the matrix pipe in use is the 16-bit one.  One launch = all 20 layers of up to 256 64-frame tiles; avg_ms = one layer over all rows
+        executed = 3.0 * achieved
+        return dict(common, kernel='residual_stack_h2_kernel (20 fused DiffNet residual blocks per launch; fp32 operands split exactly into hi + lo '
+                                   'fp16 terms, 3 fp16 MFMAs per fp32 product, fp32 accumulate; x and the skip sum on chip; figures per layer)',
+                    bound='mfma', achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_BF16_MFMA_TFLOPS,
+                    executed_tflops=executed, frac_executed=executed / PEAK_BF16_MFMA_TFLOPS,
+                    achieved_over_fp32_mfma_peak=achieved / PEAK_F32_MFMA_TFLOPS,
+                    flop_per_launch=FLOP_PER_FRAME_LAYER * frames_per_launch, achieved_per_launch=per_launch,
+                    algorithmic_bytes_per_layer=6 * 256 * 4 * frames_per_launch,
+                    traffic_over_algorithmic=traffic / (6 * 256 * 4 * frames_per_launch) if traffic else None,
+                    note='achieved = algorithmic FLOPs (direct conv, SURVEY §8d) of one layer over the batch / (launch-group duration / 20 '
+                         'layers), HIP events around the launch group on its own stream; peak = dense fp16 MFMA (= bf16, MI355X_MICROARCH.md): '
+                         'the pipe the products run on.  frac_executed prices the 3 fp16 products issued per fp32 product = matrix-pipe busy '
+                         'share.  Arithmetic is fp32-grade: product error <= 3 x 2^-24, fp32 accumulation (tests/test_gpu_h2.py vs float64)')
     if path == 'stack_f43':
         # one launch = all 20 layers of up to 256 64-frame tiles, one workgroup per CU; the timed region is the launch group of one
         # DiffNet evaluation and n_layer counts its layers, so avg_ms is the time of one layer over all rows

@@ -1281,6 +1281,9 @@ struct bsg_diffnet {
   float* apackw43 = nullptr;  // [L][6*2C*C]  Winograd F(4,3) form (diffnet_f43.hip)
   unsigned short* apack1h = nullptr;  // [L][2C*3C] bf16 fragments (bf16-operand form, diffnet_bf16.hip)
   unsigned short* apack2h = nullptr;  // [L][2C*C]
+  unsigned short* apack1s = nullptr;  // [L][2 planes][2C*3C] hi / lo fp16 fragments (split-fp16 form of the fp32 stack launch, diffnet_h2.hip)
+  unsigned short* apack2s = nullptr;  // [L][2 planes][2C*C]
+  float* h2_scale = nullptr;          // [L][4] power-of-two scales of the split-fp16 form
   unsigned short* tail_h = nullptr;   // bf16 step tail (step_tail_bf16_kernel): skip projection [C*C], output projection [96*C], input projection [C*96]
   int compute = BSG_COMPUTE_F32;      // bsg_diffnet_set_compute
   unsigned short* condterm_h = nullptr;  // [L][B][2C/4][T][4] bf16 (bf16 mode only)
@@ -1326,6 +1329,8 @@ struct bsg_diffnet {
   int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
   int occ_stack43 = -1;                // the same for residual_stack_f43_kernel
   bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
+  bool stack_is_h2 = false;            // ... the split-fp16 stack launch (diffnet_h2.hip)
+  int occ_stack_h2 = -1;               // resident workgroups per CU of residual_stack_h2_kernel (-1: not queried)
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1375,6 +1380,9 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->skip_h) (void)hipFree(h->skip_h);
   if (h->apack2h) (void)hipFree(h->apack2h);
   if (h->tail_h) (void)hipFree(h->tail_h);
+  if (h->apack1s) (void)hipFree(h->apack1s);
+  if (h->apack2s) (void)hipFree(h->apack2s);
+  if (h->h2_scale) (void)hipFree(h->h2_scale);
   delete h;
 }
 
@@ -1418,6 +1426,9 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&h->apack2w, (size_t)L * 2 * C * C));
   BSG_HIP(hipMalloc((void**)&h->apack1h, (size_t)L * 2 * C * 3 * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->apack2h, (size_t)L * 2 * C * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->apack1s, (size_t)L * 2 * 2 * C * 3 * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->apack2s, (size_t)L * 2 * 2 * C * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->h2_scale, (size_t)(4 * L + 2 * L) * sizeof(float)));   // table + [2L] scratch of the max reduction
   TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->b_cond, (size_t)L * 2 * C));
   TRY(dev_alloc(&h->b_out, (size_t)L * 2 * C));
@@ -1434,6 +1445,11 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&dtab, (size_t)S * C));
   int rc = gemm_nt(step_table, (const float*)w[2], hid, (const float*)w[3], S, 4 * C, C, C, 4 * C, ACT_MISH, st);
   if (rc == BSG_OK) rc = gemm_nt(hid, (const float*)w[4], dtab, (const float*)w[5], S, C, 4 * C, 4 * C, C, ACT_NONE, st);
+  if (rc == BSG_OK) {   // split-fp16 form: per-layer power-of-two scales from max |w|, then the hi / lo fragments below
+    std::vector<const float*> w1(L), w2(L);
+    for (int l = 0; l < L; ++l) { w1[l] = (const float*)w[6 + 8 * l]; w2[l] = (const float*)w[6 + 8 * l + 6]; }
+    rc = h2_scales(w1.data(), w2.data(), L, reinterpret_cast<unsigned*>(h->h2_scale + 4 * L), h->h2_scale, st);
+  }
   for (int l = 0; l < L && rc == BSG_OK; ++l) {
     const void* const* lw = w + 6 + 8 * l;
     // dilated conv [2C][C][3] -> fragment order with k = tap*C + ci
@@ -1452,6 +1468,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
     rc = pack_wino43((const float*)lw[0], h->apackw43 + (size_t)l * 6 * 2 * C * C, st);
     if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[0], h->apack1h + (size_t)l * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, st);
     if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[6], h->apack2h + (size_t)l * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, st);
+    if (rc == BSG_OK) rc = pack_a_frag_h2((const float*)lw[0], h->apack1s + (size_t)l * 2 * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, h->h2_scale + 4 * l, 0, st);
+    if (rc == BSG_OK) rc = pack_a_frag_h2((const float*)lw[6], h->apack2s + (size_t)l * 2 * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, h->h2_scale + 4 * l, 1, st);
     if (rc != BSG_OK) break;
     hipLaunchKernelGGL(pack_a16_kernel, dim3(cdiv(2 * C * C, 256)), dim3(256), 0, st, (const float*)lw[6], h->apack2w + (size_t)l * 2 * C * C,
                        2 * C, C);
@@ -1773,6 +1791,28 @@ static constexpr size_t kStackLds = (size_t)C * (32 + 2 * HALO + 32) * sizeof(fl
 // launch has more workgroups than CUs (two per CU overlap each other's waits); smaller launches keep the channel-split kernels.
 static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
   h->stack_is_f43 = false;
+  h->stack_is_h2 = false;
+  {
+    // split-fp16 form (diffnet_h2.hip): fp32 operands as hi + lo fp16 terms on the 16-bit matrix pipe; 64-frame tiles, one workgroup per
+    // CU, whole rows per launch group.  BSG_H2=0: off; 2: for any shape that is resident (tests); default 1: launch groups >= 50 % full
+    static int envh2 = -1;
+    if (envh2 < 0) { const char* e = getenv("BSG_H2"); envh2 = e ? atoi(e) : 1; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st) (void)hipStreamIsCapturing(st, &cap);
+    if (envh2 && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && h->apack1s && cap == hipStreamCaptureStatusNone) {
+      if (h->occ_stack_h2 < 0) h->occ_stack_h2 = stack_h2_occupancy() >= 1 ? 1 : 0;
+      const int tpr = cdiv(T, 64);
+      if (h->occ_stack_h2 >= 1 && tpr <= h->num_cus) {
+        int rows = h->num_cus / tpr;
+        if (rows > B) rows = B;
+        const int groups = cdiv(B, rows);
+        if (envh2 == 2 || (long long)B * tpr * 2 >= (long long)groups * h->num_cus) {
+          h->stack_is_h2 = true;
+          return rows;
+        }
+      }
+    }
+  }
   if (wino_env() == 43 || wino_env() == 2) {
     // F(4,3) form (diffnet_f43.hip): 64-frame tiles, one workgroup per CU, whole rows per launch group; BSG_STACK43=0 keeps per-layer
     // launches.  A launch group takes the same time whatever part of the chip it fills, so the form is taken when the groups are
@@ -1819,8 +1859,8 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
 
 static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
                         unsigned long long* stamps = nullptr) {
-  const bool f43 = h->stack_is_f43;   // the decision of the stack_rows() call that returned rows_per_launch
-  const int tpr = cdiv(T, f43 ? 64 : 32);
+  const bool f43 = h->stack_is_f43, h2 = h->stack_is_h2;   // the decision of the stack_rows() call that returned rows_per_launch
+  const int tpr = cdiv(T, f43 || h2 ? 64 : 32);
   const size_t bt = (size_t)h->B * T;   // bound batch: per-layer stride of the conditioner term
   for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
     const int nb = B - r0 < rows_per_launch ? B - r0 : rows_per_launch;
@@ -1840,7 +1880,10 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.fbase = h->stack_epoch * 64u;
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
-    if (f43) {
+    if (h2) {
+      p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
+      TRY(launch_residual_stack_h2(p, st));
+    } else if (f43) {
       p.apackw43 = h->apackw43;
       TRY(launch_residual_stack_f43(p, st));
     } else {
@@ -1848,7 +1891,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       BSG_LAUNCH_CHECK();
     }
   }
-  h->last_path = f43 ? "stack_f43" : "stack";
+  h->last_path = h2 ? "stack_h2" : f43 ? "stack_f43" : "stack";
   return BSG_OK;
 }
 

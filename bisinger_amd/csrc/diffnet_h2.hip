@@ -1,0 +1,493 @@
+// fp32 DiffNet residual stack on the 16-bit matrix pipe: every fp32 operand split EXACTLY into two fp16 terms.
+//
+// Same contract, tensors and results (to fp32 rounding) as the fp32 stack launches (diffnet.hip residual_stack_kernel,
+// diffnet_f43.hip; reference semantics /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130).  gfx950 multiplies fp32
+// operands at 256 FLOP/clk/CU (v_mfma_f32_32x32x2_f32) and fp16 operands at 4096 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  An
+// fp32 value a is hi + lo with hi = fp16(a), lo = fp16(a - hi): 11 + 11 significand bits plus the sign of lo cover the 24 of fp32, so
+// |a - hi - lo| <= 2^-24 |a| (half an fp32 ulp) as long as lo is a normal fp16.  A product of two such values is
+//     a b = ah bh + ah bl + al bh   (+ al bl, <= 2^-24 |a b|: dropped)
+// and each of the three terms is a product of fp16 numbers — EXACT in the fp32 the matrix pipe accumulates in.  Three fp16 MFMAs of
+// K = 16 replace eight fp32 MFMAs of K = 2: 3/16 of the matrix cycles of the direct fp32 form (the F(4,3) Winograd form needs 10/16).
+// The error of a product is <= 3 x 2^-24 relative — the size of ONE fp32 rounding, and a dot product of K = 256..768 terms is
+// dominated by the roundings of its fp32 accumulation either way (measured: tests/test_gpu_h2.py compares both against float64).
+//   Range.  fp16 normals span 2^-14 .. 65504.  Weights are multiplied by a power of two per layer and GEMM (chosen at create so that
+// max |w| lands in [2^13, 2^14)) and z, which lies in (-1, 1), by 2^10; the accumulators start from (initial value) x (scale) and are
+// multiplied by 1 / scale afterwards — all exact.  Activations x + d are split unscaled: below 0.5 their lo term is a subnormal
+// fp16 and carries an ABSOLUTE error of <= 2^-25 (3e-8, half an fp32 ulp of 0.5); |x + d| must stay below 65504.
+//
+// Structure: the on-chip stack launch of the bf16 configuration (diffnet_bf16.hip residual_stack_bf16_kernel) with two fp16 planes
+// per LDS image and per weight slab: one workgroup of 8 waves x 256 registers per CU owns a 64-frame tile for all L layers; x and the
+// running skip sum live in registers (fp32, accumulator layout); the conv input image x + d_l is rewritten in LDS (hi and lo plane,
+// channels-last) by the waves that own the channels; neighbours exchange the two 8-frame edges of both planes through L2 (16 KB per
+// tile and layer) under the centre tap of GEMM1; the conditioner term (fp32, 2 KB per frame and layer: the only HBM stream) is
+// requested into the free accumulators a phase ahead.  LDS: 2 x 42,240 (image) + 2 x 33,792 (z) + 3 KB of tables = 155,136 B.
+#include "diffnet_res.h"
+
+namespace bsg {
+
+namespace {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+constexpr int NT = 64;                    // frames per workgroup
+constexpr int ROWB = 2 * C + 16;          // LDS image row: 256 fp16 + 16 B pad = 528 B (132 dwords = 4 mod 64)
+constexpr int XROWS = NT + 2 * HALO;      // 80
+constexpr int XP = XROWS * ROWB;          // bytes per plane of the image: 42,240
+constexpr int ZP = NT * ROWB;             // bytes per plane of z: 33,792
+constexpr int NSH = 4;                    // weight ring (k-steps)
+constexpr int PLB = 16 * 1024;            // bytes per plane of a k-step slab (16 row tiles x 1 KB)
+constexpr int KSB2 = 2 * PLB;             // bytes per k-step: hi slab, lo slab
+constexpr float ZSCALE = 1024.0f;         // z in (-1, 1) is split as z x 2^10
+constexpr size_t H2_LDS = (size_t)2 * XP + 2 * ZP + 3 * C * sizeof(float);
+
+// scale table, per layer: [0] s1 (GEMM1 weights x s1), [1] 1 / s1, [2] s2 x 2^10 (GEMM2 weights x s2, z x 2^10), [3] its reciprocal
+__global__ void h2_absmax_kernel(const float* __restrict__ src, long long n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(fabsf(src[i])));   // non-negative floats order like their bit patterns
+  atomicMax(out, m);
+}
+__global__ void h2_scale_kernel(const unsigned* __restrict__ maxbits, float* __restrict__ tab, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * L) return;
+  const float mx = __uint_as_float(maxbits[i]);
+  // max |w| x s in [2^13, 2^14): hi never overflows, and lo = (w - hi) x s is a normal fp16 for every |w| >= 2^-15 max |w|
+  const float s = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, 13 - ilogbf(mx)) : 1.0f;
+  const float tot = (i & 1) ? s * ZSCALE : s;
+  tab[2 * i] = tot;
+  tab[2 * i + 1] = 1.0f / tot;   // a power of two: exact
+}
+
+// out[(((ks*2 + plane)*(M/32) + rt)*64 + lane)*8 + j] = plane ? lo : hi of  s x W(m = 32 rt + (lane & 31), k = 16 ks + 8 (lane >> 5) + j)
+// with W(m,k) at src[m*sm + (k % Kc)*sc + (k / Kc)*st]   (dilated conv: k = tap*C + ci, src [2C][C][3]); s = tab[0] / ZSCALE or tab[0]
+__global__ void pack_a_frag_h2_kernel(const float* __restrict__ src, _Float16* __restrict__ out, int M, int K, int Kc, long long sm,
+                                      long long sc, long long st, const float* __restrict__ tab, int is_gemm2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * K) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  const long long rest = i >> 9;
+  const int RT = M / 32;
+  const int rt = (int)(rest % RT), ks = (int)(rest / RT);
+  const int m = 32 * rt + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+  const float s = is_gemm2 ? tab[0] / ZSCALE : tab[0];
+  const float v = src[(long long)m * sm + (long long)(k % Kc) * sc + (long long)(k / Kc) * st] * s;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  const long long base = ((long long)(ks * 2) * RT + rt) * 512 + lane * 8 + j;
+  out[base] = hi;
+  out[base + (long long)RT * 512] = lo;
+}
+
+__device__ __forceinline__ f16x8 lda8(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// hi / lo split of two values into two packed dwords
+struct HiLo { unsigned hi, lo; };
+__device__ __forceinline__ HiLo split2(float a, float b) {
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  return HiLo{__builtin_bit_cast(unsigned, f16x2{ha, hb}),
+              __builtin_bit_cast(unsigned, f16x2{(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)})};
+}
+
+#define BSG_MFMA_H(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, ACC, 0, 0, 0)
+
+// i-th executed k-step -> k-step index: GEMM1 (ROT = 16, 48 k-steps, tap-major) starts with the CENTRE tap, whose B operand is the
+// tile's own 64 frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
+template <int ROT>
+__device__ __forceinline__ int kmap(int i) {
+  if (ROT == 0) return i;
+  return i < ROT ? i + ROT : (i < 2 * ROT ? i - ROT : i);
+}
+
+// k-step pipeline over two row tiles x two column tiles, 12 MFMAs per k-step (hi hi, hi lo, lo hi for each of the 4 accumulators; an
+// accumulator is revisited every 4th MFMA).  A[s] = {row tile 0 hi, row tile 0 lo, row tile 1 hi, row tile 1 lo} of ring slot s,
+// refilled right after use (NSH k-steps = 48 MFMAs ahead); the B fragments of the next k-step (LDS: column tile 0 hi, lo, column tile
+// 1 hi, lo) are read before the MFMAs of the current one.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0:
+// never): the hand-off with the neighbours sits there, under the centre tap's MFMAs; the ring keeps prefetching across it.
+// FAIRB: the two waves of a SIMD take turns at issue priority (see f43_gemm1, diffnet_f43.hip).
+template <int ROT, bool FAIRB, typename LDB, typename MID>
+__device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
+                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
+  f16x8 B[2][4];
+  ldb(kmap<ROT>(0), B[0]);
+  const int last = n_ks - 1;
+#pragma unroll 1
+  for (int ks = 0; ks < n_ks; ks += NSH) {
+    if (FAIRB) {
+      const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+      if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    if (ROT > 0 && ks == ROT) {
+      mid();
+      ldb(kmap<ROT>(ks), B[0]);   // the B operand of the next k-step was read before the halo rows arrived: read it again
+    }
+#pragma unroll
+    for (int s = 0; s < NSH; ++s) {
+      const int in = ks + s + 1 <= last ? ks + s + 1 : last;
+      ldb(kmap<ROT>(in), B[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8(&Bc)[4] = B[s & 1];
+      BSG_MFMA_H(c00, A[s][0], Bc[0]);
+      BSG_MFMA_H(c10, A[s][2], Bc[0]);
+      BSG_MFMA_H(c01, A[s][0], Bc[2]);
+      BSG_MFMA_H(c11, A[s][2], Bc[2]);
+      BSG_MFMA_H(c00, A[s][0], Bc[1]);
+      BSG_MFMA_H(c10, A[s][2], Bc[1]);
+      BSG_MFMA_H(c01, A[s][0], Bc[3]);
+      BSG_MFMA_H(c11, A[s][2], Bc[3]);
+      BSG_MFMA_H(c00, A[s][1], Bc[0]);
+      BSG_MFMA_H(c10, A[s][3], Bc[0]);
+      BSG_MFMA_H(c01, A[s][1], Bc[2]);
+      BSG_MFMA_H(c11, A[s][3], Bc[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
+      const int kr = kmap<ROT>(ir);
+      A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
+      A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
+      A[s][2] = lda8(rs, vfrag, sa1 + kr * KSB2);
+      A[s][3] = lda8(rs, vfrag, sa1 + kr * KSB2 + PLB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <bool FAIRB>
+__global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;                  // [2 planes][80 frames][528 B]: hi / lo of x + d_l, frames t0-8 .. t0+71
+  char* zs = lds_raw + 2 * XP;         // [2 planes][64 frames][528 B]: hi / lo of 2^10 x gated activation
+  float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]: d_{l+1} per channel, fetched a layer ahead
+  float* btab = dtab + C;                                              // [512]: output-projection bias of the current layer
+
+  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile_id >= n_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tpr = p.tiles_per_row, L = p.L, T = p.T;
+  const int b = tile_id / tpr, j = tile_id - b * tpr;
+  const int t0 = j * NT;
+  const int tb = p.t_dev ? (int)p.t_dev[b] : p.t_uniform;
+  const bool has_left = j > 0, has_right = j + 1 < tpr;
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
+  const int rowT = T * 4, vfrag = lane * 16;
+  int vcol[2], vst[2];
+  bool col_ok[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = t0 + 32 * ct + l31;
+    col_ok[ct] = col < T;
+    vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
+    vst[ct] = (lh * 4 * T + col) * 4;
+  }
+  const int sa_g = wave * 1024, sa_f = (8 + wave) * 1024;   // gate / filter row tile inside a plane of a k-step slab
+  const int sb_r = wave * 1024, sb_s = (8 + wave) * 1024;   // residual / skip row tile
+
+  float xr[2][16];        // x, accumulator layout: registers 4g..4g+3 = channels 32w + 8g + 4 lh + (0..3) of frame 32 ct + l31
+  float sk[2][16];        // running skip sum (fp32), same layout (skip rows C + 32w + ..)
+  f32x16 yg0, yf0, yg1, yf1;   // GEMM1 accumulators; they start from the conditioner term x s1
+
+  // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 64 dword loads per lane, 128 B coalesced per half-wave,
+  // requested straight into the accumulators a phase before they are used
+  auto cond_request = [&](int l) {
+    const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int so = (32 * wave + acc_row0(r)) * rowT;
+      yg0[r] = ldf(rs_ct, vcol[0], so);
+      yf0[r] = ldf(rs_ct, vcol[0], so + C * rowT);
+      yg1[r] = ldf(rs_ct, vcol[1], so);
+      yf1[r] = ldf(rs_ct, vcol[1], so + C * rowT);
+    }
+  };
+  // image core (frames t0 .. t0+63, this wave's 32 channels) = hi / lo of x + d_l, zero beyond T (the conv pads x + d)
+  auto write_core = [&]() {   // d of the layer being prepared is in dtab (written a phase earlier, behind a barrier)
+    float dv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = dtab[32 * wave + acc_row(r, lh)];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const HiLo s0 = split2(xr[ct][4 * g] + dv[4 * g], xr[ct][4 * g + 1] + dv[4 * g + 1]);
+        const HiLo s1_ = split2(xr[ct][4 * g + 2] + dv[4 * g + 2], xr[ct][4 * g + 3] + dv[4 * g + 3]);
+        u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
+        if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+        char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
+        *reinterpret_cast<u32x2*>(dst) = wh;
+        *reinterpret_cast<u32x2*>(dst + XP) = wl;
+      }
+  };
+
+  // ---- layer 0: x from HBM (the whole input exists, halo included) ------------------------------------------------------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xr[ct][r] = ldf(rs_x, vcol[ct], (32 * wave + acc_row0(r)) * rowT);
+      sk[ct][r] = 0.f;
+    }
+  {
+    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
+    const int hf = tid & 15, hc = tid >> 4;   // 16 halo frames x 32 chunks of 8 channels
+    const int th = hf < 8 ? t0 - HALO + hf : t0 + NT - 8 + hf;
+    const int hrow = hf < 8 ? hf : NT + hf;
+    const bool hok = th >= 0 && th < T;
+    float hv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
+    const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
+    u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
+    if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
+    *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = wh;
+    *reinterpret_cast<u32x4*>(xs + XP + hrow * ROWB + hc * 16) = wl;
+  }
+  if (tid < C) dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
+  btab[tid] = p.bias_out[tid];
+  cond_request(0);
+  __syncthreads();
+  write_core();
+  // weight ring, shared by both GEMMs.  GEMM1's first k-steps (it starts with the centre tap: kmap) are requested a phase ahead —
+  // right behind the previous layer's GEMM2 — so that the L2 latency of the weight stream is never on the layer's critical path
+  f16x8 A[NSH][4];
+  auto prefetch_a1 = [&](int l) {
+    const rsrc_t rs = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) {
+      const int kr = kmap<16>(k);
+      A[k][0] = lda8(rs, vfrag, sa_g + kr * KSB2);
+      A[k][1] = lda8(rs, vfrag, sa_g + kr * KSB2 + PLB);
+      A[k][2] = lda8(rs, vfrag, sa_f + kr * KSB2);
+      A[k][3] = lda8(rs, vfrag, sa_f + kr * KSB2 + PLB);
+    }
+  };
+  prefetch_a1(0);
+
+#define STK_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int dil = 1 << (l % p.cycle);
+    const rsrc_t rs_a1 = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+    const rsrc_t rs_a2 = mk_rsrc(p.apack2s + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
+    const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
+    const float dnext = (tid < C && l + 1 < L) ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;   // lands during GEMM1
+    const float bnext = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
+    // GEMM1 accumulates (conditioner term + W x) x s1: the requested term is scaled on arrival (its first use)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { yg0[r] *= s1; yf0[r] *= s1; yg1[r] *= s1; yf1[r] *= s1; }
+    if (l == 0) __syncthreads();   // layer 0: the staged image (core + halo rows); later layers: barrier (C) below covers the core rows
+    STK_STAMP(0);
+    // ---- GEMM1: 48 k-steps.  The centre tap (16 k-steps) reads the tile's own frames only, so it runs while the neighbours'
+    // edges of this layer are still in flight; the wait for them, and the copy of the halo rows, sit behind it (mid) -------------
+    {
+      const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
+      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
+        const int tap = ks >> 4, kc = ks & 15;
+        const char* q = xb + ((tap - 1) * dil) * ROWB + kc * 32;
+        Bf[0] = *reinterpret_cast<const f16x8*>(q);
+        Bf[1] = *reinterpret_cast<const f16x8*>(q + XP);
+        Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
+        Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + XP);
+      };
+      auto mid = [&]() {
+        if (l == 0) return;   // layer 0 staged its halo rows from HBM
+        if (tid == 0) {
+          const unsigned want = p.fbase + (unsigned)l;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? !has_left : !has_right) continue;
+            const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
+            if (p.inject) { atomicAdd(p.status, 1u); continue; }
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
+                atomicAdd(p.status, 1u);
+                break;
+              }
+            }
+          }
+        }
+        __syncthreads();   // (D) the polling wave has seen both flags
+        STK_STAMP(1);
+        {
+          // halo rows of this layer, both planes: rows 0..7 = the left neighbour's last 8 frames, rows 72..79 = the right neighbour's
+          // first 8.  Write-through (sc1) stores, drained before the flag, one workgroup per CU, and EVERY load of the handed-off
+          // bytes an sc1 buffer load to registers: the hand-off form that needs no agent-scope acquire (MI355X_MICROARCH.md)
+          const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+          const bool have = side == 0 ? has_left : has_right;
+          u32x4 vh = u32x4{0u, 0u, 0u, 0u}, vl = u32x4{0u, 0u, 0u, 0u};
+          if (have) {
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(p.hx) +
+                                        ((long long)(l & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (4 * 8 * C);
+            const rsrc_t rs_h = mk_rsrc(src, 4 * 8 * C * 2);
+            const int o = (((side == 0 ? 8 : 0) + f) * C + c16 * 8) * 2;   // the neighbour's side 1 (its last frames) for our left halo
+            vh = __builtin_amdgcn_raw_buffer_load_b128(rs_h, o, 0, 16);                 // sc1
+            vl = __builtin_amdgcn_raw_buffer_load_b128(rs_h, o + 2 * 8 * C * 2, 0, 16);   // lo plane
+          }
+          char* dst = xs + ((side ? HALO + NT : 0) + f) * ROWB + c16 * 16;
+          *reinterpret_cast<u32x4*>(dst) = vh;
+          *reinterpret_cast<u32x4*>(dst + XP) = vl;
+        }
+        __syncthreads();   // (A) halo rows in place
+        STK_STAMP(2);
+      };
+      mfma_pipe_h2<16, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
+      if (FAIRB) __builtin_amdgcn_s_setprio(0);
+    }
+    STK_STAMP(3);
+    // ---- gate -> zs (hi / lo of 2^10 z); GEMM2's first weights fly meanwhile ------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) {
+      A[k][0] = lda8(rs_a2, vfrag, sb_r + k * KSB2);
+      A[k][1] = lda8(rs_a2, vfrag, sb_r + k * KSB2 + PLB);
+      A[k][2] = lda8(rs_a2, vfrag, sb_s + k * KSB2);
+      A[k][3] = lda8(rs_a2, vfrag, sb_s + k * KSB2 + PLB);
+    }
+    if (tid < C) dtab[tid] = dnext;   // read by write_core() behind barrier (B)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const f32x16& yg = ct ? yg1 : yg0;
+      const f32x16& yf = ct ? yf1 : yf0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float z0 = ZSCALE * gate1(yg[4 * g] * inv1, yf[4 * g] * inv1), z1 = ZSCALE * gate1(yg[4 * g + 1] * inv1, yf[4 * g + 1] * inv1);
+        const float z2 = ZSCALE * gate1(yg[4 * g + 2] * inv1, yf[4 * g + 2] * inv1), z3 = ZSCALE * gate1(yg[4 * g + 3] * inv1, yf[4 * g + 3] * inv1);
+        const HiLo s0 = split2(z0, z1), s1_ = split2(z2, z3);
+        const u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
+        char* dst = zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
+        *reinterpret_cast<u32x2*>(dst) = wh;
+        *reinterpret_cast<u32x2*>(dst + ZP) = wl;
+      }
+    }
+    // residual rows start from (x + b_out) x s2', skip rows from b_out x s2' (the accumulators of GEMM1 are free now)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float br = btab[32 * wave + acc_row(r, lh)], bs = btab[C + 32 * wave + acc_row(r, lh)];
+      yg0[r] = (xr[0][r] + br) * s2;
+      yg1[r] = (xr[1][r] + br) * s2;
+      yf0[r] = bs * s2;
+      yf1[r] = bs * s2;
+    }
+    __syncthreads();   // (B) zs complete; every wave is done reading xs and this layer's biases
+    btab[tid] = bnext;
+    STK_STAMP(4);
+    // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows -----------------------------------------------------------
+    {
+      const char* zb = zs + l31 * ROWB + lh * 16;
+      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
+        const char* q = zb + ks * 32;
+        Bf[0] = *reinterpret_cast<const f16x8*>(q);
+        Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
+        Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
+        Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + ZP);
+      };
+      mfma_pipe_h2<0, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
+      if (FAIRB) __builtin_amdgcn_s_setprio(0);
+    }
+    if (l + 1 < L) prefetch_a1(l + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xr[0][r] = (yg0[r] * inv2) / 1.41421356237309504880f;   // (x + residual) / sqrt(2), net.py:78
+      xr[1][r] = (yg1[r] * inv2) / 1.41421356237309504880f;
+      sk[0][r] += yf0[r] * inv2;
+      sk[1][r] += yf1[r] * inv2;
+    }
+    STK_STAMP(5);
+    if (l + 1 == L) break;
+
+    // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
+    // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
+    cond_request(l + 1);
+    write_core();
+    __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
+    STK_STAMP(6);
+    {
+      // publish the first and the last 8 frames of both planes: [plane][side][8 frames][256 ch] fp16 = 16 KB, write-through
+      unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (4 * 8 * C);
+      const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+      const char* srcp = xs + (HALO + (side ? NT - 8 : 0) + f) * ROWB + c16 * 16;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(srcp);
+      const u32x4 vl = *reinterpret_cast<const u32x4*>(srcp + XP);
+      if (!(p.inject && (tile_id & 1))) {
+        const rsrc_t rs_hx = mk_rsrc(hx_t, 4 * 8 * C * 2);
+        const int o = ((side * 8 + f) * C + c16 * 8) * 2;
+        __builtin_amdgcn_raw_buffer_store_b128(vh, rs_hx, o, 0, 16);                   // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(vl, rs_hx, o + 2 * 8 * C * 2, 0, 16);   // lo plane
+      }
+    }
+    // every storing wave drains its write-through stores before the flag goes up.  vmcnt counts in order: the 64 conditioner loads
+    // of this wave are older than its edge stores, so this also waits for them (they have had the image phase to land)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (C)
+    if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    STK_STAMP(7);
+  }
+#undef STK_STAMP
+  // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
+  {
+    const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
+    const float div = sqrtf((float)L);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+      if (col_ok[ct]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stf(sk[ct][r] / div, rs_sk, vst[ct], (32 * wave + acc_row0(r)) * rowT);
+      }
+  }
+}
+#undef BSG_MFMA_H
+
+}  // namespace
+
+int stack_h2_occupancy() {
+  int o = 0;
+  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_h2_kernel<true>, 512, H2_LDS) != hipSuccess)
+    return 0;
+  return o;
+}
+
+int launch_residual_stack_h2(const StackArgs& p, hipStream_t st) {
+  static int fair = -1;
+  if (fair < 0) { const char* e = getenv("BSG_H2_FAIR"); fair = e ? atoi(e) : 1; }
+  if (fair) hipLaunchKernelGGL(residual_stack_h2_kernel<true>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), H2_LDS, st, p);
+  else hipLaunchKernelGGL(residual_stack_h2_kernel<false>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), H2_LDS, st, p);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// scale table of all layers: maxbits [2L] scratch (zeroed here), tab [4L]; w1[l] = dilated conv [2C][C][3], w2[l] = output projection [2C][C]
+int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* maxbits, float* tab, hipStream_t st) {
+  BSG_HIP(hipMemsetAsync(maxbits, 0, (size_t)2 * L * sizeof(unsigned), st));
+  for (int l = 0; l < L; ++l) {
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3(64), dim3(256), 0, st, w1[l], (long long)2 * C * 3 * C, maxbits + 2 * l);
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3(64), dim3(256), 0, st, w2[l], (long long)2 * C * C, maxbits + 2 * l + 1);
+  }
+  hipLaunchKernelGGL(h2_scale_kernel, dim3(cdiv(2 * L, 64)), dim3(64), 0, st, (const unsigned*)maxbits, tab, L);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// fp32 [M][K] weights -> hi / lo fp16 A fragments of v_mfma_f32_32x32x16_f16, scaled by the layer's table entry (`tab` = the 4 floats
+// of the layer; is_gemm2 selects s2)
+int pack_a_frag_h2(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
+                   int is_gemm2, hipStream_t st) {
+  const long long total = (long long)M * K;
+  hipLaunchKernelGGL(pack_a_frag_h2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(out), M, K, Kc, sm, sc,
+                     stp, is_gemm2 ? tab + 2 : tab, is_gemm2);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+}  // namespace bsg

@@ -47,6 +47,9 @@ struct StackArgs {
   const unsigned short* apack2h;     // bf16 form: output projection fragments, layer 0; + l * 2C*C
   const unsigned short* condterm_h;  // bf16 form: conditioner term in channel-quad order, layer 0 / this launch's rows; + l * ct_stride
   const float* apack2;    // layer 0; + l * a2_stride
+  const unsigned short* apack1s;  // split-fp16 form (diffnet_h2.hip): hi / lo fp16 fragments of the dilated conv, layer 0; + l * 2*2C*3C
+  const unsigned short* apack2s;  // split-fp16 form: output projection, layer 0; + l * 2*2C*C
+  const float* h2_scale;          // split-fp16 form: [L][4] = s1, 1/s1, s2 * 2^10, 1/(s2 * 2^10)
   const float* bias_out;  // layer 0; + l * 2C
   long long ct_stride;
   float* hx;              // [2 parities][n_tiles][2 sides][C][8] edge exchange
@@ -61,6 +64,14 @@ struct StackArgs {
 // bf16 stack launch: 64-frame tiles, one workgroup per CU (see diffnet_bf16.hip); grid = p.n_tiles rounded up to 8
 int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st);
 int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf16_kernel (0 on error)
+
+// fp32 stack launch on the 16-bit matrix pipe: operands split exactly into hi + lo fp16 terms (diffnet_h2.hip); 64-frame tiles, one
+// workgroup per CU; grid = p.n_tiles rounded up to 8
+int launch_residual_stack_h2(const StackArgs& p, hipStream_t st);
+int stack_h2_occupancy();
+int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* maxbits, float* tab, hipStream_t st);
+int pack_a_frag_h2(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
+                   int is_gemm2, hipStream_t st);
 
 // fp32 residual layer with GEMM1 as Winograd F(4,3) (diffnet_f43.hip); same tensors, 64-frame tiles, one workgroup per CU
 int launch_residual_layer_f43(const ResArgs& a, hipStream_t st);

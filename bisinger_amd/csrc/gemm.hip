@@ -6,10 +6,18 @@
 // products in [tokens,C] layout (B operand [N,K], K contiguous), and the k=9 / k=3 Conv1d of the
 // FFN / duration predictor as K-segmented GEMMs over shifted A rows ("taps").
 //
-// Tile: 128x128x32 per 256-thread workgroup; wave (wm, wn) owns a 64x64 sub-tile = 2x2 MFMA tiles
-// (64 accumulator VGPRs).  Operands are staged through LDS ([row][33] padded images: the 32 lanes of
-// an MFMA operand read 32 different rows at one k -> 33-float stride = conflict-free ds_read_b32),
-// next tile prefetched into registers while the current one is multiplied.
+// Two kernels:
+//  * gemm_fast_kernel<BM, TRANS_B> — every 16-byte-aligned problem (all of the path's shapes).  Tile BM x 128 x 32 per 256-thread
+//    workgroup (BM = 128, or 64 when 128-row tiles would leave CUs without a second workgroup), double-buffered LDS with ONE barrier
+//    per k-tile; the next-but-one tile is in flight from global memory while the current one is multiplied.  K-contiguous operands
+//    keep their global layout in LDS ([row][32 + 4] floats): staging is a 16-byte load and a 16-byte ds_write per 4 elements, and an
+//    MFMA operand fragment is ONE ds_read_b128 per lane = 4 k-steps (lane half lh takes k = 8g + 4 lh + 0..3; A and B use the same
+//    map, so the chain is a permutation of the k order — exact fp32 products, different summation order).  The 36-float row stride
+//    puts the 16 rows of a b128 lane group on 16 different bank quads.
+//  * gemm_f32_kernel<TRANS_B> — round 1's kernel, kept for unaligned operands (K, lda or ldb not a multiple of 4, odd base
+//    addresses): 128x128x32, [row][33] images read with ds_read_b32, two barriers per k-tile.
+#include <stdlib.h>
+
 #include "bsg_common.h"
 
 namespace bsg {
@@ -198,11 +206,204 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_fast_kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int FBN = 128;
+constexpr int FLDN = FBN + 8;                       // !TRANS_B image [k][n]: the two lane halves (k and k + 4) land 32 banks apart
+
+template <int BM, int FBK, bool TRANS_B>   // FBK = 16 or 32: k extent of an LDS stage
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs g) {
+  constexpr int FLD = FBK + 4;   // row stride 20 / 36 floats: the 16 rows of a b128 lane group fall on 16 different bank quads
+  constexpr int A_FLOATS = BM * FLD;
+  constexpr int B_FLOATS = TRANS_B ? FBN * FLD : FBK * FLDN;
+  constexpr int NI = BM == 128 ? 2 : 1;             // column tiles of 32 per wave (2 row tiles always)
+  constexpr int A_LD4 = BM * FBK / 4 / 256;         // float4 loads per thread and k-tile
+  constexpr int B_LD4 = FBN * FBK / 4 / 256;
+  constexpr int KQ = FBK / 4, KQS = FBK == 32 ? 3 : 2;   // float4 per row of a K-contiguous tile
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                      // [2][BM][FLD]
+  float* Bs = lds + 2 * A_FLOATS;       // [2][FBN][FLD] or [2][FBK][FLDN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = BM == 128 ? wave >> 1 : 0, wn = BM == 128 ? wave & 1 : wave;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * FBN, bz = blockIdx.z;
+  const int b2 = g.batch2 > 1 ? g.batch2 : 1;
+  const int zo = bz / b2, zi = bz - zo * b2;
+  const float* __restrict__ A = g.A + (long long)zo * g.sA + (long long)zi * g.sA2;
+  const float* __restrict__ Bp = g.B + (long long)zo * g.sB + (long long)zi * g.sB2;
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kTiles = (g.K + FBK - 1) / FBK;
+  const int nIter = kTiles * g.taps;
+  f32x4 ra[A_LD4], rb[B_LD4];
+
+  auto load_tiles = [&](int it) {
+    const int tap = it / kTiles, k0 = (it - tap * kTiles) * FBK;
+    const int shift = g.tap_shift0 + tap;
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx >> KQS, gk = k0 + ((idx & (KQ - 1)) << 2);
+      const int gr = bm + row + shift;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr >= 0 && gr < g.M && (bm + row) < g.M && gk < g.K) v = *reinterpret_cast<const f32x4*>(A + (long long)gr * g.lda + gk);
+      ra[j] = v;
+    }
+    const float* Bt = Bp + (long long)tap * g.sTapB;
+    if (TRANS_B) {
+#pragma unroll
+      for (int j = 0; j < B_LD4; ++j) {
+        const int idx = tid + 256 * j;
+        const int gn = bn + (idx >> KQS), gk = k0 + ((idx & (KQ - 1)) << 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gn < g.N && gk < g.K) v = *reinterpret_cast<const f32x4*>(Bt + (long long)gn * g.ldb + gk);
+        rb[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_LD4; ++j) {
+        const int idx = tid + 256 * j;
+        const int gk = k0 + (idx >> 5), gn = bn + ((idx & 31) << 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < g.K && gn < g.N) v = *reinterpret_cast<const f32x4*>(Bt + (long long)gk * g.ldb + gn);   // N % 4 == 0: all in or all out
+        rb[j] = v;
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * A_FLOATS;
+    float* bs = Bs + buf * B_FLOATS;
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) {
+      const int idx = tid + 256 * j;
+      *reinterpret_cast<f32x4*>(as + (idx >> KQS) * FLD + ((idx & (KQ - 1)) << 2)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD4; ++j) {
+      const int idx = tid + 256 * j;
+      if (TRANS_B) *reinterpret_cast<f32x4*>(bs + (idx >> KQS) * FLD + ((idx & (KQ - 1)) << 2)) = rb[j];
+      else *reinterpret_cast<f32x4*>(bs + (idx >> 5) * FLDN + ((idx & 31) << 2)) = rb[j];
+    }
+  };
+
+  load_tiles(0);
+  store_tiles(0);
+  if (nIter > 1) load_tiles(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < nIter; ++it) {
+    const int cur = it & 1;
+    // tile it+1 (in registers since the previous iteration) goes to the other buffer — every wave finished reading that buffer
+    // before the barrier that ended the previous iteration — and tile it+2 is requested; both overlap the MFMAs below
+    if (it + 1 < nIter) store_tiles(cur ^ 1);
+    if (it + 2 < nIter) load_tiles(it + 2);
+    const float* as = As + cur * A_FLOATS + (wm * 64 + l31) * FLD + 4 * lh;
+    const float* bs = TRANS_B ? Bs + cur * B_FLOATS + (wn * 32 * NI + l31) * FLD + 4 * lh
+                              : Bs + cur * B_FLOATS + (4 * lh) * FLDN + wn * 32 * NI + l31;
+#pragma unroll
+    for (int g8 = 0; g8 < FBK / 8; ++g8) {
+      f32x4 a[2], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(as + mi * 32 * FLD + 8 * g8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (TRANS_B) {
+          b[ni] = *reinterpret_cast<const f32x4*>(bs + ni * 32 * FLD + 8 * g8);
+        } else {
+          const float* p = bs + (8 * g8) * FLDN + ni * 32;
+          b[ni] = f32x4{p[0], p[FLDN], p[2 * FLDN], p[3 * FLDN]};
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][e], b[ni][e], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue (as gemm_f32_kernel): lanes 0..31 of a register hold 32 consecutive columns of one row -> 128-B stores
+  float* __restrict__ C = g.C + (long long)zo * g.sC + (long long)zi * g.sC2;
+  const float* __restrict__ R = g.R ? g.R + (long long)zo * g.sR : nullptr;
+  const float* __restrict__ RS = g.rowscale ? g.rowscale + (long long)zo * g.sRS : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = bn + wn * 32 * NI + ni * 32 + l31;
+      const float bn_v = (g.bias_n && col < g.N) ? g.bias_n[(long long)zo * g.sBiasN + col] : 0.f;
+      const float ps_v = (g.post_scale_n && col < g.N) ? g.post_scale_n[col] : 1.f;
+      const float pb_v = (g.post_scale_n && col < g.N) ? g.post_shift_n[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm * 64 + mi * 32 + acc_row(r, lh);
+        if (row < g.M && col < g.N) {
+          float v = acc[mi][ni][r] + bn_v;
+          if (g.bias_m) v += g.bias_m[row];
+          if (g.alpha_ncols == 0 || col < g.alpha_ncols) v *= g.alpha;
+          if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+          else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          if (g.post_scale_n) v = v * ps_v + pb_v;
+          if (R) v += R[(long long)row * g.ldr + col];
+          if (RS) v *= RS[row];
+          C[(long long)row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+template <int BM, int FBK, bool TRANS_B>
+int launch_fast(const GemmArgs& g, hipStream_t st) {
+  constexpr size_t lds = (size_t)(2 * BM * (FBK + 4) + 2 * (TRANS_B ? FBN * (FBK + 4) : FBK * FLDN)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    BSG_HIP(hipFuncSetAttribute((const void*)gemm_fast_kernel<BM, FBK, TRANS_B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_fast_kernel<BM, FBK, TRANS_B>), dim3(cdiv(g.N, FBN), cdiv(g.M, BM), g.batch), dim3(256), lds, st, g);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
 }  // namespace
 
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   BSG_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.taps > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
   BSG_REQUIRE(g.batch <= 65535, "gemm: batch %d > 65535", g.batch);
+  static int v1 = -1;   // BSG_GEMM_V1=1: round 1's kernel for every problem (A/B measurements)
+  if (v1 < 0) { const char* e = getenv("BSG_GEMM_V1"); v1 = e ? atoi(e) : 0; }
+  // the fast kernel moves 16-byte pieces: every operand row and every batch / tap offset must keep 16-byte alignment
+  auto al4 = [](long long v) { return (v & 3) == 0; };
+  const bool aligned = al4(g.K) && al4(g.lda) && al4(g.ldb) && al4(g.sA) && al4(g.sA2) && al4(g.sB) && al4(g.sB2) && al4(g.sTapB) &&
+                       (g.trans_b || al4(g.N)) && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0;
+  if (aligned && !v1) {
+    // 64-row tiles when 128-row tiles would not give every CU two workgroups (e.g. [16000 x 256] outputs: 250 -> 500 workgroups)
+    const long long wg128 = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
+    const bool small = wg128 < 2 * 256;
+    static int bk = -1;   // BSG_GEMM_BK=32: 32-deep LDS stages (two workgroups per CU instead of three)
+    if (bk < 0) { const char* e = getenv("BSG_GEMM_BK"); bk = e ? atoi(e) : 16; }
+    if (bk == 32) {
+      if (g.trans_b) return small ? launch_fast<64, 32, true>(g, st) : launch_fast<128, 32, true>(g, st);
+      return small ? launch_fast<64, 32, false>(g, st) : launch_fast<128, 32, false>(g, st);
+    }
+    if (g.trans_b) return small ? launch_fast<64, 16, true>(g, st) : launch_fast<128, 16, true>(g, st);
+    return small ? launch_fast<64, 16, false>(g, st) : launch_fast<128, 16, false>(g, st);
+  }
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch);
   if (g.trans_b)
     hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, g);

@@ -1,0 +1,92 @@
+"""GPU: the split-fp16 form of the fp32 residual stack (csrc/diffnet_h2.hip) is fp32-grade arithmetic.
+
+Every fp32 operand is split exactly into hi + lo fp16 terms and every fp32 product is formed as hi*hi + hi*lo + lo*hi on the
+16-bit matrix pipe with fp32 accumulation (error of a product <= 3 x 2^-24 relative: the size of one fp32 rounding).  The claim
+tested here: measured against a FLOAT64 evaluation of the same network (oracle.diffnet.diffnet_forward(dtype=float64), the
+restatement of /root/reference/train_bisinger/usr/diff/net.py:107-130), the split-fp16 launch is as close as the launches that
+multiply on the fp32 matrix pipe (direct K=768 form, Winograd F(2,3), Winograd F(4,3)) — not "within the 1e-3 bar", but within
+the rounding noise of fp32 itself.  One child process per form (the switches are read once per process)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from bisinger_amd import synth
+from oracle import diffnet as odn
+from tests.util import load_formula_weights, use_config
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, json, torch, numpy as np
+sys.path.insert(0, %r)
+from tests.util import load_formula_weights, use_config
+from bisinger_amd import synth
+torch.set_grad_enabled(False)
+use_config()
+from bisinger_amd.diffnet import DiffNet
+B, T, wscale = %d, %d, %r
+net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.')
+if wscale != 1.0:
+    for l in net.residual_layers:
+        l.dilated_conv.weight.mul_(wscale)
+        l.output_projection.weight.mul_(1.0 / wscale)
+net = net.cuda()
+rs = np.random.RandomState(5)
+x = torch.from_numpy(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
+cond = torch.from_numpy(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+t = torch.from_numpy(rs.randint(0, 100, size=(B,)).astype(np.int64)).cuda()
+eps = net(x, t, cond)
+np.save(sys.argv[1], eps.cpu().numpy())
+print(json.dumps({'path': net.last_path(), 'timeouts': net.handoff_timeouts()}))
+'''
+
+FORMS = {
+    'split_fp16': ({'BSG_H2': '2'}, 'stack_h2'),
+    'fp32_direct': ({'BSG_H2': '0', 'BSG_WINO': '0', 'BSG_SPLIT': '0'}, 'layer'),
+    'fp32_wino23': ({'BSG_H2': '0', 'BSG_WINO': '1', 'BSG_SPLIT': '0'}, 'layer'),
+    'fp32_wino43': ({'BSG_H2': '0', 'BSG_WINO': '43', 'BSG_STACK43': '2'}, 'stack_f43'),
+}
+
+
+@pytest.mark.parametrize('B,T,wscale', [(8, 300, 1.0), (3, 1000, 1.0), (4, 250, 1.0 / 256.0)])
+def test_split_fp16_is_fp32_grade(B, T, wscale, tmp_path):
+    use_config()
+    from bisinger_amd.diffnet import DiffNet
+    net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.')
+    if wscale != 1.0:     # another weight magnitude: exercises the per-layer power-of-two scales (the network's function changes; so does the oracle's)
+        with torch.no_grad():
+            for layer in net.residual_layers:
+                layer.dilated_conv.weight.mul_(wscale)
+                layer.output_projection.weight.mul_(1.0 / wscale)
+    sd = {'denoise_fn.' + k: v.detach().cpu() for k, v in net.state_dict().items()}
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.standard_normal((B, 1, 80, T)).astype(np.float32))
+    cond = torch.from_numpy(rs.standard_normal((B, 256, T)).astype(np.float32))
+    t = torch.from_numpy(rs.randint(0, 100, size=(B,)).astype(np.int64))
+    with torch.no_grad():
+        ref64 = odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.', dtype=torch.float64).numpy()
+        ref32 = odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.').double().numpy()
+    err = {'cpu_fp32': (float(np.abs(ref32 - ref64).max()), float(np.sqrt(((ref32 - ref64) ** 2).mean())))}
+    code = CHILD % (ROOT, B, T, wscale)
+    for name, (env, path) in FORMS.items():
+        f = str(tmp_path / f'{name}.npy')
+        out = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        info = json.loads(out.stdout.strip().splitlines()[-1])
+        assert info['path'] == path, (name, info)
+        assert info['timeouts'] == 0
+        e = np.load(f).astype(np.float64) - ref64
+        err[name] = (float(np.abs(e).max()), float(np.sqrt((e ** 2).mean())))
+    print(f'B={B} T={T} wscale={wscale:g}: error vs float64 (max, rms): ' + '  '.join(f'{k} {v[0]:.2e}/{v[1]:.2e}' for k, v in err.items()))
+    rms_eps = float(np.sqrt((ref64 ** 2).mean()))
+    fp32_forms = [err[k] for k in ('fp32_direct', 'fp32_wino23', 'fp32_wino43')]
+    # rounding-level in absolute terms, and no worse than the forms that multiply in fp32
+    assert err['split_fp16'][0] <= 2e-5 * max(1.0, rms_eps)
+    assert err['split_fp16'][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9
+    assert err['split_fp16'][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9

@@ -132,8 +132,9 @@ def test_fused_plms_tail_matches_separate_kernels(model, monkeypatch):
     assert maxabs(fused, sep) <= 2e-5
 
 
-F23 = {'BSG_WINO': '1'}
-F43 = {'BSG_WINO': '2'}
+F23 = {'BSG_WINO': '1', 'BSG_H2': '0'}
+F43 = {'BSG_WINO': '2', 'BSG_H2': '0'}
+H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
 
 
 @pytest.mark.parametrize('B,T,base,stack,path,tol', [
@@ -149,6 +150,14 @@ F43 = {'BSG_WINO': '2'}
     (3, 77, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),         # forced: a few tiles, partial tile
     (5, 333, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),
     (2, 31, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),         # T < one tile
+    # the split-fp16 stack launch (diffnet_h2.hip, the default for launch groups that are at least half full): the direct K=768 form with
+    # every fp32 operand as hi + lo fp16 terms on the 16-bit matrix pipe — a third rounding of the same sums
+    (16, 1000, F23, H2, 'stack_h2', 1e-5),
+    (32, 997, F23, H2, 'stack_h2', 1e-5),
+    (8, 1000, F23, H2, 'stack_h2', 1e-5),                                # a half-full launch group
+    (3, 77, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),
+    (5, 333, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),
 ])
 def test_stack_launch_matches_per_layer_launches(B, T, base, stack, path, tol, tmp_path):
     """The on-chip stack launches (all 20 layers in one launch, x on chip, neighbour tiles exchanging 8-frame edges every
@@ -156,7 +165,8 @@ def test_stack_launch_matches_per_layer_launches(B, T, base, stack, path, tol, t
     sampler steps + one evaluation with per-row timesteps.  F(2,3) stack (opt-in, BSG_STACK): same arithmetic except that the
     conditioner term is the GEMM1 accumulators' initial value: 1e-5.  F(4,3) stack (diffnet_f43.hip, the default at these
     sizes): Winograd F(4,3) transforms instead of F(2,3) and x recovered as image - d: measured 7e-7, bar 1e-5.  Child process per mode (the
-    switches are read once per process).  BSG_STACK=2 / BSG_STACK43=2 force the form for small / ragged shapes."""
+    switches are read once per process).  BSG_STACK=2 / BSG_STACK43=2 / BSG_H2=2 force the form for small / ragged shapes.
+    Split-fp16 stack (diffnet_h2.hip): products exact to 3 x 2^-24, fp32 accumulation in another order: bar 1e-5."""
     import json
     import os
     import subprocess
@@ -217,6 +227,9 @@ def test_sampler_loop_is_graph_capturable(model, B, T, n):
     x0 = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
     eager = model.sample(cond, x0.clone(), seed=11, n_steps=n).clone()      # also warms up (workspaces, function attributes)
     torch.cuda.synchronize()
+    # a stack launch (flags carry a launch epoch) is never taken inside a capture: when the eager call ran one, the captured loop runs
+    # the per-layer F(2,3) kernels instead — another rounding of the same sums (1e-5); otherwise the replay is bit-identical
+    eager_is_stack = model.denoise_fn.last_path().startswith('stack')
     xg = x0.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -225,11 +238,17 @@ def test_sampler_loop_is_graph_capturable(model, B, T, n):
         with torch.cuda.graph(g, stream=side):
             model.sample(cond, xg, seed=11, n_steps=n)
     torch.cuda.current_stream().wait_stream(side)
+    first = None
     for _ in range(2):
         xg.copy_(x0)
         g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(xg, eager)
+        if eager_is_stack:
+            assert maxabs(xg, eager) <= 1e-5
+        else:
+            assert torch.equal(xg, eager)
+        first = xg.clone() if first is None else first
+        assert torch.equal(xg, first)
 
 
 def test_single_layer_graph_replays(model):

@@ -28,7 +28,8 @@ for _ in range(3):
     net(x, t, cond)          # binds, fills xa, warms up
 torch.cuda.synchronize()
 F43 = net.last_path() == 'stack_f43'
-NTILE = 64 if DT == 'bf16' or F43 else 32
+H2 = net.last_path() == 'stack_h2'   # split-fp16 form: same stamp slots as the bf16 stack launch
+NTILE = 64 if DT == 'bf16' or F43 or H2 else 32
 tiles, L = B * ((T + NTILE - 1) // NTILE), 20
 st = torch.zeros(tiles * L * 8, dtype=torch.int64, device=dev)
 for rep in range(3):
@@ -39,7 +40,7 @@ s = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64) / 100.0      # us
 names = ['GEMM1 (A->1)', 'gate+z+barrier (1->2)', 'GEMM2 residual (2->3)' if DT != 'bf16' else 'GEMM2 (2->3)',
          'publish+GEMM2 skip (3->4)' if DT != 'bf16' else 'core image + barrier C1 (3->4)', 'drain+barrier C (4->5)',
          'flag wait (5->6)', 'acquire+barrier D (6->7)', 'halo load+barrier A (7->0 next)']
-if DT == 'bf16':   # stamps in time order: 0 start, 1 flags seen, 2 halo rows in place, 3 GEMM1 done, 4 gate done, 5 GEMM2 done, 6 image, 7 flag stored
+if DT == 'bf16' or H2:   # stamps in time order: 0 start, 1 flags seen, 2 halo rows in place, 3 GEMM1 done, 4 gate done, 5 GEMM2 done, 6 image, 7 flag stored
     names = ['centre tap + flag wait (0->1)', 'halo copy (1->2)', 'outer taps (2->3)', 'gate+z+barrier (3->4)', 'GEMM2 + x/skip update (4->5)',
              'cond request + image + barrier C1 (5->6)', 'publish + drain + barrier C (6->7)', 'loop top (7->0 next)']
 if F43:   # 0 start, 1 GEMM1 done (wave 0), 2 barrier B passed, 3 residual rows done, 4 image + publish + flag, 5 skip rows stored, 6 flags seen, 7 halo copied
@@ -53,7 +54,7 @@ if F43:
 inner = s[:, 1:L - 1]                                                          # layers with all 8 stamps and a successor
 d = [inner[:, :, i + 1] - inner[:, :, i] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
 period = s[:, 2:L, 0] - s[:, 1:L - 1, 0]
-print(f'B={B} T={T}: {tiles} tiles; layer period {period.mean():.1f} us (min {period.min():.1f}, max {period.max():.1f}); '
+print(f'path {net.last_path()}  B={B} T={T}: {tiles} tiles; layer period {period.mean():.1f} us (min {period.min():.1f}, max {period.max():.1f}); '
       f'kernel span {(s[:, L - 1, 4].max() - s[:, 0, 0].min()):.0f} us')
 for n, v in zip(names, d):
     print(f'  {n:34s} mean {v.mean():7.2f} us   p10 {np.percentile(v, 10):7.2f}   p90 {np.percentile(v, 90):7.2f}')
