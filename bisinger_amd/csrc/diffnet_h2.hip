@@ -22,6 +22,7 @@
 // tile and layer) under the centre tap of GEMM1; the conditioner term (fp32, 2 KB per frame and layer: the only HBM stream) is
 // requested into the free accumulators a phase ahead.  LDS: 2 x 42,240 (image) + 2 x 33,792 (z) + 3 KB of tables = 155,136 B.
 #include "diffnet_res.h"
+#include "diffnet_tail.h"
 
 namespace bsg {
 
@@ -58,6 +59,15 @@ __global__ void h2_scale_kernel(const unsigned* __restrict__ maxbits, float* __r
   const float tot = (i & 1) ? s * ZSCALE : s;
   tab[2 * i] = tot;
   tab[2 * i + 1] = 1.0f / tot;   // a power of two: exact
+}
+
+__global__ void h2_tail_scale_kernel(const unsigned* __restrict__ maxbits, float* __restrict__ tab) {
+  const int i = threadIdx.x;
+  if (i >= 3) return;
+  const float mx = __uint_as_float(maxbits[i]);
+  const float s = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, 13 - ilogbf(mx)) : 1.0f;
+  tab[2 * i] = s;
+  tab[2 * i + 1] = 1.0f / s;
 }
 
 // out[(((ks*2 + plane)*(M/32) + rt)*64 + lane)*8 + j] = plane ? lo : hi of  s x W(m = 32 rt + (lane & 31), k = 16 ks + 8 (lane >> 5) + j)
@@ -154,8 +164,43 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c
   }
 }
 
-template <bool FAIRB>
-__global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p) {
+// Small split-fp16 GEMM of the fused step tail: one row tile of 32 x NC column tiles of 32, N_KS k-steps of 16, fully unrolled; A fragments
+// (hi at sa + ks*ksb, lo at + plb) in a ring of up to 8 k-steps, B fragments from `ldb(ks, Bf)`: Bf[2 nc] = hi, Bf[2 nc + 1] = lo of column
+// tile nc.
+template <int NC, int N_KS, typename LDB>
+__device__ __forceinline__ void tail_gemm_h2(f32x16 (&c)[NC], rsrc_t rs, int vfrag, int sa, int ksb, int plb, LDB ldb) {
+  constexpr int R = N_KS < 8 ? N_KS : 8;
+  f16x8 Ar[R][2];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    Ar[k][0] = lda8(rs, vfrag, sa + k * ksb);
+    Ar[k][1] = lda8(rs, vfrag, sa + k * ksb + plb);
+  }
+  f16x8 Bf[2][2 * NC];
+  ldb(0, Bf[0]);
+#pragma unroll
+  for (int ks = 0; ks < N_KS; ++ks) {
+    if (ks + 1 < N_KS) ldb(ks + 1, Bf[(ks + 1) & 1]);
+    const f16x8(&Bc)[2 * NC] = Bf[ks & 1];
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], Ar[ks % R][0], Bc[2 * nc]);
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], Ar[ks % R][0], Bc[2 * nc + 1]);
+#pragma unroll
+    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], Ar[ks % R][1], Bc[2 * nc]);
+    if (ks + R < N_KS) {
+      Ar[ks % R][0] = lda8(rs, vfrag, sa + (ks + R) * ksb);
+      Ar[ks % R][1] = lda8(rs, vfrag, sa + (ks + R) * ksb + plb);
+    }
+  }
+}
+
+// TAIL: the tail of the sampler step runs on the tile while it is still on chip (the fp32 launch pair it replaces: this kernel without
+// TAIL + step_tail_kernel, diffnet.hip; net.py:126-129, shallow_diffusion_tts.py:149-201): skip projection + ReLU, output projection,
+// sampler update of x (DDPM ancestral or PLMS), and the next evaluation's input projection — the same split-fp16 products, biases
+// and sampler arithmetic (diffnet_tail.h) — so that a step is ONE launch and neither the skip sum nor the hidden tile touch HBM.
+template <bool FAIRB, bool TAIL>
+__global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* xs = lds_raw;                  // [2 planes][80 frames][528 B]: hi / lo of x + d_l, frames t0-8 .. t0+71
   char* zs = lds_raw + 2 * XP;         // [2 planes][64 frames][528 B]: hi / lo of 2^10 x gated activation
@@ -433,8 +478,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p) 
     STK_STAMP(7);
   }
 #undef STK_STAMP
-  // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
-  {
+  if constexpr (!TAIL) {
+    // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
     const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
     const float div = sqrtf((float)L);
 #pragma unroll
@@ -443,6 +488,145 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) stf(sk[ct][r] / div, rs_sk, vst[ct], (32 * wave + acc_row0(r)) * rowT);
       }
+  } else {
+    // ================= fused step tail =================================================================================================
+    const int M = a.M;
+    const float* tsc = a.tail_scale;   // [3][2]: scale, 1 / scale of the skip / output / input projection
+    // ---- s = skip sum / sqrt(L) -> hi / lo image rows (the conv image is dead: every wave is behind barrier (B) of the last layer) ----
+    {
+      const float div = sqrtf((float)L);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const HiLo s0 = split2(sk[ct][4 * g] / div, sk[ct][4 * g + 1] / div), s1_ = split2(sk[ct][4 * g + 2] / div, sk[ct][4 * g + 3] / div);
+          char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
+          *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+          *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
+        }
+    }
+    const char* xcore = xs + (HALO + l31) * ROWB + lh * 16;
+    auto ldb_x2 = [&](int ks, f16x8 (&Bf)[4]) {   // both column tiles of the image rows
+      const char* q = xcore + ks * 32;
+      Bf[0] = *reinterpret_cast<const f16x8*>(q);
+      Bf[1] = *reinterpret_cast<const f16x8*>(q + XP);
+      Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
+      Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + XP);
+    };
+    // ---- h = relu(W_skip s + b) -> zs (hi / lo) -----------------------------------------------------------------------------------
+    {
+      const rsrc_t rs_ws = mk_rsrc(a.ws_s, 2 * C * C * 2);
+      const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
+      const float sc = tsc[0], inv = tsc[1];
+      f32x16 hc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hc[0][r] = hc[1][r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
+      __syncthreads();   // (T1) s complete; every wave is done with GEMM2 of the last layer (zs is free)
+      tail_gemm_h2<2, 16>(hc, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const HiLo s0 = split2(fmaxf(hc[ct][4 * g] * inv, 0.f), fmaxf(hc[ct][4 * g + 1] * inv, 0.f));
+          const HiLo s1_ = split2(fmaxf(hc[ct][4 * g + 2] * inv, 0.f), fmaxf(hc[ct][4 * g + 3] * inv, 0.f));
+          char* dst = zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
+          *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+          *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
+        }
+    }
+    __syncthreads();   // (T2) h complete; every wave is done reading s
+    // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins x 2 column tiles: waves 0..5 ----
+    if (wave < 6) {
+      const int rt = wave % 3, ct2 = wave / 3;
+      const int col = t0 + 32 * ct2 + l31;
+      const bool cok = col < T;
+      const int vc = (lh * 4 * T + (cok ? col : T - 1)) * 4, vs = (lh * 4 * T + col) * 4;
+      const rsrc_t rs_wo = mk_rsrc(a.wo_s, 2 * 96 * C * 2);
+      const rsrc_t rs_bf = mk_rsrc(a.b_fin, 96 * 4);
+      const rsrc_t rs_xx = mk_rsrc(a.x + (long long)b * M * T, (unsigned)M * T * 4);
+      const rsrc_t rs_n = mk_rsrc(a.noise ? a.noise + (long long)b * M * T : a.x, a.noise ? (unsigned)M * T * 4 : 0u);
+      const float sc = tsc[2], inv = tsc[3];
+      f32x16 e[1];
+      float xv[16], nv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // the lane's row is m0 + 4 lh; rows >= M fall outside the descriptor's range and read as 0, and are never stored
+        const int m0 = 32 * rt + acc_row0(r);
+        e[0][r] = ldf(rs_bf, lh * 16, m0 * 4) * sc;
+        xv[r] = ldf(rs_xx, vc, m0 * rowT);
+        nv[r] = a.noise ? ldf(rs_n, vc, m0 * rowT) : 0.f;
+      }
+      float h1v[16], h2v[16], h3v[16];
+      if (a.plms_hist) {
+        const unsigned hb = (unsigned)M * T * 4;
+        const rsrc_t rs_h1 = mk_rsrc(a.h1 + (long long)b * M * T, hb);
+        const rsrc_t rs_h2 = mk_rsrc(a.plms_hist > 1 ? a.h2 + (long long)b * M * T : a.x, a.plms_hist > 1 ? hb : 0u);
+        const rsrc_t rs_h3 = mk_rsrc(a.plms_hist > 2 ? a.h3 + (long long)b * M * T : a.x, a.plms_hist > 2 ? hb : 0u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int so = (32 * rt + acc_row0(r)) * rowT;
+          h1v[r] = ldf(rs_h1, vc, so);
+          h2v[r] = ldf(rs_h2, vc, so);   // zero-size descriptors read as 0
+          h3v[r] = ldf(rs_h3, vc, so);
+        }
+      }
+      const char* zb = zs + (32 * ct2 + l31) * ROWB + lh * 16;
+      auto ldb_h = [&](int ks, f16x8 (&Bf)[2]) {
+        Bf[0] = *reinterpret_cast<const f16x8*>(zb + ks * 32);
+        Bf[1] = *reinterpret_cast<const f16x8*>(zb + ks * 32 + ZP);
+      };
+      tail_gemm_h2<1, 16>(e, rs_wo, vfrag, rt * 1024, 2 * 3 * 1024, 3 * 1024, ldb_h);
+      const rsrc_t rs_en = mk_rsrc(a.plms_hist ? a.e_new + (long long)b * M * T : a.x, a.plms_hist ? (unsigned)M * T * 4 : 0u);
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * rt + acc_row(r, lh);
+        const float ev = e[0][r] * inv;
+        o[r] = 0.f;
+        if (m < M) {
+          if (a.plms_hist) {
+            o[r] = plms_update(xv[r], ev, h1v[r], h2v[r], h3v[r], a.plms_hist, a.pk, nullptr);
+            if (cok) stf(ev, rs_en, vs, (32 * rt + acc_row0(r)) * rowT);
+          } else {
+            float nz = nv[r];
+            if (!a.noise && a.k.sigma != 0.f)
+              nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + (cok ? col : T - 1));
+            float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, ev));
+            x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
+            o[r] = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
+          }
+          if (cok) stf(o[r], rs_xx, vs, (32 * rt + acc_row0(r)) * rowT);
+        }
+      }
+      // the updated x as the input projection's B operand: channels-last rows of the image region (channels 0..95; rows >= M zero)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const HiLo s0 = split2(o[4 * g], o[4 * g + 1]), s1_ = split2(o[4 * g + 2], o[4 * g + 3]);
+        char* dst = xs + (HALO + 32 * ct2 + l31) * ROWB + (32 * rt + 8 * g + 4 * lh) * 2;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+        *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
+      }
+    }
+    if (!a.do_head) return;
+    // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded) ------------------------------------
+    {
+      const rsrc_t rs_wi = mk_rsrc(a.wi_s, 2 * C * 96 * 2);
+      const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
+      const float sc = tsc[4], inv = tsc[5];
+      f32x16 hc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hc[0][r] = hc[1][r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
+      __syncthreads();   // (T3) the updated x tile is complete
+      tail_gemm_h2<2, 6>(hc, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
+      const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, plane);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        if (col_ok[ct]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) stf(fmaxf(hc[ct][r] * inv, 0.f), rs_xa, vst[ct], (32 * wave + acc_row0(r)) * rowT);
+        }
+    }
   }
 }
 #undef BSG_MFMA_H
@@ -451,18 +635,47 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p) 
 
 int stack_h2_occupancy() {
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_h2_kernel<true>, 512, H2_LDS) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_h2_kernel<true, true>, 512, H2_LDS) != hipSuccess)
     return 0;
   return o;
 }
 
-int launch_residual_stack_h2(const StackArgs& p, hipStream_t st) {
+// tail == nullptr: the residual stack only (skip sum to p.skip); else the sampler step's tail runs in the same launch (TailArgs of THIS
+// launch's rows: x, noise, xa_next, history pointers and quad_row0 already offset to its first row)
+int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
   static int fair = -1;
   if (fair < 0) { const char* e = getenv("BSG_H2_FAIR"); fair = e ? atoi(e) : 1; }
-  if (fair) hipLaunchKernelGGL(residual_stack_h2_kernel<true>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), H2_LDS, st, p);
-  else hipLaunchKernelGGL(residual_stack_h2_kernel<false>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), H2_LDS, st, p);
+  const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
+  const TailArgs a = tail ? *tail : TailArgs{};
+  if (tail) {
+    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, true>), grid, block, H2_LDS, st, p, a);
+    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, true>), grid, block, H2_LDS, st, p, a);
+  } else {
+    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, false>), grid, block, H2_LDS, st, p, a);
+    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, false>), grid, block, H2_LDS, st, p, a);
+  }
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// the three projections of the step tail as split-fp16 fragments + their scale table [3][2]; maxbits: [3] scratch
+int h2_tail_pack(const float* ws, const float* wo96, const float* wi96, unsigned short* out_ws, unsigned short* out_wo, unsigned short* out_wi,
+                 unsigned* maxbits, float* tab, hipStream_t st) {
+  BSG_HIP(hipMemsetAsync(maxbits, 0, 3 * sizeof(unsigned), st));
+  hipLaunchKernelGGL(h2_absmax_kernel, dim3(64), dim3(256), 0, st, ws, (long long)C * C, maxbits);
+  hipLaunchKernelGGL(h2_absmax_kernel, dim3(64), dim3(256), 0, st, wo96, (long long)96 * C, maxbits + 1);
+  hipLaunchKernelGGL(h2_absmax_kernel, dim3(64), dim3(256), 0, st, wi96, (long long)C * 96, maxbits + 2);
+  hipLaunchKernelGGL(h2_tail_scale_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)maxbits, tab);
+  hipLaunchKernelGGL(pack_a_frag_h2_kernel, dim3(cdiv((long long)C * C, 256)), dim3(256), 0, st, ws, reinterpret_cast<_Float16*>(out_ws), C, C, C,
+                     (long long)C, 1LL, 0LL, (const float*)tab, 0);
+  hipLaunchKernelGGL(pack_a_frag_h2_kernel, dim3(cdiv((long long)96 * C, 256)), dim3(256), 0, st, wo96, reinterpret_cast<_Float16*>(out_wo), 96, C, C,
+                     (long long)C, 1LL, 0LL, (const float*)(tab + 2), 0);
+  hipLaunchKernelGGL(pack_a_frag_h2_kernel, dim3(cdiv((long long)C * 96, 256)), dim3(256), 0, st, wi96, reinterpret_cast<_Float16*>(out_wi), C, 96, 96,
+                     96LL, 1LL, 0LL, (const float*)(tab + 4), 0);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

@@ -80,6 +80,11 @@ struct TailArgs {
   const unsigned short* ws_h;  // skip projection   [16 k-steps][8 row tiles][64][8]
   const unsigned short* wo_h;  // output projection [16][3][64][8]   (rows >= M zero)
   const unsigned short* wi_h;  // input projection  [6][8][64][8]    (K = in_dims padded to 96 with zero columns)
+  // split-fp16 tail (fused into residual_stack_h2_kernel, diffnet_h2.hip): hi / lo fp16 fragments [ks][plane][row tiles][64][8]
+  const unsigned short* ws_s;  // skip projection   [16][2][8][64][8]
+  const unsigned short* wo_s;  // output projection [16][2][3][64][8]   (rows >= M zero)
+  const unsigned short* wi_s;  // input projection  [6][2][8][64][8]    (K padded to 96)
+  const float* tail_scale;     // [3][2]: power-of-two scale and its reciprocal of the three projections
   StepCoef k;
   unsigned long long seed, quad_row0;   // Philox: key, and the flat element index of this shard's row 0
   unsigned stream;
@@ -99,6 +104,11 @@ __device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigne
   return s == 0 ? z[0] : s == 1 ? z[1] : s == 2 ? z[2] : z[3];
 }
 
+
+// split-fp16 stack launch (diffnet_h2.hip), optionally with the step tail in the same launch
+int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st);
+int h2_tail_pack(const float* ws, const float* wo96, const float* wi96, unsigned short* out_ws, unsigned short* out_wo, unsigned short* out_wi,
+                 unsigned* maxbits, float* tab, hipStream_t st);
 
 // bf16-operand form of the fused step tail (diffnet_bf16.hip): 64-frame tiles, skip sum read as bf16 channel quads (a.skip_h)
 int launch_step_tail_bf16(const TailArgs& a, hipStream_t st);

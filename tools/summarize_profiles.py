@@ -73,7 +73,8 @@ for cfg in ('f32', 'bf16', 'voc'):
     # Figures are normalised to ONE LAYER OVER THE WHOLE BATCH for the stack forms (launch bytes x launch groups / 20), which is the unit
     # bench.py's roofline uses for them; for per-layer launches they are per launch.
     batch_frames = 64000 if cfg == 'bf16' else 16000
-    cands = {'f32': [('residual_stack_f43_kernel<1>', 'stack_f43'), ('residual_stack_f43_kernel<0>', 'stack_f43'),
+    cands = {'f32': [('residual_stack_h2_kernel<true>', 'stack_h2'), ('residual_stack_h2_kernel<false>', 'stack_h2'),
+                     ('residual_stack_f43_kernel<1>', 'stack_f43'), ('residual_stack_f43_kernel<0>', 'stack_f43'),
                      ('residual_layer_kernel<false, true>', 'layer')],
              'bf16': [('residual_stack_bf16_kernel<true>', 'stack_bf16'), ('residual_stack_bf16_kernel<false>', 'stack_bf16'),
                       ('residual_layer_bf16_kernel<false>', 'bf16')]}.get(cfg, [])
@@ -87,7 +88,10 @@ for cfg in ('f32', 'bf16', 'voc'):
             frames, by = batch_frames, by * groups / 20   # one layer over the batch
             # what the on-chip form must move per frame and layer: conditioner term (fp32 2 KB / bf16 1 KB) + running skip sum r+w
             # (fp32 2 KB; bf16 form: in registers) + x in / skip out once per 20 layers + edges through L2
-            alg_form = (2048 + 2048 + 1024 / 20) * frames if cfg == 'f32' else (1024 + 2048 / 20 + 2 * 8192 / 64) * frames
+            if path == 'stack_h2':      # conditioner term fp32 2 KB + x in / skip out once per 20 layers + two fp16 planes of the edges through L2
+                alg_form = (2048 + 2048 / 20 + 2 * 16384 / 64) * frames
+            else:
+                alg_form = (2048 + 2048 + 1024 / 20) * frames if cfg == 'f32' else (1024 + 2048 / 20 + 2 * 8192 / 64) * frames
         else:
             frames = batch_frames * 2000 // max(n, 1)     # one pass = 100 steps x 20 layers; more launches = half-batch chains
             alg_form = (4 if cfg == 'bf16' else 6) * 256 * 4 * frames
