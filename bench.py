@@ -219,7 +219,7 @@ def traffic_from_profiles(bf16, frames_per_launch, path=None):
     if not os.path.exists(tpath):
         return None
     tj = json.load(open(tpath))
-    if tj.get('path', 'bf16' if bf16 else 'layer') != (path or ('bf16' if bf16 else 'layer')):
+    if tj.get('path', 'bf16' if bf16 else 'layer') != (path or ('bf16' if bf16 else 'layer')).replace('_tail', ''):
         return None
     if abs(tj.get('frames_per_launch', 16000) - frames_per_launch) < 1:
         return tj.get('residual_layer_kernel_hbm_bytes_per_launch')
@@ -268,7 +268,7 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
                     traffic_over_algorithmic=traffic / (HBM_BYTES_PER_FRAME_LAYER_BF16 * frames_per_launch) if traffic else None,
                     mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / PEAK_BF16_MFMA_TFLOPS,
                     note='achieved = algorithmic bytes of one launch / its average duration (HIP events on its own stream) x launches in flight')
-    if path == 'stack_h2':
+    if (path or '').startswith('stack_h2'):
         # split-fp16 stack launch (diffnet_h2.hip): every fp32 product as 3 fp16 MFMA products (hi hi, hi lo, lo hi), fp32 accumulate, so
         # the matrix pipe in use is the 16-bit one.  One launch = all 20 layers of up to 256 64-frame tiles; avg_ms = one layer over all rows
         executed = 3.0 * achieved

@@ -1284,6 +1284,8 @@ struct bsg_diffnet {
   unsigned short* apack1s = nullptr;  // [L][2 planes][2C*3C] hi / lo fp16 fragments (split-fp16 form of the fp32 stack launch, diffnet_h2.hip)
   unsigned short* apack2s = nullptr;  // [L][2 planes][2C*C]
   float* h2_scale = nullptr;          // [L][4] power-of-two scales of the split-fp16 form
+  unsigned short* tail_s = nullptr;   // split-fp16 step tail (fused into the h2 stack launch): skip [2*C*C], output [2*96*C], input projection [2*C*96]
+  float* tail_scale = nullptr;        // [3][2] scales of the three projections (+ 3 words of scratch)
   unsigned short* tail_h = nullptr;   // bf16 step tail (step_tail_bf16_kernel): skip projection [C*C], output projection [96*C], input projection [C*96]
   int compute = BSG_COMPUTE_F32;      // bsg_diffnet_set_compute
   unsigned short* condterm_h = nullptr;  // [L][B][2C/4][T][4] bf16 (bf16 mode only)
@@ -1383,6 +1385,8 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->apack1s) (void)hipFree(h->apack1s);
   if (h->apack2s) (void)hipFree(h->apack2s);
   if (h->h2_scale) (void)hipFree(h->h2_scale);
+  if (h->tail_s) (void)hipFree(h->tail_s);
+  if (h->tail_scale) (void)hipFree(h->tail_scale);
   delete h;
 }
 
@@ -1517,6 +1521,15 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
       if (rc == BSG_OK) rc = pack_a_frag_bf16(wo_pad, h->tail_h + C * C, 96, C, C, (long long)C, 1LL, 0LL, st);
       if (rc == BSG_OK) rc = pack_a_frag_bf16(wi_pad96, h->tail_h + C * C + 96 * C, C, 96, 96, 96LL, 1LL, 0LL, st);
     }
+    // and as split-fp16 fragments (hi / lo planes) for the tail fused into the split-fp16 stack launch
+    if (rc == BSG_OK && (hipMalloc((void**)&h->tail_s, (size_t)2 * (C * C + 96 * C + C * 96) * sizeof(unsigned short)) != hipSuccess ||
+                         hipMalloc((void**)&h->tail_scale, 9 * sizeof(float)) != hipSuccess)) {
+      set_error("diffnet_create: out of device memory");
+      rc = BSG_EHIP;
+    }
+    if (rc == BSG_OK)
+      rc = h2_tail_pack((const float*)tw[0], wo_pad, wi_pad96, h->tail_s, h->tail_s + 2 * C * C, h->tail_s + 2 * C * C + 2 * 96 * C,
+                        reinterpret_cast<unsigned*>(h->tail_scale + 6), h->tail_scale, st);
   }
   hipError_t e = hipStreamSynchronize(st);
   dev_free(hid);
@@ -1858,7 +1871,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
 }
 
 static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
-                        unsigned long long* stamps = nullptr) {
+                        unsigned long long* stamps = nullptr, const TailArgs* tail = nullptr) {
   const bool f43 = h->stack_is_f43, h2 = h->stack_is_h2;   // the decision of the stack_rows() call that returned rows_per_launch
   const int tpr = cdiv(T, f43 || h2 ? 64 : 32);
   const size_t bt = (size_t)h->B * T;   // bound batch: per-layer stride of the conditioner term
@@ -1882,7 +1895,19 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
-      TRY(launch_residual_stack_h2(p, st));
+      if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
+        TailArgs a = *tail;
+        const size_t mo = (size_t)r0 * h->M * T;
+        a.x += mo; a.xa_next += (size_t)r0 * C * T; a.quad_row0 += mo;
+        if (a.noise) a.noise += mo;
+        if (a.e_new) a.e_new += mo;
+        if (a.h1) a.h1 += mo;
+        if (a.h2) a.h2 += mo;
+        if (a.h3) a.h3 += mo;
+        TRY(launch_residual_stack_h2(p, &a, st));
+      } else {
+        TRY(launch_residual_stack_h2(p, nullptr, st));
+      }
     } else if (f43) {
       p.apackw43 = h->apackw43;
       TRY(launch_residual_stack_f43(p, st));
@@ -1891,7 +1916,8 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       BSG_LAUNCH_CHECK();
     }
   }
-  h->last_path = h2 ? "stack_h2" : f43 ? "stack_f43" : "stack";
+  BSG_REQUIRE(!tail || h2, "stack launch: a fused tail needs the split-fp16 form");
+  h->last_path = h2 ? (tail ? "stack_h2_tail" : "stack_h2") : f43 ? "stack_f43" : "stack";
   return BSG_OK;
 }
 
@@ -2079,6 +2105,32 @@ static int launch_tail(bsg_diffnet* h, TailArgs& a, float* x, int B, int T, hipS
   return BSG_OK;
 }
 
+// One sampler step from the in-projected x in h->xa: the residual stack, then the tail (`a` carries the sampler-specific fields).  When
+// the stack runs as the split-fp16 launch, the tail runs inside it (one launch per step; BSG_H2_TAIL=0: two launches).
+static int step_from_xa(bsg_diffnet* h, int t_uniform, TailArgs& a, float* x, int B, int T, hipStream_t st) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("BSG_H2_TAIL"); env = e ? atoi(e) : 1; }
+  const int srows = (h->no_split || h->compute != BSG_COMPUTE_F32 || !env || !h->tail_s || h->M > 96) ? 0 : stack_rows(h, B, T, st);
+  if (srows && h->stack_is_h2) {
+    const size_t off = (size_t)h->row_off * C * T;
+    a.x = x; a.xa_next = h->xa + off;
+    a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
+    a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 64);
+    a.ws_s = h->tail_s; a.wo_s = h->tail_s + 2 * C * C; a.wi_s = h->tail_s + 2 * C * C + 2 * 96 * C; a.tail_scale = h->tail_scale;
+    const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
+    if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
+    TRY(launch_stack(h, nullptr, t_uniform, B, T, srows, st, nullptr, &a));
+    if (prof) {
+      BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
+      h->prof_used += 2;
+      h->prof_launches += h->L;   // layer-equivalents; the launch also carries the step tail (~1 % of its FLOPs)
+    }
+    return BSG_OK;
+  }
+  TRY(layers_from_xa(h, t_uniform, B, T, st));
+  return launch_tail(h, a, x, B, T, st);
+}
+
 struct SubBatch { int off, B; hipStream_t st; };
 
 // Two half-batches on two streams.  One launch per layer puts all workgroups of the chip in the same phase (they stage, hit
@@ -2187,15 +2239,13 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
     const int i = t_start - k;
     for (int u = 0; u < n_sub && rc == BSG_OK; ++u) {
       h->row_off = subs[u].off;
-      rc = layers_from_xa(h, i, subs[u].B, T, subs[u].st);
-      if (rc != BSG_OK) break;
       TailArgs a{};
       a.noise = noise ? noise + (long long)k * n + (long long)subs[u].off * h->M * T : nullptr;
       a.k = StepCoef{s->sqrt_recip_alphas_cumprod[i], s->sqrt_recipm1_alphas_cumprod[i], s->posterior_mean_coef1[i],
                      s->posterior_mean_coef2[i], s->sigma[i]};
       a.seed = seed; a.quad_row0 = (unsigned long long)(row0 + subs[u].off) * h->M * T; a.stream = (unsigned)(i + 1);
       a.do_head = k + 1 < n_steps;
-      rc = launch_tail(h, a, x + (size_t)subs[u].off * h->M * T, subs[u].B, T, subs[u].st);
+      rc = step_from_xa(h, i, a, x + (size_t)subs[u].off * h->M * T, subs[u].B, T, subs[u].st);
     }
   }
   rc = dual_join(h, n_sub, st, rc);
@@ -2391,15 +2441,13 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
       for (int u = 0; u < n_sub && rc == BSG_OK; ++u) {
         const size_t mo = (size_t)subs[u].off * h->M * T;
         h->row_off = subs[u].off;
-        rc = layers_from_xa(h, i, subs[u].B, T, subs[u].st);
-        if (rc != BSG_OK) break;
         TailArgs a{};
         a.plms_hist = n_hist; a.pk = c; a.e_new = e_new + mo; a.h1 = hist[0] + mo; a.h2 = hist[1] + mo; a.h3 = hist[2] + mo;
         if (n_hist == 1) { a.pk.w0 = 3.f; a.pk.inv = 2.f; }
         else if (n_hist == 2) { a.pk.w0 = 23.f; a.pk.w1 = -16.f; a.pk.w2 = 5.f; a.pk.inv = 12.f; }
         else { a.pk.w0 = 55.f; a.pk.w1 = -59.f; a.pk.w2 = 37.f; a.pk.w3 = -9.f; a.pk.inv = 24.f; }
         a.do_head = i - interval >= 0;
-        rc = launch_tail(h, a, x + mo, subs[u].B, T, subs[u].st);
+        rc = step_from_xa(h, i, a, x + mo, subs[u].B, T, subs[u].st);
       }
       if (rc != BSG_OK) break;
       hist[3] = hist[2]; hist[2] = hist[1]; hist[1] = hist[0]; hist[0] = e_new;

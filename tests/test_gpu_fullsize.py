@@ -123,7 +123,7 @@ def test_full_size_shard_invariance_and_seed(model):
         assert maxabs(full, run(seed=6)) > 1e-2
         for r0, r1 in ((0, 8), (8, 16), (5, 7)):
             part = run(seed=5, rows=slice(r0, r1))
-            if full_path in ('stack_f43', 'stack_h2') and model.denoise_fn.last_path() != full_path:
+            if full_path.startswith(('stack_f43', 'stack_h2')) and model.denoise_fn.last_path() != full_path:
                 assert maxabs(part, full[r0:r1]) <= 1e-5, f'rows [{r0},{r1}) differ from the unsharded run'
             else:
                 assert torch.equal(part, full[r0:r1]), f'rows [{r0},{r1}) differ from the unsharded run'

@@ -95,7 +95,7 @@ def test_injected_giveup_self_heals_f43_stack_launch():
     x0 = noise[0][:, None].contiguous()
     good = _model()
     want = good.sample(cond, x0.clone(), noise=noise[1:], n_steps=3).clone()
-    assert good.denoise_fn.last_path() in ('stack_h2', 'stack_f43') and good.denoise_fn.uses_handoffs(B, T)
+    assert good.denoise_fn.last_path().startswith(('stack_h2', 'stack_f43')) and good.denoise_fn.uses_handoffs(B, T)
     assert good.denoise_fn.handoff_timeouts() == 0
     m = _model()
     net = m.denoise_fn
