@@ -1807,7 +1807,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
   h->stack_is_h2 = false;
   {
     // split-fp16 form (diffnet_h2.hip): fp32 operands as hi + lo fp16 terms on the 16-bit matrix pipe; 64-frame tiles, one workgroup per
-    // CU, whole rows per launch group.  BSG_H2=0: off; 2: for any shape that is resident (tests); default 1: launch groups >= 50 % full
+    // CU, whole rows per launch group.  BSG_H2=0: off; 2: for any shape that is resident (tests); default 1: launch groups >= 30 % full
     static int envh2 = -1;
     if (envh2 < 0) { const char* e = getenv("BSG_H2"); envh2 = e ? atoi(e) : 1; }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1819,7 +1819,9 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
         int rows = h->num_cus / tpr;
         if (rows > B) rows = B;
         const int groups = cdiv(B, rows);
-        if (envh2 == 2 || (long long)B * tpr * 2 >= (long long)groups * h->num_cus) {
+        // measured per 100-step pass at T = 1000 (tools/bench_small.py, BSG_H2=2 against 0): B=4 88 vs 84 ms, B=6 92 vs 120, B=8 96 vs 133,
+        // B=12 105 vs 200, B=16 120 vs 203 on one box: taken when the launch groups fill >= 30 % of the CUs (B >= 5 at T = 1000)
+        if (envh2 == 2 || (long long)B * tpr * 10 >= (long long)groups * h->num_cus * 3) {
           h->stack_is_h2 = true;
           return rows;
         }
@@ -1893,6 +1895,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.fbase = h->stack_epoch * 64u;
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
+    if (stamps) { const char* e = getenv("BSG_H2_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row

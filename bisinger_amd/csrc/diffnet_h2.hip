@@ -119,7 +119,7 @@ __device__ __forceinline__ int kmap(int i) {
 // FAIRB: the two waves of a SIMD take turns at issue priority (see f43_gemm1, diffnet_f43.hip).
 template <int ROT, bool FAIRB, typename LDB, typename MID>
 __device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
-                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
+                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half, int kmul = 1) {
   f16x8 B[2][4];
   ldb(kmap<ROT>(0), B[0]);
   const int last = n_ks - 1;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c
       BSG_MFMA_H(c11, A[s][3], Bc[2]);
       __builtin_amdgcn_sched_barrier(0);
       const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
-      const int kr = kmap<ROT>(ir);
+      const int kr = kmap<ROT>(ir) * kmul;   // kmul = 0: timing experiment (p.dbg)
       A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
       A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
       A[s][2] = lda8(rs, vfrag, sa1 + kr * KSB2);
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   do {                                                                                                            \
     if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+  const unsigned long long clk0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;   // shader clock, to price the phases in cycles
 #pragma unroll 1
   for (int l = 0; l < L; ++l) {
     const int dil = 1 << (l % p.cycle);
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         __syncthreads();   // (A) halo rows in place
         STK_STAMP(2);
       };
-      mfma_pipe_h2<16, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
+      mfma_pipe_h2<16, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2, p.dbg & 1 ? 0 : 1);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
         Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + ZP);
       };
-      mfma_pipe_h2<0, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
+      mfma_pipe_h2<0, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2, p.dbg & 1 ? 0 : 1);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (l + 1 < L) prefetch_a1(l + 1);
@@ -448,7 +449,13 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       sk[1][r] += yf1[r] * inv2;
     }
     STK_STAMP(5);
-    if (l + 1 == L) break;
+    if (l + 1 == L) {
+      if (p.stamps && tid == 0) {   // slots 6, 7 of the last layer: shader cycles from the first layer's start to here
+        p.stamps[((long long)tile_id * L + l) * 8 + 6] = clk0;
+        p.stamps[((long long)tile_id * L + l) * 8 + 7] = __builtin_amdgcn_s_memtime();
+      }
+      break;
+    }
 
     // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
     // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------

@@ -367,6 +367,201 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_split_kernel: the same problems on the 16-bit matrix pipe, fp32-grade.  Both operands are split EXACTLY into hi + lo fp16 terms
+// while they are staged (a = ah + al to 2^-24 |a|; see diffnet_h2.hip for the argument), and every fp32 product is formed as
+// ah bh + ah bl + al bh by three v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3/16 of the matrix cycles of the fp32 MFMA form.
+// Operands are scaled by 2^4 on the way in (products by 2^8, removed from the accumulator: exact) so that the lo terms of values down
+// to 2^-6 are normal fp16 numbers; below that they carry an absolute error <= 2^-29.  |operand| must stay below 4094.
+// Tile BM x 128 x 16 per 256-thread workgroup, double-buffered LDS: per stage and operand two planes of [rows][16 fp16 + 8 pad] (48-byte
+// rows: the 16 rows of a ds_read_b128 lane group fall on 16 different bank quads); an MFMA fragment = 8 consecutive k = one 16-byte
+// read.  !TRANS_B ([K][N] operand, N contiguous): a thread gathers 8 consecutive k of one column with 8 coalesced dword loads.
+// ------------------------------------------------------------------------------------------------
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr int SBK = 16, SROW = 48;        // k extent of a stage; bytes per LDS row of a plane
+constexpr float SPLIT_IN = 16.0f, SPLIT_OUT = 1.0f / 256.0f;
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x = v[e] * SPLIT_IN;
+    hi[e] = (_Float16)x;
+    lo[e] = (_Float16)(x - (float)hi[e]);
+  }
+}
+
+template <int BM, bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
+  constexpr int A_BYTES = BM * SROW, B_BYTES = FBN * SROW;       // one plane of one stage
+  constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;               // hi A, lo A, hi B, lo B
+  constexpr int NI = BM == 128 ? 2 : 1;
+  constexpr int A_LD4 = BM * SBK / 4 / 256;                      // float4 per thread and stage: 2 (BM = 128) or 1
+  extern __shared__ __attribute__((aligned(16))) char slds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = BM == 128 ? wave >> 1 : 0, wn = BM == 128 ? wave & 1 : wave;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bm = blockIdx.y * BM, bn = blockIdx.x * FBN, bz = blockIdx.z;
+  const int b2 = g.batch2 > 1 ? g.batch2 : 1;
+  const int zo = bz / b2, zi = bz - zo * b2;
+  const float* __restrict__ A = g.A + (long long)zo * g.sA + (long long)zi * g.sA2;
+  const float* __restrict__ Bp = g.B + (long long)zo * g.sB + (long long)zi * g.sB2;
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int kTiles = (g.K + SBK - 1) / SBK;
+  const int nIter = kTiles * g.taps;
+  f32x4 ra[A_LD4], rb[2];     // TRANS_B: 2 float4 (4 consecutive k of a row); else rb[0], rb[1] = 8 consecutive k of one column
+
+  auto load_tiles = [&](int it) {
+    const int tap = it / kTiles, k0 = (it - tap * kTiles) * SBK;
+    const int shift = g.tap_shift0 + tap;
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx >> 2, gk = k0 + ((idx & 3) << 2);
+      const int gr = bm + row + shift;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr >= 0 && gr < g.M && (bm + row) < g.M && gk < g.K) v = *reinterpret_cast<const f32x4*>(A + (long long)gr * g.lda + gk);
+      ra[j] = v;
+    }
+    const float* Bt = Bp + (long long)tap * g.sTapB;
+    if (TRANS_B) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int idx = tid + 256 * j;
+        const int gn = bn + (idx >> 2), gk = k0 + ((idx & 3) << 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gn < g.N && gk < g.K) v = *reinterpret_cast<const f32x4*>(Bt + (long long)gn * g.ldb + gk);
+        rb[j] = v;
+      }
+    } else {
+      // item = (column n = tid & 127, k block kb = tid >> 7): 8 dword loads down the column; lanes = consecutive n (coalesced)
+      const int gn = bn + (tid & 127), kb = k0 + 8 * (tid >> 7);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gk = kb + e;
+        const float v = (gn < g.N && gk < g.K) ? Bt[(long long)gk * g.ldb + gn] : 0.f;
+        if (e < 4) rb[0][e] = v; else rb[1][e - 4] = v;
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    char* st = slds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) {
+      const int idx = tid + 256 * j;
+      f16x4 hi, lo;
+      split4(ra[j], hi, lo);
+      char* d = st + (idx >> 2) * SROW + ((idx & 3) << 3);
+      *reinterpret_cast<f16x4*>(d) = hi;
+      *reinterpret_cast<f16x4*>(d + A_BYTES) = lo;
+    }
+    char* sb = st + 2 * A_BYTES;
+    if (TRANS_B) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int idx = tid + 256 * j;
+        f16x4 hi, lo;
+        split4(rb[j], hi, lo);
+        char* d = sb + (idx >> 2) * SROW + ((idx & 3) << 3);
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + B_BYTES) = lo;
+      }
+    } else {
+      f16x4 h0, l0, h1, l1;
+      split4(rb[0], h0, l0);
+      split4(rb[1], h1, l1);
+      char* d = sb + (tid & 127) * SROW + ((tid >> 7) << 4);
+      *reinterpret_cast<f16x8*>(d) = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      *reinterpret_cast<f16x8*>(d + B_BYTES) = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+  };
+
+  load_tiles(0);
+  store_tiles(0);
+  if (nIter > 1) load_tiles(1);
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < nIter; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nIter) store_tiles(cur ^ 1);
+    if (it + 2 < nIter) load_tiles(it + 2);
+    const char* as = slds + cur * STAGE + (wm * 64 + l31) * SROW + lh * 16;
+    const char* bs = slds + cur * STAGE + 2 * A_BYTES + (wn * 32 * NI + l31) * SROW + lh * 16;
+    f16x8 ah[2], al[2], bh[NI], bl[NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ah[mi] = *reinterpret_cast<const f16x8*>(as + mi * 32 * SROW);
+      al[mi] = *reinterpret_cast<const f16x8*>(as + mi * 32 * SROW + A_BYTES);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      bh[ni] = *reinterpret_cast<const f16x8*>(bs + ni * 32 * SROW);
+      bl[ni] = *reinterpret_cast<const f16x8*>(bs + ni * 32 * SROW + B_BYTES);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+    __syncthreads();
+  }
+
+  float* __restrict__ C = g.C + (long long)zo * g.sC + (long long)zi * g.sC2;
+  const float* __restrict__ R = g.R ? g.R + (long long)zo * g.sR : nullptr;
+  const float* __restrict__ RS = g.rowscale ? g.rowscale + (long long)zo * g.sRS : nullptr;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = bn + wn * 32 * NI + ni * 32 + l31;
+      const float bn_v = (g.bias_n && col < g.N) ? g.bias_n[(long long)zo * g.sBiasN + col] : 0.f;
+      const float ps_v = (g.post_scale_n && col < g.N) ? g.post_scale_n[col] : 1.f;
+      const float pb_v = (g.post_scale_n && col < g.N) ? g.post_shift_n[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm * 64 + mi * 32 + acc_row(r, lh);
+        if (row < g.M && col < g.N) {
+          float v = acc[mi][ni][r] * SPLIT_OUT + bn_v;
+          if (g.bias_m) v += g.bias_m[row];
+          if (g.alpha_ncols == 0 || col < g.alpha_ncols) v *= g.alpha;
+          if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+          else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          if (g.post_scale_n) v = v * ps_v + pb_v;
+          if (R) v += R[(long long)row * g.ldr + col];
+          if (RS) v *= RS[row];
+          C[(long long)row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+template <int BM, bool TRANS_B>
+int launch_split(const GemmArgs& g, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (2 * BM * SROW + 2 * FBN * SROW);
+  hipLaunchKernelGGL((gemm_split_kernel<BM, TRANS_B>), dim3(cdiv(g.N, FBN), cdiv(g.M, BM), g.batch), dim3(256), lds, st, g);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
 template <int BM, int FBK, bool TRANS_B>
 int launch_fast(const GemmArgs& g, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BM * (FBK + 4) + 2 * (TRANS_B ? FBN * (FBK + 4) : FBK * FLDN)) * sizeof(float);
@@ -395,6 +590,14 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     // 64-row tiles when 128-row tiles would not give every CU two workgroups (e.g. [16000 x 256] outputs: 250 -> 500 workgroups)
     const long long wg128 = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
     const bool small = wg128 < 2 * 256;
+    static int split = -1;   // BSG_GEMM_SPLIT=0: multiply on the fp32 matrix pipe (gemm_fast_kernel) instead of the split-fp16 form
+    if (split < 0) { const char* e = getenv("BSG_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
+    if (split) {
+      const long long wgs = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
+      const bool sm = wgs < 3 * 256;
+      if (g.trans_b) return sm ? launch_split<64, true>(g, st) : launch_split<128, true>(g, st);
+      return sm ? launch_split<64, false>(g, st) : launch_split<128, false>(g, st);
+    }
     static int bk = -1;   // BSG_GEMM_BK=32: 32-deep LDS stages (two workgroups per CU instead of three)
     if (bk < 0) { const char* e = getenv("BSG_GEMM_BK"); bk = e ? atoi(e) : 16; }
     if (bk == 32) {

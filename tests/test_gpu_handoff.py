@@ -54,6 +54,10 @@ def test_injected_giveup_self_heals_in_the_same_call(B):
     want_eps = net(x0, t, cond).clone()
     want_x = good.sample(cond, x0.clone(), noise=noise[1:], n_steps=8).clone()
     assert net.handoff_timeouts() == 0
+    # B=16 (80 tiles of 64 frames: a third of the CUs) runs the split-fp16 stack launch by default; its repeat after a give-up runs the
+    # per-layer F(2,3) kernels — another rounding of the same sums (1e-5).  The channel-split forms (B=1) heal bit for bit.
+    stack = net.last_path().startswith('stack')
+    same = (lambda a, b: maxabs(a, b) <= 1e-5) if stack else torch.equal
 
     # (1) DiffNet.forward: inject into the 20 layer launches of one evaluation
     m = _model()
@@ -63,7 +67,7 @@ def test_injected_giveup_self_heals_in_the_same_call(B):
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         got = net(x0, t, cond).clone()
-    assert torch.equal(got, want_eps), 'a tensor computed from a given-up hand-off left the call'
+    assert same(got, want_eps), 'a tensor computed from a given-up hand-off left the call'
     if B == 1:          # (a single evaluation at 160 tiles runs the 16-wave one-workgroup-per-tile form: nothing to inject into)
         assert any('hand-offs gave up' in str(x.message) for x in w), 'the give-up went unnoticed'
         assert getattr(net, 'split_disabled', False) and not net.uses_handoffs(B, T)
@@ -78,10 +82,10 @@ def test_injected_giveup_self_heals_in_the_same_call(B):
         warnings.simplefilter('always')
         got = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=8).clone()
     assert any('hand-offs gave up' in str(x.message) for x in w)
-    assert torch.equal(got, want_x)
+    assert same(got, want_x)
     # and the healed handle keeps producing the same bits without hand-offs
     again = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=8).clone()
-    assert torch.equal(again, want_x) and net.handoff_timeouts() == 0
+    assert torch.equal(again, got) and net.handoff_timeouts() == 0
 
 
 def test_injected_giveup_self_heals_f43_stack_launch():

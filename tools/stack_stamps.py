@@ -46,7 +46,7 @@ if DT == 'bf16' or H2:   # stamps in time order: 0 start, 1 flags seen, 2 halo r
 if F43:   # 0 start, 1 GEMM1 done (wave 0), 2 barrier B passed, 3 residual rows done, 4 image + publish + flag, 5 skip rows stored, 6 flags seen, 7 halo copied
     names = ['GEMM1, wave 0 (0->1)', 'gate + x recovery + barrier B (1->2)', 'GEMM2 residual rows (2->3)', 'image + barrier + publish + drain + flag (3->4)',
              'GEMM2 skip rows + skip RMW (4->5)', 'd tables + flag wait + barrier D (5->6)', 'halo copy (6->7)', 'barrier A (7->0 next)']
-if F43:
+if F43 or H2:
     raw = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64)
     cyc = raw[:, L - 1, 7] - raw[:, L - 1, 6]
     us = (raw[:, L - 1, 5] - raw[:, 0, 0]) / 100.0
