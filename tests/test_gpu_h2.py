@@ -90,3 +90,43 @@ def test_split_fp16_is_fp32_grade(B, T, wscale, tmp_path):
     assert err['split_fp16'][0] <= 2e-5 * max(1.0, rms_eps)
     assert err['split_fp16'][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9
     assert err['split_fp16'][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9
+
+
+GEMM_CHILD = r'''
+import sys, json, torch, numpy as np
+sys.path.insert(0, %r)
+from bisinger_amd import _lib
+lib = _lib.load()
+out = {}
+for (M, N, K, tb, scale) in %r:
+    rs = np.random.RandomState(M + N + K)
+    a = (rs.standard_normal((M, K)) * scale).astype(np.float32)
+    b = rs.standard_normal((N, K) if tb else (K, N)).astype(np.float32) * np.float32(0.05)
+    A, B = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    C = torch.empty(M, N, device='cuda')
+    _lib.check(lib.bsg_gemm_f32(_lib.ptr(A), _lib.ptr(B), _lib.ptr(C), None, None, M, N, K, K, K if tb else N, N, tb, 1, 0, 0, 0, 0,
+                                _lib.stream_ptr()), 'gemm')
+    ref = a.astype(np.float64) @ (b.astype(np.float64).T if tb else b.astype(np.float64))
+    e = C.cpu().numpy().astype(np.float64) - ref
+    out['%%dx%%dx%%d_%%d_%%g' %% (M, N, K, tb, scale)] = [float(np.abs(e).max()), float(np.sqrt((e ** 2).mean())), float(np.sqrt((ref ** 2).mean()))]
+print(json.dumps(out))
+'''
+
+
+def test_split_gemm_is_fp32_grade():
+    """gemm_split_kernel (csrc/gemm.hip: operands split into hi + lo fp16 while staged, 3 fp16 MFMAs per product) against
+    gemm_fast_kernel (fp32 MFMAs) on the path's shapes and on operands of other magnitudes (tiny: the lo terms are subnormal fp16;
+    large: close to the documented |operand| < 4094 limit): error vs float64 no worse than the fp32 pipe's."""
+    shapes = [(1000, 768, 256, 1, 1.0), (1000, 256, 1024, 1, 1.0), (512, 1000, 256, 0, 1.0), (777, 80, 256, 1, 1.0),
+              (640, 256, 2304, 1, 1e-3), (640, 256, 256, 1, 500.0)]
+    code = GEMM_CHILD % (ROOT, shapes)
+    res = {}
+    for name, env in (('split', {'BSG_GEMM_SPLIT': '1'}), ('fp32', {'BSG_GEMM_SPLIT': '0'})):
+        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in res['split']:
+        (ms, rs_, ref), (mf, rf, _) = res['split'][k], res['fp32'][k]
+        print(f'{k}: split-fp16 max {ms:.2e} rms {rs_:.2e} | fp32 pipe max {mf:.2e} rms {rf:.2e} | rms of the result {ref:.2e}')
+        assert rs_ <= 1.5 * rf + 1e-12 and ms <= 2.0 * mf + 1e-12
+        assert rs_ <= 2e-6 * ref
