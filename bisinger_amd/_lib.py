@@ -100,6 +100,8 @@ _SIGS = {
     'bsg_weight_norm_fold': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'bsg_gemm_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),
+    'bsg_gemm_set_split': (c_int32, [c_int32]),
+    'bsg_gemm_range_events': (c_int32, [POINTER(c_int32), c_int32, c_void_p]),
 }
 
 _lib = None
@@ -123,6 +125,16 @@ def load():
         raise BsgError(f'ABI mismatch: library {lib.bsg_abi_version()} vs binding {ABI_VERSION}; rebuild')
     _lib = lib
     return lib
+
+
+range_retries = 0      # calls repeated on the fp32 matrix pipe because an operand left the fp16 range of the split-fp16 GEMMs
+
+
+def gemm_range_take():
+    """Wait for the current stream; number of split-fp16 GEMM waves that staged an out-of-range operand since the last take (reset)."""
+    n = c_int32()
+    check(load().bsg_gemm_range_events(ctypes.byref(n), 1, stream_ptr()), 'bsg_gemm_range_events')
+    return n.value
 
 
 def declared_symbols():

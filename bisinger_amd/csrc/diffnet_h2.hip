@@ -13,7 +13,9 @@
 //   Range.  fp16 normals span 2^-14 .. 65504.  Weights are multiplied by a power of two per layer and GEMM (chosen at create so that
 // max |w| lands in [2^13, 2^14)) and z, which lies in (-1, 1), by 2^10; the accumulators start from (initial value) x (scale) and are
 // multiplied by 1 / scale afterwards — all exact.  Activations x + d are split unscaled: below 0.5 their lo term is a subnormal
-// fp16 and carries an ABSOLUTE error of <= 2^-25 (3e-8, half an fp32 ulp of 0.5); |x + d| must stay below 65504.
+// fp16 and carries an ABSOLUTE error of <= 2^-25 (3e-8, half an fp32 ulp of 0.5); |x + d| must stay below 65504 — a RANGE GUARD
+// watches every value that is split in the kernel (image, skip sum, hidden tile, updated x): one beyond 60000 (or not finite) raises
+// the launch's status word, and the host repeats the call on the fp32 matrix pipe (the path of a hand-off give-up, DiffNet.guarded).
 //
 // Structure: the on-chip stack launch of the bf16 configuration (diffnet_bf16.hip residual_stack_bf16_kernel) with two fp16 planes
 // per LDS image and per weight slab: one workgroup of 8 waves x 256 registers per CU owns a 64-frame tile for all L layers; x and the
@@ -237,6 +239,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   float xr[2][16];        // x, accumulator layout: registers 4g..4g+3 = channels 32w + 8g + 4 lh + (0..3) of frame 32 ct + l31
   float sk[2][16];        // running skip sum (fp32), same layout (skip rows C + 32w + ..)
   f32x16 yg0, yf0, yg1, yf1;   // GEMM1 accumulators; they start from the conditioner term x s1
+  // range guard: a value whose hi term would leave the fp16 range (or is not finite) is reported through the hand-off status word, and
+  // the host repeats the call on the fp32 matrix pipe (DiffNet.guarded) — the split never returns a clipped result silently
+  bool out_of_range = false;
+  auto in_range = [&](float v) { out_of_range |= !(fabsf(v) < 60000.0f); return v; };
 
   // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 64 dword loads per lane, 128 B coalesced per half-wave,
   // requested straight into the accumulators a phase before they are used
@@ -260,8 +266,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const HiLo s0 = split2(xr[ct][4 * g] + dv[4 * g], xr[ct][4 * g + 1] + dv[4 * g + 1]);
-        const HiLo s1_ = split2(xr[ct][4 * g + 2] + dv[4 * g + 2], xr[ct][4 * g + 3] + dv[4 * g + 3]);
+        const HiLo s0 = split2(in_range(xr[ct][4 * g] + dv[4 * g]), in_range(xr[ct][4 * g + 1] + dv[4 * g + 1]));
+        const HiLo s1_ = split2(in_range(xr[ct][4 * g + 2] + dv[4 * g + 2]), in_range(xr[ct][4 * g + 3] + dv[4 * g + 3]));
         u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
         if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
         char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
@@ -287,7 +293,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     float hv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
-    const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
+    const HiLo h0 = split2(in_range(hv[0]), in_range(hv[1])), h1 = split2(in_range(hv[2]), in_range(hv[3]));
+    const HiLo h2 = split2(in_range(hv[4]), in_range(hv[5])), h3 = split2(in_range(hv[6]), in_range(hv[7]));
     u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
     if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
     *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = wh;
@@ -486,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   }
 #undef STK_STAMP
   if constexpr (!TAIL) {
+    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull && lane == 0) atomicAdd(p.status, 1u);
     // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
     const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
     const float div = sqrtf((float)L);
@@ -506,7 +514,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const HiLo s0 = split2(sk[ct][4 * g] / div, sk[ct][4 * g + 1] / div), s1_ = split2(sk[ct][4 * g + 2] / div, sk[ct][4 * g + 3] / div);
+          const HiLo s0 = split2(in_range(sk[ct][4 * g] / div), in_range(sk[ct][4 * g + 1] / div));
+          const HiLo s1_ = split2(in_range(sk[ct][4 * g + 2] / div), in_range(sk[ct][4 * g + 3] / div));
           char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
           *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
           *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
@@ -534,8 +543,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const HiLo s0 = split2(fmaxf(hc[ct][4 * g] * inv, 0.f), fmaxf(hc[ct][4 * g + 1] * inv, 0.f));
-          const HiLo s1_ = split2(fmaxf(hc[ct][4 * g + 2] * inv, 0.f), fmaxf(hc[ct][4 * g + 3] * inv, 0.f));
+          const HiLo s0 = split2(in_range(fmaxf(hc[ct][4 * g] * inv, 0.f)), in_range(fmaxf(hc[ct][4 * g + 1] * inv, 0.f)));
+          const HiLo s1_ = split2(in_range(fmaxf(hc[ct][4 * g + 2] * inv, 0.f)), in_range(fmaxf(hc[ct][4 * g + 3] * inv, 0.f)));
           char* dst = zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
           *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
           *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
@@ -609,12 +618,13 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       // the updated x as the input projection's B operand: channels-last rows of the image region (channels 0..95; rows >= M zero)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const HiLo s0 = split2(o[4 * g], o[4 * g + 1]), s1_ = split2(o[4 * g + 2], o[4 * g + 3]);
+        const HiLo s0 = split2(in_range(o[4 * g]), in_range(o[4 * g + 1])), s1_ = split2(in_range(o[4 * g + 2]), in_range(o[4 * g + 3]));
         char* dst = xs + (HALO + 32 * ct2 + l31) * ROWB + (32 * rt + 8 * g + 4 * lh) * 2;
         *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
         *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
       }
     }
+    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull && lane == 0) atomicAdd(p.status, 1u);
     if (!a.do_head) return;
     // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded) ------------------------------------
     {

@@ -22,6 +22,9 @@
 
 namespace bsg {
 
+// range guard of gemm_split_kernel: number of waves that staged an operand whose hi term leaves the fp16 range (bsg_gemm_range_events)
+__device__ unsigned g_gemm_range_events = 0;
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDP = BK + 1;
@@ -383,10 +386,11 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr int SBK = 16, SROW = 48;        // k extent of a stage; bytes per LDS row of a plane
 constexpr float SPLIT_IN = 16.0f, SPLIT_OUT = 1.0f / 256.0f;
 
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo, bool& bad) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float x = v[e] * SPLIT_IN;
+    bad |= !(fabsf(x) < 65000.0f);   // also true for NaN / inf
     hi[e] = (_Float16)x;
     lo[e] = (_Float16)(x - (float)hi[e]);
   }
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 
   const int kTiles = (g.K + SBK - 1) / SBK;
   const int nIter = kTiles * g.taps;
+  bool bad = false;           // an operand outside the fp16 range was staged (range guard)
   f32x4 ra[A_LD4], rb[2];     // TRANS_B: 2 float4 (4 consecutive k of a row); else rb[0], rb[1] = 8 consecutive k of one column
 
   auto load_tiles = [&](int it) {
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     for (int j = 0; j < A_LD4; ++j) {
       const int idx = tid + 256 * j;
       f16x4 hi, lo;
-      split4(ra[j], hi, lo);
+      split4(ra[j], hi, lo, bad);
       char* d = st + (idx >> 2) * SROW + ((idx & 3) << 3);
       *reinterpret_cast<f16x4*>(d) = hi;
       *reinterpret_cast<f16x4*>(d + A_BYTES) = lo;
@@ -472,15 +477,15 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
       for (int j = 0; j < 2; ++j) {
         const int idx = tid + 256 * j;
         f16x4 hi, lo;
-        split4(rb[j], hi, lo);
+        split4(rb[j], hi, lo, bad);
         char* d = sb + (idx >> 2) * SROW + ((idx & 3) << 3);
         *reinterpret_cast<f16x4*>(d) = hi;
         *reinterpret_cast<f16x4*>(d + B_BYTES) = lo;
       }
     } else {
       f16x4 h0, l0, h1, l1;
-      split4(rb[0], h0, l0);
-      split4(rb[1], h1, l1);
+      split4(rb[0], h0, l0, bad);
+      split4(rb[1], h1, l1, bad);
       char* d = sb + (tid & 127) * SROW + ((tid >> 7) << 4);
       *reinterpret_cast<f16x8*>(d) = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
       *reinterpret_cast<f16x8*>(d + B_BYTES) = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
     __syncthreads();
   }
+  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(&g_gemm_range_events, 1u);
 
   float* __restrict__ C = g.C + (long long)zo * g.sC + (long long)zi * g.sC2;
   const float* __restrict__ R = g.R ? g.R + (long long)zo * g.sR : nullptr;
@@ -577,6 +583,8 @@ int launch_fast(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
+static int g_split = -1;   // -1: not read yet (environment); set by bsg_gemm_set_split
+
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   BSG_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.taps > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
   BSG_REQUIRE(g.batch <= 65535, "gemm: batch %d > 65535", g.batch);
@@ -590,9 +598,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     // 64-row tiles when 128-row tiles would not give every CU two workgroups (e.g. [16000 x 256] outputs: 250 -> 500 workgroups)
     const long long wg128 = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
     const bool small = wg128 < 2 * 256;
-    static int split = -1;   // BSG_GEMM_SPLIT=0: multiply on the fp32 matrix pipe (gemm_fast_kernel) instead of the split-fp16 form
-    if (split < 0) { const char* e = getenv("BSG_GEMM_SPLIT"); split = e ? atoi(e) : 1; }
-    if (split) {
+    // BSG_GEMM_SPLIT=0 / bsg_gemm_set_split(0): multiply on the fp32 matrix pipe (gemm_fast_kernel) instead of the split-fp16 form
+    if (g_split < 0) { const char* e = getenv("BSG_GEMM_SPLIT"); g_split = e ? atoi(e) : 1; }
+    if (g_split) {
       const long long wgs = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
       const bool sm = wgs < 3 * 256;
       if (g.trans_b) return sm ? launch_split<64, true>(g, st) : launch_split<128, true>(g, st);
@@ -628,4 +636,24 @@ extern "C" int bsg_gemm_f32(const float* A, const float* Bm, float* C, const flo
   g.bias_m = bias_m; g.bias_n = bias_n; g.alpha = 1.f; g.act = relu ? bsg::ACT_RELU : bsg::ACT_NONE;
   g.batch = batch;
   return bsg::launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int bsg_gemm_set_split(int32_t enable) {
+  bsg::g_split = enable ? 1 : 0;
+  return BSG_OK;
+}
+
+extern "C" int bsg_gemm_range_events(int32_t* events, int32_t reset, void* stream) {
+  BSG_REQUIRE(events, "gemm_range_events: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned v = 0;
+  BSG_HIP(hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(bsg::g_gemm_range_events), sizeof(unsigned), 0, hipMemcpyDeviceToHost, st));
+  BSG_HIP(hipStreamSynchronize(st));
+  if (v && reset) {
+    const unsigned z = 0;
+    BSG_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(bsg::g_gemm_range_events), &z, sizeof(unsigned), 0, hipMemcpyHostToDevice, st));
+    BSG_HIP(hipStreamSynchronize(st));
+  }
+  *events = (int32_t)v;
+  return BSG_OK;
 }

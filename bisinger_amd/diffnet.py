@@ -204,11 +204,27 @@ class DiffNet(nn.Module):
         if torch.cuda.is_current_stream_capturing() or not self.uses_handoffs(B, T):
             return
         n = self.take_handoff_timeouts()
+        if _lib.gemm_range_take():
+            # an operand of a split-fp16 GEMM (input / conditioner projections, FS2) left the fp16 range: every GEMM moves to the fp32
+            # matrix pipe, the bound condition is projected again and the work repeated; a caller that produced `cond` with those GEMMs
+            # (GaussianDiffusion.forward) sees _lib.range_retries change and repeats its own part
+            import warnings
+            warnings.warn('bisinger_amd: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4094); GEMMs now run on the fp32 '
+                          'matrix pipe and the evaluation is repeated')
+            _lib.check(_lib.load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
+            _lib.range_retries += 1
+            if self._bound is not None:
+                self.prepare(self._bound[0])
+            if restore is not None:
+                restore()
+            run()
+            n = self.take_handoff_timeouts()
         if n == 0:
             return
         import warnings
-        warnings.warn(f'bisinger_amd: {n} inter-workgroup hand-offs gave up (a partner workgroup was not resident); '
-                      f'channel-split launches are now off for this DiffNet handle and the evaluation is repeated')
+        warnings.warn(f'bisinger_amd: {n} inter-workgroup hand-offs gave up (a partner workgroup was not resident) or an activation '
+                      f'left the fp16 range of the split-fp16 launch; channel-split and stack launches are now off for this DiffNet '
+                      f'handle (per-layer launches on the fp32 matrix pipe) and the evaluation is repeated')
         _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
         self.split_disabled = True
         if restore is not None:

@@ -187,6 +187,15 @@ class GaussianDiffusion(nn.Module):
         have len(rows) rows and reproduce the same rows of the unsharded call — SURVEY.md §8e)."""
         if not infer:
             raise NotImplementedError('training (p_losses) is outside the accelerated hot path (SURVEY.md §8)')
+        # range guard of the split-fp16 GEMMs: when the sampler's guard had to move the GEMMs to the fp32 matrix pipe (an operand beyond
+        # the fp16 range; bisinger_amd/diffnet.py guarded), FS2 above it ran with the same GEMMs: repeat the whole call once
+        retries = _lib.range_retries
+        ret = self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs)
+        if _lib.range_retries != retries:
+            ret = self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs)
+        return ret
+
+    def _forward_infer(self, txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs):
         B_total = txt_tokens.shape[0]
         row0 = 0
         if rows is not None:

@@ -130,3 +130,62 @@ def test_split_gemm_is_fp32_grade():
         print(f'{k}: split-fp16 max {ms:.2e} rms {rs_:.2e} | fp32 pipe max {mf:.2e} rms {rf:.2e} | rms of the result {ref:.2e}')
         assert rs_ <= 1.5 * rf + 1e-12 and ms <= 2.0 * mf + 1e-12
         assert rs_ <= 2e-6 * ref
+
+
+@pytest.mark.parametrize('mode', ['stack', 'gemm'])
+def test_range_guards_repeat_on_the_fp32_pipe(mode):
+    """Operands beyond the fp16 range cannot be split.  'stack': inside the stack launch (|x + d| >= 60000, here through the bias of one
+    layer's diffusion projection) the launch reports it through the hand-off status word; 'gemm': in the split-fp16 GEMMs (|operand| >=
+    4094, here the input projection of a huge x) a device counter does.  Either way the evaluation is repeated on the fp32 matrix pipe in
+    the same call, with a warning, and agrees with a handle that never used the 16-bit pipe.  Child process: the switches are process-wide
+    once they have tripped."""
+    code = r'''
+import sys, json, warnings, torch, numpy as np
+sys.path.insert(0, %r)
+from tests.util import load_formula_weights, use_config, maxabs
+from bisinger_amd import synth, _lib
+torch.set_grad_enabled(False)
+use_config()
+from bisinger_amd.diffnet import DiffNet
+mode = sys.argv[1]
+B, T = 16, 320
+rs = np.random.RandomState(21)
+x = torch.from_numpy(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
+cond = torch.from_numpy(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+t = torch.full((B,), 17, device='cuda', dtype=torch.long)
+def make():
+    net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.')
+    if mode == 'stack':
+        net.residual_layers[3].diffusion_projection.bias.add_(3e6)   # d_3 ~ 3e6: x + d beyond the launch's range; no GEMM operand is large
+    return net.cuda()
+xin = x * 3e6 if mode == 'gemm' else x
+out = {}
+net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+with warnings.catch_warnings(record=True) as w0:
+    warnings.simplefilter('always')
+    small = net(x, t, cond).clone()
+out['small_path'], out['small_warn'] = net.last_path(), len(w0)
+net = make()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    y = net(xin, t, cond).clone()
+msgs = [str(m.message) for m in w]
+out['warn_stack'] = any('fp16 range of the split-fp16 launch' in m for m in msgs)
+out['warn_gemm'] = any('split-fp16 GEMMs' in m for m in msgs)
+out['path'], out['finite'], out['retries'] = net.last_path(), bool(torch.isfinite(y).all()), _lib.range_retries
+_lib.check(_lib.load().bsg_gemm_set_split(0), 'gemm_set_split')          # reference: fp32 matrix pipe everywhere, from creation on
+ref = make(); ref.prepare(cond)
+_lib.check(_lib.load().bsg_diffnet_set_split(ref._h, 0), 'set_split')
+yr = ref(xin, t, cond).clone()
+out['ref_path'] = ref.last_path()
+out['dev'], out['scale'] = maxabs(y, yr), float(yr.abs().max())
+print(json.dumps(out))
+''' % ROOT
+    res = subprocess.run([sys.executable, '-c', code, mode], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    print(out)
+    assert out['small_path'] == 'stack_h2' and out['small_warn'] == 0            # the shape does run the split-fp16 launch, quietly
+    assert out['finite'] and not out['ref_path'].startswith('stack')
+    assert out['warn_stack'] if mode == 'stack' else (out['warn_gemm'] and out['retries'] >= 1)
+    assert out['dev'] <= 1e-5 * max(1.0, out['scale'])
