@@ -1895,7 +1895,6 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.fbase = h->stack_epoch * 64u;
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
-    if (stamps) { const char* e = getenv("BSG_H2_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row

@@ -121,7 +121,7 @@ __device__ __forceinline__ int kmap(int i) {
 // FAIRB: the two waves of a SIMD take turns at issue priority (see f43_gemm1, diffnet_f43.hip).
 template <int ROT, bool FAIRB, typename LDB, typename MID>
 __device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
-                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half, int kmul = 1) {
+                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
   f16x8 B[2][4];
   ldb(kmap<ROT>(0), B[0]);
   const int last = n_ks - 1;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c
       BSG_MFMA_H(c11, A[s][3], Bc[2]);
       __builtin_amdgcn_sched_barrier(0);
       const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
-      const int kr = kmap<ROT>(ir) * kmul;   // kmul = 0: timing experiment (p.dbg)
+      const int kr = kmap<ROT>(ir);
       A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
       A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
       A[s][2] = lda8(rs, vfrag, sa1 + kr * KSB2);
@@ -240,9 +240,13 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   float sk[2][16];        // running skip sum (fp32), same layout (skip rows C + 32w + ..)
   f32x16 yg0, yf0, yg1, yf1;   // GEMM1 accumulators; they start from the conditioner term x s1
   // range guard: a value whose hi term would leave the fp16 range (or is not finite) is reported through the hand-off status word, and
-  // the host repeats the call on the fp32 matrix pipe (DiffNet.guarded) — the split never returns a clipped result silently
-  bool out_of_range = false;
-  auto in_range = [&](float v) { out_of_range |= !(fabsf(v) < 60000.0f); return v; };
+  // the host repeats the call on the fp32 matrix pipe (DiffNet.guarded) — the split never returns a clipped result silently.  `worst`
+  // collects the largest |value| bit pattern a phase splits (NaN and inf order above every finite float); the flag is wave-uniform
+  int range_flag = 0;
+  auto range_check = [&](unsigned worst) {
+    if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
+  };
+  auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
 
   // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 64 dword loads per lane, 128 B coalesced per half-wave,
   // requested straight into the accumulators a phase before they are used
@@ -260,20 +264,25 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   // image core (frames t0 .. t0+63, this wave's 32 channels) = hi / lo of x + d_l, zero beyond T (the conv pads x + d)
   auto write_core = [&]() {   // d of the layer being prepared is in dtab (written a phase earlier, behind a barrier)
     float dv[16];
+    unsigned worst = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv[r] = dtab[32 * wave + acc_row(r, lh)];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const HiLo s0 = split2(in_range(xr[ct][4 * g] + dv[4 * g]), in_range(xr[ct][4 * g + 1] + dv[4 * g + 1]));
-        const HiLo s1_ = split2(in_range(xr[ct][4 * g + 2] + dv[4 * g + 2]), in_range(xr[ct][4 * g + 3] + dv[4 * g + 3]));
+        const float v0 = xr[ct][4 * g] + dv[4 * g], v1 = xr[ct][4 * g + 1] + dv[4 * g + 1];
+        const float v2 = xr[ct][4 * g + 2] + dv[4 * g + 2], v3 = xr[ct][4 * g + 3] + dv[4 * g + 3];
+        worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
+        const HiLo s0 = split2(v0, v1);
+        const HiLo s1_ = split2(v2, v3);
         u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
         if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
         char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
         *reinterpret_cast<u32x2*>(dst) = wh;
         *reinterpret_cast<u32x2*>(dst + XP) = wl;
       }
+    range_check(worst);
   };
 
   // ---- layer 0: x from HBM (the whole input exists, halo included) ------------------------------------------------------
@@ -293,8 +302,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     float hv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
-    const HiLo h0 = split2(in_range(hv[0]), in_range(hv[1])), h1 = split2(in_range(hv[2]), in_range(hv[3]));
-    const HiLo h2 = split2(in_range(hv[4]), in_range(hv[5])), h3 = split2(in_range(hv[6]), in_range(hv[7]));
+    range_check(max(max(max(absbits(hv[0]), absbits(hv[1])), max(absbits(hv[2]), absbits(hv[3]))),
+                    max(max(absbits(hv[4]), absbits(hv[5])), max(absbits(hv[6]), absbits(hv[7])))));
+    const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
     u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
     if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
     *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = wh;
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   do {                                                                                                            \
     if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
-  const unsigned long long clk0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;   // shader clock, to price the phases in cycles
+  if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
 #pragma unroll 1
   for (int l = 0; l < L; ++l) {
     const int dil = 1 << (l % p.cycle);
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         __syncthreads();   // (A) halo rows in place
         STK_STAMP(2);
       };
-      mfma_pipe_h2<16, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2, p.dbg & 1 ? 0 : 1);
+      mfma_pipe_h2<16, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
         Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + ZP);
       };
-      mfma_pipe_h2<0, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2, p.dbg & 1 ? 0 : 1);
+      mfma_pipe_h2<0, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (l + 1 < L) prefetch_a1(l + 1);
@@ -456,13 +466,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       sk[1][r] += yf1[r] * inv2;
     }
     STK_STAMP(5);
-    if (l + 1 == L) {
-      if (p.stamps && tid == 0) {   // slots 6, 7 of the last layer: shader cycles from the first layer's start to here
-        p.stamps[((long long)tile_id * L + l) * 8 + 6] = clk0;
-        p.stamps[((long long)tile_id * L + l) * 8 + 7] = __builtin_amdgcn_s_memtime();
-      }
-      break;
-    }
+    if (l + 1 == L) break;
 
     // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
     // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
@@ -492,8 +496,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     STK_STAMP(7);
   }
 #undef STK_STAMP
+  if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock: end of the last layer ...
   if constexpr (!TAIL) {
-    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull && lane == 0) atomicAdd(p.status, 1u);
+    if (range_flag && lane == 0) atomicAdd(p.status, 1u);
     // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
     const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
     const float div = sqrtf((float)L);
@@ -510,12 +515,17 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     // ---- s = skip sum / sqrt(L) -> hi / lo image rows (the conv image is dead: every wave is behind barrier (B) of the last layer) ----
     {
       const float div = sqrtf((float)L);
+      unsigned worst = 0;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) worst = max(worst, absbits(sk[ct][r]));   // |s| <= |skip sum|
+      range_check(worst);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const HiLo s0 = split2(in_range(sk[ct][4 * g] / div), in_range(sk[ct][4 * g + 1] / div));
-          const HiLo s1_ = split2(in_range(sk[ct][4 * g + 2] / div), in_range(sk[ct][4 * g + 3] / div));
+          const HiLo s0 = split2(sk[ct][4 * g] / div, sk[ct][4 * g + 1] / div), s1_ = split2(sk[ct][4 * g + 2] / div, sk[ct][4 * g + 3] / div);
           char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
           *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
           *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
@@ -539,12 +549,20 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       for (int r = 0; r < 16; ++r) hc[0][r] = hc[1][r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
       __syncthreads();   // (T1) s complete; every wave is done with GEMM2 of the last layer (zs is free)
       tail_gemm_h2<2, 16>(hc, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
+      {
+        unsigned worst = 0;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) worst = max(worst, absbits(hc[ct][r] * inv));
+        range_check(worst);
+      }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const HiLo s0 = split2(in_range(fmaxf(hc[ct][4 * g] * inv, 0.f)), in_range(fmaxf(hc[ct][4 * g + 1] * inv, 0.f)));
-          const HiLo s1_ = split2(in_range(fmaxf(hc[ct][4 * g + 2] * inv, 0.f)), in_range(fmaxf(hc[ct][4 * g + 3] * inv, 0.f)));
+          const HiLo s0 = split2(fmaxf(hc[ct][4 * g] * inv, 0.f), fmaxf(hc[ct][4 * g + 1] * inv, 0.f));
+          const HiLo s1_ = split2(fmaxf(hc[ct][4 * g + 2] * inv, 0.f), fmaxf(hc[ct][4 * g + 3] * inv, 0.f));
           char* dst = zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
           *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
           *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
@@ -615,16 +633,22 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           if (cok) stf(o[r], rs_xx, vs, (32 * rt + acc_row0(r)) * rowT);
         }
       }
+      {
+        unsigned worst = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) worst = max(worst, absbits(o[r]));
+        range_check(worst);
+      }
       // the updated x as the input projection's B operand: channels-last rows of the image region (channels 0..95; rows >= M zero)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const HiLo s0 = split2(in_range(o[4 * g]), in_range(o[4 * g + 1])), s1_ = split2(in_range(o[4 * g + 2]), in_range(o[4 * g + 3]));
+        const HiLo s0 = split2(o[4 * g], o[4 * g + 1]), s1_ = split2(o[4 * g + 2], o[4 * g + 3]);
         char* dst = xs + (HALO + 32 * ct2 + l31) * ROWB + (32 * rt + 8 * g + 4 * lh) * 2;
         *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
         *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
       }
     }
-    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull && lane == 0) atomicAdd(p.status, 1u);
+    if (range_flag && lane == 0) atomicAdd(p.status, 1u);
     if (!a.do_head) return;
     // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded) ------------------------------------
     {

@@ -58,7 +58,6 @@ struct StackArgs {
   int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
-  int dbg;                // timing experiments of the diagnostic launch only (wrong results): 1 = every weight load of the split-fp16 form hits the same k-step (L1)
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
 };
 

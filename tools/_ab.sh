@@ -1,1 +1,9 @@
-timeout 300 python tools/stack_stamps.py 16 1000 2>&1 | sed -n 1,4p | cut -c1-150
+# same-box A/B of library builds: tools/_ab.sh <label=path-or-empty> ...   (empty path = the tree's build); extra env via AB_ENV_<label>
+for rep in 1 2; do
+  for spec in "$@"; do
+    label=${spec%%=*}; path=${spec#*=}
+    envs=$(eval echo \$AB_ENV_$label)
+    out=$(env BSG_LIB=$path $envs timeout -k 10 200 python bench.py --no-secondary --cpu-steps 0 --steps 5 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['value']), round(j['ms_per_step'],2), round(j['roofline']['avg_launch_us'],2), j['roofline']['kernel'][:28])")
+    echo "$label rep$rep: $out"
+  done
+done
