@@ -15,13 +15,17 @@ Workloads
           the mels per pass; a weak-scaling figure (16 utterances per GPU) is measured after it and attached as `weak_scaling`.
 
 The JSON line also carries
-  roofline     : the dominant kernel (fused residual layer), timed live with HIP events on the launch streams during the timed
-                 steps, against the fp32 MFMA peak.  `frac` prices ALGORITHMIC FLOPs (the reference's direct convolution,
-                 SURVEY §8d); `frac_executed` prices the FLOPs the kernel's Winograd form actually issues (3/4 of them), i.e.
-                 how busy the matrix pipe is.  `traffic` = HBM-side bytes per launch from PMC counters of a SOLO launch
-                 (rocprofv3 serialises kernels; profiles/traffic*.json) — labelled as such in `traffic_condition`;
-  secondary    : (N = 1, untimed against the headline) BASELINE configs[2] — bf16 operands, B=64 — with its own roofline
-                 (HBM-bound), and configs[4] — B=1, T=1000 mel generation + HiFi-GAN vocoder, real-time factor;
+  roofline     : the dominant kernel (the residual stack launch: all 20 layers — and the step tail — per launch), timed live with
+                 HIP events on the launch stream during the timed steps.  `achieved` prices ALGORITHMIC FLOPs of one layer over
+                 the batch (the reference's direct convolution) against the dense peak of the matrix pipe the
+                 products run on (fp16 for the default split-fp16 form, fp32 with BSG_H2=0); `frac_executed` prices the MFMAs
+                 the form actually issues (3 fp16 products per fp32 product; 5/8 of the direct FLOPs for Winograd F(4,3)), i.e.
+                 how busy the pipe is.  `traffic` = HBM-side bytes from PMC counters (profiles/traffic*.json, looked up by the
+                 launch form that ran), condition stated in `traffic_condition`;
+  secondary    : (N = 1, untimed against the headline) BASELINE configs[2] — bf16 operands, B=64 — with its own roofline,
+                 configs[4] — B=1, T=1000 mel generation + HiFi-GAN vocoder, real-time factor — and f32_matrix_pipe: the headline
+                 workload with every product on the fp32 matrix pipe (the default forms fp32 products on the 16-bit pipe from
+                 exact hi + lo fp16 splits: `arithmetic`);
   cpu_baseline : the oracle (PyTorch-CPU restatement of the reference, oracle/) timed on this host with one socket's physical
                  cores, median of 3 runs of a bounded sample (FS2 + --cpu-steps sampler steps, extrapolated to
                  100; --cpu-steps 100 = the full pass); the same sample replayed on the GPU with the same supplied noise must
@@ -374,6 +378,23 @@ def secondary_bf16(model, device, fence):
             'roofline': roofline(True, layer_ms, n_layer, 3, 64, path)}
 
 
+def secondary_fp32_pipe():
+    """The headline workload with every product on the fp32 matrix pipe (BSG_H2=0: F(4,3) stack launch, BSG_GEMM_SPLIT=0: fp32-MFMA GEMMs)
+    — a child process, because the launch-form switches are read once per process.  3 timed passes, no secondaries, no CPU leg."""
+    env = dict(os.environ, BSG_H2='0', BSG_GEMM_SPLIT='0')
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--no-secondary', '--cpu-steps', '0', '--steps', '3', '--warmup', '1'],
+                             env=env, capture_output=True, text=True, timeout=300)
+        j = json.loads(out.stdout.strip().splitlines()[-1])
+        r = j['roofline']
+        return {'config': {'workload': j['config']['workload'] + '; BSG_H2=0 BSG_GEMM_SPLIT=0: every product on the fp32 matrix pipe'},
+                'dtype': 'f32', 'metric': 'mel_frames_per_sec', 'value': j['value'], 'unit': 'mel-frames/s', 'steps': j['steps'],
+                'warmup': j['warmup'], 'ms_per_step': j['ms_per_step'],
+                'roofline': {k: r.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_executed', 'avg_launch_us')}}
+    except Exception as e:      # the secondary must never take the headline down
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
 def secondary_e2e(model, device, fence):
     """BASELINE configs[4]: B=1, T=1000 mel generation + HiFi-GAN vocoder, 22.05 kHz; real-time factor."""
     import torch
@@ -563,13 +584,19 @@ def main():
             'roofline': roofline(bf16, layer_ms, n_layer, args.steps, wl.b_local, model.denoise_fn.last_path()),
             'handoff_timeouts': timeouts,
         }
+        if not bf16 and model.denoise_fn.last_path().startswith('stack_h2'):
+            rec['arithmetic'] = ('fp32 tensors and fp32 results; in the residual stack, the step tail and the GEMMs every fp32 product is formed on the '
+                                 '16-bit matrix pipe as ah*bh + ah*bl + al*bh from EXACT hi + lo fp16 splits of both operands (fp32 accumulate; '
+                                 'product error <= 3 x 2^-24).  Error against float64 equals that of the fp32-MFMA forms (tests/test_gpu_h2.py); '
+                                 'secondary.f32_matrix_pipe is the same workload with every product on the fp32 matrix pipe')
         if use_dist:
             rec['ranks_seen_by_rccl'] = dist.get_world_size()
             rec['collective_backend'] = dist.get_backend()
         if weak:
             rec['weak_scaling'] = weak
         if world == 1 and not args.no_secondary and not bf16 and args.batch is None:
-            rec['secondary'] = {'bf16_b64': secondary_bf16(model, device, fence), 'e2e_rtf_b1': secondary_e2e(model, device, fence)}
+            rec['secondary'] = {'bf16_b64': secondary_bf16(model, device, fence), 'e2e_rtf_b1': secondary_e2e(model, device, fence),
+                                'f32_matrix_pipe': secondary_fp32_pipe()}
         if world == 1 and args.cpu_steps > 0:
             base, parity = cpu_baseline_and_parity(model, wl.inp_np, device, args.cpu_steps)
             rec['cpu_baseline'] = base
