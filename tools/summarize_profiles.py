@@ -78,6 +78,7 @@ for cfg in ('f32', 'bf16', 'voc'):
                      ('residual_layer_kernel<false, true>', 'layer')],
              'bf16': [('residual_stack_bf16_kernel<true>', 'stack_bf16'), ('residual_stack_bf16_kernel<false>', 'stack_bf16'),
                       ('residual_layer_bf16_kernel<false>', 'bf16')]}.get(cfg, [])
+    cands = [(k, 'stack_h2') for k in per_kernel if k.startswith('residual_stack_h2_kernel')] + cands   # any instantiation (<FAIR, TAIL>)
     for dom, path in cands:
         if dom not in per_kernel or 'hbm_bytes_per_launch' not in per_kernel[dom]:
             continue
