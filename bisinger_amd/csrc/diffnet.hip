@@ -703,282 +703,20 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
 }
 
 // ------------------------------------------------------------------------------------------------
-// All L residual layers of one DiffNet evaluation in ONE launch, with the residual stream ON CHIP (residual_stack_kernel).
-// Workgroup = one 32-frame tile of one utterance for the whole stack:
-//   * x lives in LDS (xs = x + d_l, the B operand of GEMM1) and in registers (the lane's 16 accumulator positions, the
-//     initial value of GEMM2's residual rows); it is read from HBM once (layer 0) and never written back;
-//   * the running skip sum lives in 16 registers and is stored once, after the last layer;
-//   * per layer the only inter-workgroup traffic is the 8-frame edge of the new x that each of the two neighbour tiles
-//     needs as its halo (dilation <= 8 < 32): 2 x 8 KB per tile, published write-through (sc1) into a double-buffered (layer
-//     parity) exchange array; flag[tile] = base + number of layers published.  Protocol (cdna_hip_programming.md Guideline 16,
-//     valid form, as the split launch): producer: sc1 stores -> every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed
-//     agent-scope flag store; consumer: one lane polls the two neighbour flags (relaxed, s_sleep, bounded) -> ONE agent-scope
-//     acquire -> s_waitcnt vmcnt(0) -> barrier -> plain loads.  Double buffering is enough: a tile can only publish layer l+2
-//     after its neighbours published l+1, which they do after reading its l.
-//   * the hoisted conditioner term of the NEXT layer (the largest HBM stream, 64 KB per tile and layer, independent of
-//     everything) is requested straight into the GEMM1 accumulators while the workgroup waits for its neighbours, so the gate
-//     phase no longer waits for memory; GEMM2 is split into its residual half (-> new x -> publish) and its skip half, which
-//     runs while the published edges drain.
-// HBM bytes per frame and layer: 2 KB (conditioner term) + 0.5 KB edges, against 6 KB for the per-layer launch; no launch
-// boundary, no staging phase, no skip read-modify-write between layers.  Arithmetic per output element is the per-layer
-// kernel's, except that the conditioner term is the accumulator's initial value instead of being added after the products.
-// Every workgroup must be resident (neighbours wait for each other): the host launches at most 2 per CU (80 KB of LDS each)
-// and never inside a stream capture; spins are bounded and counted in `status` like the split launch's.
+// Stack launches: all L residual layers of a group of rows in ONE launch with the residual stream on chip (diffnet_h2.hip: split-fp16
+// form, the fp32 default; diffnet_f43.hip: Winograd F(4,3) on the fp32 matrix pipe; diffnet_bf16.hip: bf16-operand configuration; the
+// host side — stack_rows / launch_stack — is below).  (The first form, a F(2,3) kernel with two 32-frame workgroups per CU, lived here
+// in the first half of round 2; it was 3 % slower than two chains of per-layer launches, was superseded by the forms above and removed.)
+// The hand-off protocol all of them share: per layer the only inter-workgroup traffic is the 8-frame edge of the new conv image that
+// each of the two neighbour tiles needs as its halo (dilation <= 8): published write-through (sc1) into an exchange array that is
+// double-buffered by layer parity; flag[tile] = launch epoch * 64 + number of layers published.  Producer: sc1 stores -> every storing
+// wave s_waitcnt vmcnt(0) -> barrier -> one relaxed agent-scope flag store.  Consumer: one lane polls the two neighbour flags (relaxed,
+// s_sleep, bounded: a give-up is counted in `status` and handled by the host in the same call) -> barrier -> sc1 buffer loads of the
+// handed-off bytes to registers (cdna_hip_programming.md Guideline 16, MI355X_MICROARCH.md hand-off "valid forms": no agent-scope
+// acquire, which would invalidate the CU's L1 — the weight stream's — every layer).  Double buffering is enough: a tile can only
+// publish layer l+2 after its neighbours published l+1, which they do after reading its l.  Every workgroup of a launch must be
+// resident (neighbours wait for each other): the host launches whole rows, at most one workgroup per CU, never inside a stream capture.
 // ------------------------------------------------------------------------------------------------
-
-// one row tile (32 rows) x 32 columns, K = 8 * (q_end - q_begin): A fragments in a ring of NS groups of 4 k-steps
-template <int NS, typename LDB>
-__device__ __forceinline__ void mfma_pipe1(f32x16& acc, f32x4 (&A)[NS], rsrc_t rs, int vfrag, int sa, int q_begin, int q_end, int q_last,
-                                           LDB ldb) {
-  f32x4 Bf[2];
-  Bf[0] = ldb(q_begin);
-#pragma unroll 1
-  for (int q = q_begin; q < q_end; q += NS) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int qn = q + s + 1 <= q_last ? q + s + 1 : q_last;
-      Bf[(s + 1) & 1] = ldb(qn);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s][j], Bf[s & 1][j], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      const int qr = q + s + NS <= q_last ? q + s + NS : q_last;
-      A[s] = ldf4(rs, vfrag, sa + qr * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-__global__ __launch_bounds__(512, 4) void residual_stack_kernel(StackArgs p) {
-  constexpr int NT = 32, LDX = NT + 2 * HALO, LDZ = NT;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;             // [C][48]  x + d of the current layer, halo columns included
-  float* zs = lds + C * LDX;   // [C][32]  gated activation (own region: the next layer's xs is written while GEMM2 still reads zs)
-
-  const StackArgs& a = p;
-  // XCD-aware tile order (see residual_layer_kernel): neighbouring tiles exchange their edges through one L2
-  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
-  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-  if (tile_id >= n_tiles) return;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5, p16 = lane & 15, lq = lane >> 4;
-  const int tpr = a.tiles_per_row, L = a.L, T = a.T;
-  const int b = tile_id / tpr, j = tile_id - b * tpr;
-  const int t0 = j * NT;
-  const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
-  const int col = t0 + l31;
-  const bool col_ok = col < T;
-  const int colc = col_ok ? col : T - 1;
-  const bool has_left = j > 0, has_right = j + 1 < tpr;
-
-  const unsigned plane = (unsigned)C * T * 4;
-  const rsrc_t rs_x = mk_rsrc(a.x_in + (long long)b * C * T, plane);
-  const rsrc_t rs_sk = mk_rsrc(a.skip + (long long)b * C * T, plane);
-  const int rowT = T * 4, vfrag = lane * 16;
-  const int vcol = (lh * 4 * T + colc) * 4;
-  const int sw[4] = {(2 * wave) * 16 * 1024, (2 * wave + 1) * 16 * 1024, (16 + 2 * wave) * 16 * 1024, (16 + 2 * wave + 1) * 16 * 1024};
-  const int sb_r = wave * 32 * 1024, sb_s = (8 + wave) * 32 * 1024;
-
-  f32x16 skipacc;         // this lane's 16 positions (rows 32w + acc_row(r, lh), frame col) of the running skip sum
-  f32x4 y0[4], y1[4];     // GEMM1 outputs of the pair (t, t+d): [0..1] gate tiles, [2..3] filter tiles; start from the conditioner term
-
-  // conditioner term of layer l -> y0 / y1 (the accumulators' initial value)
-  auto load_cond = [&](int l, int dil) {
-    const rsrc_t rs_ct = mk_rsrc(a.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
-    const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
-    const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
-    const int f0c = t0 + tp < T ? t0 + tp : T - 1, f1c = t0 + tp + dil < T ? t0 + tp + dil : T - 1;
-    const int vc0 = (lq * 4 * T + f0c) * 4, vc1 = (lq * 4 * T + f1c) * 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int so_g = (32 * wave + 16 * i + r) * rowT, so_f = so_g + C * rowT;
-        y0[i][r] = ldf(rs_ct, vc0, so_g);
-        y0[2 + i][r] = ldf(rs_ct, vc0, so_f);
-        y1[i][r] = ldf(rs_ct, vc1, so_g);
-        y1[2 + i][r] = ldf(rs_ct, vc1, so_f);
-      }
-  };
-
-  // ---- layer 0: stage xs = x + d_0 from HBM (halo included: the whole input exists), x into registers ----------------
-  {
-    const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * L + 0) * C, C * 4);
-    if ((T & 3) == 0) {
-#pragma unroll 3
-      for (int k = 0; k < 6; ++k) {
-        const int idx = tid + 512 * k;
-        const int c = idx / 12, j4 = idx - c * 12;
-        const int t = t0 - HALO + 4 * j4;
-        const bool ok = t >= 0 && t < T;
-        f32x4 v = ldf4(rs_x, ok ? (c * T + t) * 4 : 0, 0);
-        const float d = ldf(rs_dp, c * 4, 0);
-        v += d;
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(xs + c * LDX + 4 * j4) = v;
-      }
-    } else {
-#pragma unroll 4
-      for (int idx = tid; idx < C * LDX; idx += 512) {
-        const int c = idx / LDX, jj = idx - c * LDX;
-        const int t = t0 - HALO + jj;
-        const bool ok = t >= 0 && t < T;
-        const float v = ldf(rs_x, ok ? (c * T + t) * 4 : 0, 0) + ldf(rs_dp, c * 4, 0);
-        xs[idx] = ok ? v : 0.f;
-      }
-    }
-    // x of this lane's 16 accumulator positions -> its stash in zs (read back at GEMM2; rows 32w.. belong to wave w alone)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] = ldf(rs_x, vcol, (32 * wave + acc_row0(r)) * rowT);
-    load_cond(0, 1);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) skipacc[r] = 0.f;
-
-#define STK_STAMP(i)                                                                                              \
-  do {                                                                                                            \
-    if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#pragma unroll 1
-  for (int l = 0; l < L; ++l) {
-    const int dil = 1 << (l % p.cycle);
-    const rsrc_t rs_aw = mk_rsrc(a.apackw + (long long)l * (4 * 2 * C * C), 4 * 2 * C * C * 4);
-    const rsrc_t rs_a2 = mk_rsrc(a.apack2 + (long long)l * (2 * C * C), 2 * C * C * 4);
-    const rsrc_t rs_bo = mk_rsrc(a.bias_out + (long long)l * (2 * C), 2 * C * 4);
-    f32x4 AW[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) AW[k][i] = ldf4(rs_aw, vfrag, sw[i] + k * 1024);
-    __syncthreads();   // (A) xs of layer l is complete: core columns (own x + d_l) and halo columns
-    STK_STAMP(0);
-
-    // ---- GEMM1 as Winograd F(2,3) over the dilated taps (see residual_tile) ---------------------------
-    const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
-    const int tp = ((p16 >> ld) << (ld + 1)) + (p16 & (dil - 1));
-    wino_gemm1<4, 2>(y0, y1, AW, xs, lq * LDX + HALO + tp, dil, rs_aw, vfrag, sw);
-    STK_STAMP(1);
-    // ---- gate: z = sigmoid(gate) * tanh(filter) -> zs (net.py:73-74); first A fragments of GEMM2 fly meanwhile -------
-    f32x4 A2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) A2[k] = ldf4(rs_a2, vfrag, sb_r + k * 1024);
-    // x of this lane's 16 positions comes back from its stash in zs (rows 32w.. are written and read by wave w only — the
-    // stash and, below, this wave's z rows — so no barrier is needed around it)
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc[r] = zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] + ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);   // x + b_out (residual rows)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 32 * wave + 16 * i + 4 * lq + r;
-        zs[row * LDZ + tp] = fast_sigmoid(y0[i][r]) * fast_tanh(y0[2 + i][r]);
-        zs[row * LDZ + tp + dil] = fast_sigmoid(y1[i][r]) * fast_tanh(y1[2 + i][r]);
-      }
-    __syncthreads();   // (B) zs complete; every wave is done reading xs of this layer
-    STK_STAMP(2);
-
-    const float* zrow = zs + lh * LDZ + l31;
-    auto ldbz = [&](int q) {
-      const float* pz = zrow + 8 * q * LDZ;
-      return f32x4{pz[0], pz[2 * LDZ], pz[4 * LDZ], pz[6 * LDZ]};
-    };
-    // ---- GEMM2, residual half: x_new = (x + b + W_res z) / sqrt(2)   (net.py:75-78) ----------------------------------
-    mfma_pipe1<4>(acc, A2, rs_a2, vfrag, sb_r, 0, 32, 31, ldbz);
-    STK_STAMP(3);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) A2[k] = ldf4(rs_a2, vfrag, sb_s + k * 1024);
-    f32x16 accs;   // skip rows
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accs[r] = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
-    const bool more = l + 1 < L;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc[r] / 1.41421356237309504880f;   // x_new: stays in `acc` through the skip half, then goes to the stash
-    if (more) {
-      // next layer's xs core = x_new + d_{l+1} (zero beyond T: the conv pads x + d), and the two 8-frame edges for the neighbours
-      const rsrc_t rs_dn = mk_rsrc(a.dproj + ((long long)tb * L + l + 1) * C, C * 4);
-      float* xcore = xs + (32 * wave + 4 * lh) * LDX + HALO + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        xcore[acc_row0(r) * LDX] = col_ok ? acc[r] + ldf(rs_dn, lh * 16, (32 * wave + acc_row0(r)) * 4) : 0.f;
-      // publish: rows 32w..32w+31 of xs were written by this wave alone, so it reads its two 8-frame edges back (program order
-      // within a wave) as 16-byte pieces: lane = (row, side), 2 x float4 -> 2 write-through (sc1) 16-byte stores
-      float* hx_t = p.hx + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (2 * C * 8);
-      const rsrc_t rs_hx = mk_rsrc(hx_t, 2 * C * 8 * 4);
-      const int erow = 32 * wave + (lane >> 1), eside = lane & 1;
-      const float* ep = xs + erow * LDX + HALO + (eside ? NT - 8 : 0);
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(ep), e1 = *reinterpret_cast<const f32x4*>(ep + 4);
-      const int vh = ((eside ? C * 8 : 0) + erow * 8) * 4;
-      if (!(p.inject && (tile_id & 1))) {   // injected fault: odd tiles never publish, their neighbours consume stale edges
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e0), rs_hx, vh, 0, 16);        // sc1
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, e1), rs_hx, vh + 16, 0, 16);   // sc1
-      }
-    }
-    // ---- GEMM2, skip half (covers the drain of the published edges) ----------------------------------------------------
-    mfma_pipe1<4>(accs, A2, rs_a2, vfrag, sb_s, 0, 32, 31, ldbz);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) skipacc[r] = (l == 0 ? 0.f : skipacc[r]) + accs[r];
-    STK_STAMP(4);
-    if (!more) break;
-
-    // ---- hand-off: publish, then wait for the neighbours' edges of the same layer ----------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-    __syncthreads();   // (C) also: every wave is done reading zs
-    STK_STAMP(5);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zs[(32 * wave + acc_row(r, lh)) * LDZ + l31] = acc[r];   // stash x for the next layer's GEMM2
-    load_cond(l + 1, 1 << ((l + 1) % p.cycle));        // 64 KB per tile, independent of the neighbours: lands while we wait
-    if (tid == 0) {
-      const unsigned want = p.fbase + (unsigned)(l + 1);
-      __hip_atomic_store(p.flags + tile_id, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        if (side == 0 ? !has_left : !has_right) continue;
-        const unsigned* f = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
-        if (p.inject) { atomicAdd(p.status, 1u); continue; }
-        unsigned spins = 0;
-        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
-            atomicAdd(p.status, 1u);
-            break;
-          }
-        }
-      }
-      if (p.stamps) p.stamps[((long long)tile_id * L + l) * 8 + 6] = __builtin_amdgcn_s_memrealtime();   // neighbours' flags seen
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();   // (D)
-    STK_STAMP(7);
-    {
-      // halo columns of the next layer's xs: left = the left neighbour's right edge, right = the right neighbour's left edge
-      const int side = tid >> 8, row = tid & 255;
-      const bool have = side == 0 ? has_left : has_right;
-      const float* src = p.hx + ((long long)((l + 1) & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (2 * C * 8) +
-                         (side == 0 ? C * 8 : 0) + row * 8;
-      f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-      if (have) {
-        v0 = *reinterpret_cast<const f32x4*>(src);
-        v1 = *reinterpret_cast<const f32x4*>(src + 4);
-      }
-      float* dst = xs + row * LDX + (side == 0 ? 0 : HALO + NT);
-      *reinterpret_cast<f32x4*>(dst) = v0;
-      *reinterpret_cast<f32x4*>(dst + 4) = v1;
-    }
-  }
-#undef STK_STAMP
-  // ---- the skip sum / sqrt(L) (net.py:126), stored once ----------------------------------------------------------------
-  if (col_ok) {
-    const int vst = (lh * 4 * T + col) * 4;
-    const float div = sqrtf((float)L);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) stf(skipacc[r] / div, rs_sk, vst, (32 * wave + acc_row0(r)) * rowT);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // sampler: one ancestral step, elementwise over [B][M][T]   (shallow_diffusion_tts.py:134-166)
@@ -1322,12 +1060,11 @@ struct bsg_diffnet {
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   size_t prof_launches = 0;   // layer-equivalents covered by the recorded pairs (L per evaluation)
-  // on-chip stack launch (residual_stack_kernel): edge exchange [2][tiles][2][C][8], flags [tiles] + status word
+  // on-chip stack launches: edge exchange [2][tiles][2][C][8], flags [tiles] + status word
   float* hx = nullptr;
   unsigned* flags = nullptr;
   size_t flags_cap = 0;                // tiles the exchange array and the flags are sized for
   unsigned stack_epoch = 0;
-  int occ_stack = -1;                  // resident workgroups per CU of residual_stack_kernel (-1: not queried)
   int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
   int occ_stack43 = -1;                // the same for residual_stack_f43_kernel
   bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
@@ -1789,16 +1526,6 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
   return BSG_OK;
 }
 
-// The on-chip stack launch (residual_stack_kernel): all L layers of `rows` utterances in one launch.  Opt-in (BSG_STACK=1; 2: also for
-// launches of at most one workgroup per CU): measured 107 us per layer at B=16, T=1000 against 101.9 us for two chains of per-layer
-// launches (DESIGN.md section 9 has the phase timeline and what would have to change).
-static int stack_env() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("BSG_STACK"); v = e ? atoi(e) : 0; }
-  return v;
-}
-static constexpr size_t kStackLds = (size_t)C * (32 + 2 * HALO + 32) * sizeof(float);   // xs + zs = 80 KB: two workgroups fill a CU's LDS
-
 // rows per launch group (0: the stack launch is not used for this shape).  A tile row is ceil(T/32) workgroups that wait for
 // each other, and every workgroup of a launch must be resident: at most occ x CUs workgroups, whole rows only.  It pays when a
 // launch has more workgroups than CUs (two per CU overlap each other's waits); smaller launches keep the channel-split kernels.
@@ -1851,31 +1578,13 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
     }
     if (wino_env() == 43) return 0;
   }
-  if (!stack_env() || h->compute != BSG_COMPUTE_F32 || !use_wino() || h->split_off || !h->num_cus || !h->hx) return 0;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cap);
-  if (cap != hipStreamCaptureStatusNone) return 0;   // a replay would reuse the launch epoch of the flags
-  if (h->occ_stack < 0) {
-    int o = 0;
-    if (hipFuncSetAttribute((const void*)residual_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStackLds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_kernel, 512, kStackLds) != hipSuccess)
-      o = 0;
-    h->occ_stack = o > 2 ? 2 : o;
-  }
-  const int tpr = cdiv(T, 32);
-  const long long slots = (long long)h->occ_stack * h->num_cus;
-  if (h->occ_stack < 2 || tpr > slots) return 0;
-  const int env = stack_env();
-  if ((long long)B * tpr <= h->num_cus && env != 2) return 0;   // BSG_STACK=2: also for launches of at most one workgroup per CU
-  int rows = (int)(slots / tpr);
-  if (rows > B) rows = B;
-  return rows;
+  return 0;
 }
 
 static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
                         unsigned long long* stamps = nullptr, const TailArgs* tail = nullptr) {
   const bool f43 = h->stack_is_f43, h2 = h->stack_is_h2;   // the decision of the stack_rows() call that returned rows_per_launch
-  const int tpr = cdiv(T, f43 || h2 ? 64 : 32);
+  const int tpr = cdiv(T, 64);
   const size_t bt = (size_t)h->B * T;   // bound batch: per-layer stride of the conditioner term
   for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
     const int nb = B - r0 < rows_per_launch ? B - r0 : rows_per_launch;
@@ -1914,12 +1623,12 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       p.apackw43 = h->apackw43;
       TRY(launch_residual_stack_f43(p, st));
     } else {
-      hipLaunchKernelGGL(residual_stack_kernel, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), kStackLds, st, p);
-      BSG_LAUNCH_CHECK();
+      set_error("stack launch: no launch form selected");
+      return BSG_ESTATE;
     }
   }
   BSG_REQUIRE(!tail || h2, "stack launch: a fused tail needs the split-fp16 form");
-  h->last_path = h2 ? (tail ? "stack_h2_tail" : "stack_h2") : f43 ? "stack_f43" : "stack";
+  h->last_path = h2 ? (tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
   return BSG_OK;
 }
 

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) 
 
 // ------------------------------------------------------------------------------------------------
 // All L layers of the bf16-operand configuration in ONE launch, residual stream on chip (the bf16 sibling of
-// residual_stack_kernel, diffnet.hip — same hand-off protocol, see there).  The per-layer kernel above is bound by bytes and by
+// the fp32 stack launches — same hand-off protocol, described in diffnet.hip).  The per-layer kernel above is bound by bytes and by
 // the latency of its weight stream; here
 //   * x (fp32) lives in 32 registers per lane in accumulator layout — it IS the initial value of GEMM2's residual rows — and as the
 //     bf16 image xs = bf16(x + d_l) in LDS; it is read from HBM once (layer 0) and never written back;

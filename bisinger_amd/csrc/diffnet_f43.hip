@@ -464,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void residual_layer_f43_kernel(ResArgs a) {
 }
 #undef F43_STAMP
 // ------------------------------------------------------------------------------------------------
-// All L layers of one 64-frame tile in ONE launch, residual stream on chip (the F(4,3) sibling of residual_stack_kernel, diffnet.hip;
+// All L layers of one 64-frame tile in ONE launch, residual stream on chip (the fp32-matrix-pipe sibling of diffnet_h2.hip;
 // same hand-off protocol — write-through stores, drain, barrier, flag with the launch epoch, bounded poll, sc1 loads — see there).
 // One workgroup per CU; every tile of the launch must be resident (the host checks).  Per layer the per-layer kernel above pays the
 // staging of x (HBM round trip with the matrix pipe idle: one workgroup per CU has nothing to overlap it with), the store of x, and

@@ -1,7 +1,6 @@
 // fp32 DiffNet residual stack on the 16-bit matrix pipe: every fp32 operand split EXACTLY into two fp16 terms.
 //
-// Same contract, tensors and results (to fp32 rounding) as the fp32 stack launches (diffnet.hip residual_stack_kernel,
-// diffnet_f43.hip; reference semantics /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130).  gfx950 multiplies fp32
+// Same contract, tensors and results (to fp32 rounding) as the fp32-matrix-pipe stack launch (diffnet_f43.hip; reference semantics /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130).  gfx950 multiplies fp32
 // operands at 256 FLOP/clk/CU (v_mfma_f32_32x32x2_f32) and fp16 operands at 4096 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  An
 // fp32 value a is hi + lo with hi = fp16(a), lo = fp16(a - hi): 11 + 11 significand bits plus the sign of lo cover the 24 of fp32, so
 // |a - hi - lo| <= 2^-24 |a| (half an fp32 ulp) as long as lo is a normal fp16.  A product of two such values is

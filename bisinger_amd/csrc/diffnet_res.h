@@ -33,7 +33,7 @@ struct ResArgs {
 };
 
 // arguments of the stack launches (all L layers of a group of rows in one launch, residual stream on chip):
-// residual_stack_kernel (diffnet.hip, fp32) and residual_stack_bf16_kernel (diffnet_bf16.hip)
+// residual_stack_h2_kernel (diffnet_h2.hip), residual_stack_f43_kernel (diffnet_f43.hip), residual_stack_bf16_kernel (diffnet_bf16.hip)
 struct StackArgs {
   const float* x_in;      // [B][C][T] in-projected x of this launch's rows
   float* skip;            // [B][C][T] output: skip sum / sqrt(L)

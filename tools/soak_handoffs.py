@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Soak test of the launches that hand data between workgroups (channel-split launch at small batch; the opt-in stack
-launch with BSG_STACK=1): repeated 100-step sampler runs must be bit-identical and report zero hand-off time-outs."""
+"""Soak test of the launches that hand data between workgroups (channel-split launches at small batch; the stack
+launches from B = 5): repeated 100-step sampler runs must be bit-identical and report zero hand-off time-outs."""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of the on-chip stack launch (residual_stack_kernel) from its in-kernel s_memrealtime stamps.
+"""Phase timeline of the on-chip stack launches (split-fp16, F(4,3), bf16) from its in-kernel s_memrealtime stamps.
     python tools/stack_stamps.py [B T]      (default 16 1000)
 Prints, averaged over tiles and layers, the duration of each phase of a layer, the layer period, and how the start of
 layer 10 spreads over the tiles (are the two workgroups of a CU in phase?)."""
