@@ -586,9 +586,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
       const f32x16& yf = ct ? yf1 : yf0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float z0 = gate1(yg[4 * g], yf[4 * g]), z1 = gate1(yg[4 * g + 1], yf[4 * g + 1]);
-        const float z2 = gate1(yg[4 * g + 2], yf[4 * g + 2]), z3 = gate1(yg[4 * g + 3], yf[4 * g + 3]);
-        *reinterpret_cast<u32x2*>(zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) = u32x2{pack2(z0, z1), pack2(z2, z3)};
+        const f32x2 z01 = gate2_scaled(f32x2{yg[4 * g], yg[4 * g + 1]}, f32x2{yf[4 * g], yf[4 * g + 1]}, -1.44269504088896340736f, -2.88539008177792681472f, 15.0f, 1.0f);
+        const f32x2 z23 = gate2_scaled(f32x2{yg[4 * g + 2], yg[4 * g + 3]}, f32x2{yf[4 * g + 2], yf[4 * g + 3]}, -1.44269504088896340736f, -2.88539008177792681472f, 15.0f, 1.0f);
+        *reinterpret_cast<u32x2*>(zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) = u32x2{pack2(z01[0], z01[1]), pack2(z23[0], z23[1])};
       }
     }
     // residual rows start from x + b_out, skip rows from b_out (the accumulators of GEMM1 are free now)
@@ -613,8 +613,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
     if (l + 1 < L) prefetch_a1(l + 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      xr[0][r] = yg0[r] / 1.41421356237309504880f;   // (x + residual) / sqrt(2), net.py:78 (a product instead measured no faster: this
-      xr[1][r] = yg1[r] / 1.41421356237309504880f;   // phase waits for the SIMD's other wave to finish its MFMAs)
+      xr[0][r] = yg0[r] * 0.70710678118654752440f;   // (x + residual) / sqrt(2), net.py:78, as a product (the IEEE division is ~10 instructions
+      xr[1][r] = yg1[r] * 0.70710678118654752440f;   // per element)
       sk[0][r] += yf0[r];
       sk[1][r] += yf1[r];
     }

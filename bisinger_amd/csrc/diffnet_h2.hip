@@ -102,22 +102,6 @@ __device__ __forceinline__ HiLo split2(float a, float b) {
               __builtin_bit_cast(unsigned, f16x2{(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)})};
 }
 
-// 2^10 sigmoid(g) tanh(f) for two elements from the RAW GEMM1 accumulators (g, f carry the scale s1): the un-scaling is folded into the
-// exponents' arguments and the 2^10 into the numerator, and everything but the exponentials / reciprocals is packed fp32 math
-// (v_pk_mul / v_pk_add / v_pk_fma: two elements per instruction).  (1 - e^{-2f}) / ((1 + e^{-g}) (1 + e^{-2f})) as gate1 (diffnet_res.h);
-// cg = -log2(e) / s1, cf = -2 log2(e) / s1, lim = 15 s1 (tanh = +-1 to 1e-13 beyond |f| = 15)
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ f32x2 gate2_scaled(f32x2 g, f32x2 f, float cg, float cf, float lim) {
-  f[0] = fminf(fmaxf(f[0], -lim), lim);
-  f[1] = fminf(fmaxf(f[1], -lim), lim);
-  const f32x2 a = g * cg, b = f * cf;
-  const f32x2 eg = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-  const f32x2 ef = f32x2{__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
-  const f32x2 den = (eg + 1.0f) * (ef + 1.0f);
-  const f32x2 r = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  return (ZSCALE - ZSCALE * ef) * r;
-}
-
 #define BSG_MFMA_H(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, ACC, 0, 0, 0)
 
 // i-th executed k-step -> k-step index: GEMM1 (ROT = 16, 48 k-steps, tap-major) starts with the CENTRE tap, whose B operand is the
@@ -440,8 +424,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       const f32x16& yf = ct ? yf1 : yf0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x2 z01 = gate2_scaled(f32x2{yg[4 * g], yg[4 * g + 1]}, f32x2{yf[4 * g], yf[4 * g + 1]}, gcg, gcf, glim);
-        const f32x2 z23 = gate2_scaled(f32x2{yg[4 * g + 2], yg[4 * g + 3]}, f32x2{yf[4 * g + 2], yf[4 * g + 3]}, gcg, gcf, glim);
+        const f32x2 z01 = gate2_scaled(f32x2{yg[4 * g], yg[4 * g + 1]}, f32x2{yf[4 * g], yf[4 * g + 1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
+        const f32x2 z23 = gate2_scaled(f32x2{yg[4 * g + 2], yg[4 * g + 3]}, f32x2{yf[4 * g + 2], yf[4 * g + 3]}, gcg, gcf, glim, ZSCALE);
         const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
         const u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
         char* dst = zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;

@@ -105,6 +105,20 @@ __device__ __forceinline__ float gate1(float g, float f) {
   return (1.0f - ef) * __frcp_rn((1.0f + eg) * (1.0f + ef));
 }
 
+// gate1 for two elements on packed fp32 math (v_pk_mul / v_pk_add / v_pk_fma: two elements per instruction; only the exponentials and the
+// reciprocals are per element): `num` x sigmoid(g / s) tanh(f / s) from accumulators that carry a scale s — cg = -log2(e) / s,
+// cf = -2 log2(e) / s, lim = 15 s; s = 1, num = 1 is gate1 itself
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 gate2_scaled(f32x2 g, f32x2 f, float cg, float cf, float lim, float num) {
+  f[0] = fminf(fmaxf(f[0], -lim), lim);
+  f[1] = fminf(fmaxf(f[1], -lim), lim);
+  const f32x2 a = g * cg, b = f * cf;
+  const f32x2 eg = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const f32x2 ef = f32x2{__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
+  const f32x2 den = (eg + 1.0f) * (ef + 1.0f);
+  const f32x2 r = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  return (num - num * ef) * r;
+}
 
 // Buffer (SRSRC) addressing: one wave-uniform 128-bit descriptor per tensor, a per-lane 32-bit byte offset that
 // is computed once, and a wave-uniform SGPR offset per access — the 32 row-strided loads of an accumulator tile
