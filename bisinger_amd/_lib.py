@@ -101,6 +101,7 @@ _SIGS = {
     'bsg_gemm_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),
     'bsg_gemm_set_split': (c_int32, [c_int32]),
+    'bsg_diffnet_set_h2': (c_int32, [c_void_p, c_int32]),
     'bsg_gemm_range_events': (c_int32, [POINTER(c_int32), c_int32, c_void_p]),
 }
 

@@ -1069,7 +1069,9 @@ struct bsg_diffnet {
   int occ_stack43 = -1;                // the same for residual_stack_f43_kernel
   bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
   bool stack_is_h2 = false;            // ... the split-fp16 stack launch (diffnet_h2.hip)
-  int occ_stack_h2 = -1;               // resident workgroups per CU of residual_stack_h2_kernel (-1: not queried)
+  bool h2_off = false;                 // bsg_diffnet_set_h2(h, 0): this handle multiplies on the fp32 matrix pipe only
+  int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
+  int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1534,24 +1536,29 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
   h->stack_is_h2 = false;
   {
     // split-fp16 form (diffnet_h2.hip): fp32 operands as hi + lo fp16 terms on the 16-bit matrix pipe; 64-frame tiles, one workgroup per
-    // CU, whole rows per launch group.  BSG_H2=0: off; 2: for any shape that is resident (tests); default 1: launch groups >= 30 % full
+    // CU, whole rows per launch group, every batch size.  BSG_H2=0 / bsg_diffnet_set_h2(h, 0): off (the kernels of the fp32 matrix pipe)
     static int envh2 = -1;
     if (envh2 < 0) { const char* e = getenv("BSG_H2"); envh2 = e ? atoi(e) : 1; }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (st) (void)hipStreamIsCapturing(st, &cap);
-    if (envh2 && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && h->apack1s && cap == hipStreamCaptureStatusNone) {
-      if (h->occ_stack_h2 < 0) h->occ_stack_h2 = stack_h2_occupancy() >= 1 ? 1 : 0;
-      const int tpr = cdiv(T, 64);
-      if (h->occ_stack_h2 >= 1 && tpr <= h->num_cus) {
+    if (envh2 && !h->h2_off && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && h->apack1s && cap == hipStreamCaptureStatusNone) {
+      // tile width: 32 frames (one column tile per workgroup) while those tiles fit ONE launch group, else 64 frames (two column tiles:
+      // half the weight stream per frame).  ms per 100-step pass at T = 1000 on one box (tools/bench_small.py), 32-frame / 64-frame /
+      // fp32-pipe kernels (BSG_H2=0):  B=1 55 / 70 / 60,  B=2 53 / 70 / 64,  B=4 52 / 70 / 84,  B=6 56 / 74 / 119,  B=8 69 / 76 / 132,
+      // B=10 115 / 80 / 187,  B=12 113 / 87 / 198,  B=16 134 / 103 / 200 — so the launch is taken for every batch size (BSG_H2_NCT=1 / 2
+      // forces a width)
+      static int env_nct = -1;
+      if (env_nct < 0) { const char* e = getenv("BSG_H2_NCT"); env_nct = e ? atoi(e) : 0; }
+      int nct = (long long)B * cdiv(T, 32) > h->num_cus ? 2 : 1;
+      if (env_nct == 1 || env_nct == 2) nct = env_nct;
+      if (h->occ_stack_h2[nct] < 0) h->occ_stack_h2[nct] = stack_h2_occupancy(nct) >= 1 ? 1 : 0;
+      const int tpr = cdiv(T, 32 * nct);
+      if (h->occ_stack_h2[nct] >= 1 && tpr <= h->num_cus) {
         int rows = h->num_cus / tpr;
         if (rows > B) rows = B;
-        const int groups = cdiv(B, rows);
-        // measured per 100-step pass at T = 1000 (tools/bench_small.py, BSG_H2=2 against 0): B=4 88 vs 84 ms, B=6 92 vs 120, B=8 96 vs 133,
-        // B=12 105 vs 200, B=16 120 vs 203 on one box: taken when the launch groups fill >= 30 % of the CUs (B >= 5 at T = 1000)
-        if (envh2 == 2 || (long long)B * tpr * 10 >= (long long)groups * h->num_cus * 3) {
-          h->stack_is_h2 = true;
-          return rows;
-        }
+        h->stack_is_h2 = true;
+        h->stack_nct = nct;
+        return rows;
       }
     }
   }
@@ -1584,7 +1591,8 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
 static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
                         unsigned long long* stamps = nullptr, const TailArgs* tail = nullptr) {
   const bool f43 = h->stack_is_f43, h2 = h->stack_is_h2;   // the decision of the stack_rows() call that returned rows_per_launch
-  const int tpr = cdiv(T, 64);
+  const int nct = h2 ? h->stack_nct : 2;
+  const int tpr = cdiv(T, 32 * nct);
   const size_t bt = (size_t)h->B * T;   // bound batch: per-layer stride of the conditioner term
   for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
     const int nb = B - r0 < rows_per_launch ? B - r0 : rows_per_launch;
@@ -1615,9 +1623,9 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
         if (a.h1) a.h1 += mo;
         if (a.h2) a.h2 += mo;
         if (a.h3) a.h3 += mo;
-        TRY(launch_residual_stack_h2(p, &a, st));
+        TRY(launch_residual_stack_h2(p, &a, st, nct));
       } else {
-        TRY(launch_residual_stack_h2(p, nullptr, st));
+        TRY(launch_residual_stack_h2(p, nullptr, st, nct));
       }
     } else if (f43) {
       p.apackw43 = h->apackw43;
@@ -2025,6 +2033,12 @@ extern "C" int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, i
 extern "C" int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable) {
   BSG_REQUIRE(h, "diffnet_set_split: null handle");
   h->split_off = enable == 0;
+  return BSG_OK;
+}
+
+extern "C" int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable) {
+  BSG_REQUIRE(h, "diffnet_set_h2: null handle");
+  h->h2_off = enable == 0;
   return BSG_OK;
 }
 

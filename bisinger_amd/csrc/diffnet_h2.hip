@@ -33,16 +33,16 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
-constexpr int NT = 64;                    // frames per workgroup
+// NCT = column tiles of 32 frames per workgroup: 2 (64-frame tiles, the form described above) or 1 (32-frame tiles: twice the tiles for
+// batches that would leave CUs without one — half the matrix work per tile against the same weight stream)
 constexpr int ROWB = 2 * C + 16;          // LDS image row: 256 fp16 + 16 B pad = 528 B (132 dwords = 4 mod 64)
-constexpr int XROWS = NT + 2 * HALO;      // 80
-constexpr int XP = XROWS * ROWB;          // bytes per plane of the image: 42,240
-constexpr int ZP = NT * ROWB;             // bytes per plane of z: 33,792
+constexpr int h2_xp(int nct) { return (32 * nct + 2 * HALO) * ROWB; }   // bytes per plane of the image: 42,240 (NCT = 2)
+constexpr int h2_zp(int nct) { return 32 * nct * ROWB; }                // bytes per plane of z: 33,792 (NCT = 2)
 constexpr int NSH = 4;                    // weight ring (k-steps)
 constexpr int PLB = 16 * 1024;            // bytes per plane of a k-step slab (16 row tiles x 1 KB)
 constexpr int KSB2 = 2 * PLB;             // bytes per k-step: hi slab, lo slab
 constexpr float ZSCALE = 1024.0f;         // z in (-1, 1) is split as z x 2^10
-constexpr size_t H2_LDS = (size_t)2 * XP + 2 * ZP + 3 * C * sizeof(float);
+constexpr size_t h2_lds(int nct) { return (size_t)2 * h2_xp(nct) + 2 * h2_zp(nct) + 3 * C * sizeof(float); }
 
 // scale table, per layer: [0] s1 (GEMM1 weights x s1), [1] 1 / s1, [2] s2 x 2^10 (GEMM2 weights x s2, z x 2^10), [3] its reciprocal
 __global__ void h2_absmax_kernel(const float* __restrict__ src, long long n, unsigned* __restrict__ out) {
@@ -118,10 +118,11 @@ __device__ __forceinline__ int kmap(int i) {
 // 1 hi, lo) are read before the MFMAs of the current one.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0:
 // never): the hand-off with the neighbours sits there, under the centre tap's MFMAs; the ring keeps prefetching across it.
 // FAIRB: the two waves of a SIMD take turns at issue priority (see f43_gemm1, diffnet_f43.hip).
-template <int ROT, bool FAIRB, typename LDB, typename MID>
-__device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
+template <int ROT, bool FAIRB, int NCT, typename LDB, typename MID>
+__device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT], f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
                                              int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
-  f16x8 B[2][4];
+  // c0[ct] / c1[ct]: row tile 0 / 1 x column tile ct.  B[..][2 ct] = hi, [2 ct + 1] = lo of column tile ct
+  f16x8 B[2][2 * NCT];
   ldb(kmap<ROT>(0), B[0]);
   const int last = n_ks - 1;
 #pragma unroll 1
@@ -140,19 +141,22 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16& c00, f32x16& c10, f32x16& c
       const int in = ks + s + 1 <= last ? ks + s + 1 : last;
       ldb(kmap<ROT>(in), B[(s + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      const f16x8(&Bc)[4] = B[s & 1];
-      BSG_MFMA_H(c00, A[s][0], Bc[0]);
-      BSG_MFMA_H(c10, A[s][2], Bc[0]);
-      BSG_MFMA_H(c01, A[s][0], Bc[2]);
-      BSG_MFMA_H(c11, A[s][2], Bc[2]);
-      BSG_MFMA_H(c00, A[s][0], Bc[1]);
-      BSG_MFMA_H(c10, A[s][2], Bc[1]);
-      BSG_MFMA_H(c01, A[s][0], Bc[3]);
-      BSG_MFMA_H(c11, A[s][2], Bc[3]);
-      BSG_MFMA_H(c00, A[s][1], Bc[0]);
-      BSG_MFMA_H(c10, A[s][3], Bc[0]);
-      BSG_MFMA_H(c01, A[s][1], Bc[2]);
-      BSG_MFMA_H(c11, A[s][3], Bc[2]);
+      const f16x8(&Bc)[2 * NCT] = B[s & 1];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // hi hi
+        BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct]);
+        BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // hi lo
+        BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct + 1]);
+        BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct + 1]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // lo hi
+        BSG_MFMA_H(c0[ct], A[s][1], Bc[2 * ct]);
+        BSG_MFMA_H(c1[ct], A[s][3], Bc[2 * ct]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
       const int kr = kmap<ROT>(ir);
@@ -200,11 +204,12 @@ __device__ __forceinline__ void tail_gemm_h2(f32x16 (&c)[NC], rsrc_t rs, int vfr
 // TAIL + step_tail_kernel, diffnet.hip; net.py:126-129, shallow_diffusion_tts.py:149-201): skip projection + ReLU, output projection,
 // sampler update of x (DDPM ancestral or PLMS), and the next evaluation's input projection — the same split-fp16 products, biases
 // and sampler arithmetic (diffnet_tail.h) — so that a step is ONE launch and neither the skip sum nor the hidden tile touch HBM.
-template <bool FAIRB, bool TAIL>
+template <bool FAIRB, bool TAIL, int NCT>
 __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, TailArgs a) {
+  constexpr int NT = 32 * NCT, XP = h2_xp(NCT), ZP = h2_zp(NCT);   // frames per workgroup; bytes per plane of the image / of z
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* xs = lds_raw;                  // [2 planes][80 frames][528 B]: hi / lo of x + d_l, frames t0-8 .. t0+71
-  char* zs = lds_raw + 2 * XP;         // [2 planes][64 frames][528 B]: hi / lo of 2^10 x gated activation
+  char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation
   float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]: d_{l+1} per channel, fetched a layer ahead
   float* btab = dtab + C;                                              // [512]: output-projection bias of the current layer
 
@@ -223,10 +228,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   const unsigned plane = (unsigned)C * T * 4;
   const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
   const int rowT = T * 4, vfrag = lane * 16;
-  int vcol[2], vst[2];
-  bool col_ok[2];
+  int vcol[NCT], vst[NCT];
+  bool col_ok[NCT];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < NCT; ++ct) {
     const int col = t0 + 32 * ct + l31;
     col_ok[ct] = col < T;
     vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
@@ -235,9 +240,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   const int sa_g = wave * 1024, sa_f = (8 + wave) * 1024;   // gate / filter row tile inside a plane of a k-step slab
   const int sb_r = wave * 1024, sb_s = (8 + wave) * 1024;   // residual / skip row tile
 
-  float xr[2][16];        // x, accumulator layout: registers 4g..4g+3 = channels 32w + 8g + 4 lh + (0..3) of frame 32 ct + l31
-  float sk[2][16];        // running skip sum (fp32), same layout (skip rows C + 32w + ..)
-  f32x16 yg0, yf0, yg1, yf1;   // GEMM1 accumulators; they start from the conditioner term x s1
+  float xr[NCT][16];      // x, accumulator layout: registers 4g..4g+3 = channels 32w + 8g + 4 lh + (0..3) of frame 32 ct + l31
+  float sk[NCT][16];      // running skip sum (fp32), same layout (skip rows C + 32w + ..)
+  f32x16 yg[NCT], yf[NCT];     // GEMM1 accumulators (gate / filter rows x column tile); they start from the conditioner term x s1
   // range guard: a value whose hi term would leave the fp16 range (or is not finite) is reported through the hand-off status word, and
   // the host repeats the call on the fp32 matrix pipe (DiffNet.guarded) — the split never returns a clipped result silently.  `worst`
   // collects the largest |value| bit pattern a phase splits (NaN and inf order above every finite float); the flag is wave-uniform
@@ -254,10 +259,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int so = (32 * wave + acc_row0(r)) * rowT;
-      yg0[r] = ldf(rs_ct, vcol[0], so);
-      yf0[r] = ldf(rs_ct, vcol[0], so + C * rowT);
-      yg1[r] = ldf(rs_ct, vcol[1], so);
-      yf1[r] = ldf(rs_ct, vcol[1], so + C * rowT);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        yg[ct][r] = ldf(rs_ct, vcol[ct], so);
+        yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
+      }
     }
   };
   // image core (frames t0 .. t0+63, this wave's 32 channels) = hi / lo of x + d_l, zero beyond T (the conv pads x + d)
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv[r] = dtab[32 * wave + acc_row(r, lh)];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float v0 = xr[ct][4 * g] + dv[4 * g], v1 = xr[ct][4 * g + 1] + dv[4 * g + 1];
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 
   // ---- layer 0: x from HBM (the whole input exists, halo included) ------------------------------------------------------
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       xr[ct][r] = ldf(rs_x, vcol[ct], (32 * wave + acc_row0(r)) * rowT);
@@ -345,20 +351,23 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     const float bnext = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
     // GEMM1 accumulates (conditioner term + W x) x s1: the requested term is scaled on arrival (its first use)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { yg0[r] *= s1; yf0[r] *= s1; yg1[r] *= s1; yf1[r] *= s1; }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) { yg[ct][r] *= s1; yf[ct][r] *= s1; }
     if (l == 0) __syncthreads();   // layer 0: the staged image (core + halo rows); later layers: barrier (C) below covers the core rows
     STK_STAMP(0);
     // ---- GEMM1: 48 k-steps.  The centre tap (16 k-steps) reads the tile's own frames only, so it runs while the neighbours'
     // edges of this layer are still in flight; the wait for them, and the copy of the halo rows, sit behind it (mid) -------------
     {
       const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
+      auto ldb = [&](int ks, f16x8 (&Bf)[2 * NCT]) {
         const int tap = ks >> 4, kc = ks & 15;
         const char* q = xb + ((tap - 1) * dil) * ROWB + kc * 32;
-        Bf[0] = *reinterpret_cast<const f16x8*>(q);
-        Bf[1] = *reinterpret_cast<const f16x8*>(q + XP);
-        Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
-        Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + XP);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB);
+          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB + XP);
+        }
       };
       auto mid = [&]() {
         if (l == 0) return;   // layer 0 staged its halo rows from HBM
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         __syncthreads();   // (A) halo rows in place
         STK_STAMP(2);
       };
-      mfma_pipe_h2<16, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
+      mfma_pipe_h2<16, FAIRB, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -419,13 +428,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     const float rs2 = inv2 * 0.70710678118654752440f;
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const f32x16& yg = ct ? yg1 : yg0;
-      const f32x16& yf = ct ? yf1 : yf0;
+    for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x2 z01 = gate2_scaled(f32x2{yg[4 * g], yg[4 * g + 1]}, f32x2{yf[4 * g], yf[4 * g + 1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
-        const f32x2 z23 = gate2_scaled(f32x2{yg[4 * g + 2], yg[4 * g + 3]}, f32x2{yf[4 * g + 2], yf[4 * g + 3]}, gcg, gcf, glim, ZSCALE);
+        const f32x2 z01 = gate2_scaled(f32x2{yg[ct][4 * g], yg[ct][4 * g + 1]}, f32x2{yf[ct][4 * g], yf[ct][4 * g + 1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
+        const f32x2 z23 = gate2_scaled(f32x2{yg[ct][4 * g + 2], yg[ct][4 * g + 3]}, f32x2{yf[ct][4 * g + 2], yf[ct][4 * g + 3]}, gcg, gcf, glim, ZSCALE);
         const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
         const u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
         char* dst = zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
@@ -437,10 +444,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float br = btab[32 * wave + acc_row(r, lh)], bs = btab[C + 32 * wave + acc_row(r, lh)];
-      yg0[r] = (xr[0][r] + br) * s2;
-      yg1[r] = (xr[1][r] + br) * s2;
-      yf0[r] = bs * s2;
-      yf1[r] = bs * s2;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        yg[ct][r] = (xr[ct][r] + br) * s2;
+        yf[ct][r] = bs * s2;
+      }
     }
     __syncthreads();   // (B) zs complete; every wave is done reading xs and this layer's biases
     btab[tid] = bnext;
@@ -448,23 +456,25 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows -----------------------------------------------------------
     {
       const char* zb = zs + l31 * ROWB + lh * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
+      auto ldb = [&](int ks, f16x8 (&Bf)[2 * NCT]) {
         const char* q = zb + ks * 32;
-        Bf[0] = *reinterpret_cast<const f16x8*>(q);
-        Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
-        Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
-        Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + ZP);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB);
+          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB + ZP);
+        }
       };
-      mfma_pipe_h2<0, FAIRB>(yg0, yf0, yg1, yf1, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
+      mfma_pipe_h2<0, FAIRB, NCT>(yg, yf, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (l + 1 < L) prefetch_a1(l + 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      xr[0][r] = yg0[r] * rs2;   // (x + residual) / sqrt(2), net.py:78: un-scaling and 1 / sqrt(2) in one factor (a product: the IEEE
-      xr[1][r] = yg1[r] * rs2;   // division is ~10 instructions per element, 32 elements per lane and layer)
-      sk[0][r] += yf0[r] * inv2;
-      sk[1][r] += yf1[r] * inv2;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        xr[ct][r] = yg[ct][r] * rs2;   // (x + residual) / sqrt(2), net.py:78: un-scaling and 1 / sqrt(2) in one factor (a product: the IEEE
+        sk[ct][r] += yf[ct][r] * inv2; // division is ~10 instructions per element)
+      }
     }
     STK_STAMP(5);
     if (l + 1 == L) break;
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
     const float rdiv = 1.0f / sqrtf((float)L);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
       if (col_ok[ct]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) stf(sk[ct][r] * rdiv, rs_sk, vst[ct], (32 * wave + acc_row0(r)) * rowT);
@@ -518,12 +528,12 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       const float rdiv = 1.0f / sqrtf((float)L);
       unsigned worst = 0;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) worst = max(worst, absbits(sk[ct][r]));   // |s| <= |skip sum|
       range_check(worst);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const HiLo s0 = split2(sk[ct][4 * g] * rdiv, sk[ct][4 * g + 1] * rdiv), s1_ = split2(sk[ct][4 * g + 2] * rdiv, sk[ct][4 * g + 3] * rdiv);
@@ -533,33 +543,36 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         }
     }
     const char* xcore = xs + (HALO + l31) * ROWB + lh * 16;
-    auto ldb_x2 = [&](int ks, f16x8 (&Bf)[4]) {   // both column tiles of the image rows
+    auto ldb_x2 = [&](int ks, f16x8 (&Bf)[2 * NCT]) {   // every column tile of the image rows
       const char* q = xcore + ks * 32;
-      Bf[0] = *reinterpret_cast<const f16x8*>(q);
-      Bf[1] = *reinterpret_cast<const f16x8*>(q + XP);
-      Bf[2] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB);
-      Bf[3] = *reinterpret_cast<const f16x8*>(q + 32 * ROWB + XP);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        Bf[2 * ct] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB);
+        Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB + XP);
+      }
     };
     // ---- h = relu(W_skip s + b) -> zs (hi / lo) -----------------------------------------------------------------------------------
     {
       const rsrc_t rs_ws = mk_rsrc(a.ws_s, 2 * C * C * 2);
       const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
       const float sc = tsc[0], inv = tsc[1];
-      f32x16 hc[2];
+      f32x16 hc[NCT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hc[0][r] = hc[1][r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) hc[ct][r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
       __syncthreads();   // (T1) s complete; every wave is done with GEMM2 of the last layer (zs is free)
-      tail_gemm_h2<2, 16>(hc, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
+      tail_gemm_h2<NCT, 16>(hc, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
       {
         unsigned worst = 0;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
           for (int r = 0; r < 16; ++r) worst = max(worst, absbits(hc[ct][r] * inv));
         range_check(worst);
       }
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const HiLo s0 = split2(fmaxf(hc[ct][4 * g] * inv, 0.f), fmaxf(hc[ct][4 * g + 1] * inv, 0.f));
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     }
     __syncthreads();   // (T2) h complete; every wave is done reading s
     // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins x 2 column tiles: waves 0..5 ----
-    if (wave < 6) {
+    if (wave < 3 * NCT) {
       const int rt = wave % 3, ct2 = wave / 3;
       const int col = t0 + 32 * ct2 + l31;
       const bool cok = col < T;
@@ -656,14 +669,16 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       const rsrc_t rs_wi = mk_rsrc(a.wi_s, 2 * C * 96 * 2);
       const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
       const float sc = tsc[4], inv = tsc[5];
-      f32x16 hc[2];
+      f32x16 hc[NCT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hc[0][r] = hc[1][r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) hc[ct][r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
       __syncthreads();   // (T3) the updated x tile is complete
-      tail_gemm_h2<2, 6>(hc, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
+      tail_gemm_h2<NCT, 6>(hc, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x2);
       const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, plane);
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < NCT; ++ct)
         if (col_ok[ct]) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) stf(fmaxf(hc[ct][r] * inv, 0.f), rs_xa, vst[ct], (32 * wave + acc_row0(r)) * rowT);
@@ -675,33 +690,44 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 
 }  // namespace
 
-int stack_h2_occupancy() {
+template <int NCT>
+static int h2_occupancy() {
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H2_LDS) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_h2_kernel<true, true>, 512, H2_LDS) != hipSuccess)
+  const int lds = (int)h2_lds(NCT);
+  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_h2_kernel<true, true, NCT>, 512, h2_lds(NCT)) != hipSuccess)
     return 0;
   return o;
 }
+// resident workgroups per CU (0 on error) of the form with `nct` column tiles of 32 frames per workgroup (1 or 2)
+int stack_h2_occupancy(int nct) { return nct == 1 ? h2_occupancy<1>() : h2_occupancy<2>(); }
 
-// tail == nullptr: the residual stack only (skip sum to p.skip); else the sampler step's tail runs in the same launch (TailArgs of THIS
-// launch's rows: x, noise, xa_next, history pointers and quad_row0 already offset to its first row)
-int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
-  static int fair = -1;
-  if (fair < 0) { const char* e = getenv("BSG_H2_FAIR"); fair = e ? atoi(e) : 1; }
+template <int NCT>
+static int h2_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st, int fair) {
   const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
   const TailArgs a = tail ? *tail : TailArgs{};
+  const size_t lds = h2_lds(NCT);
   if (tail) {
-    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, true>), grid, block, H2_LDS, st, p, a);
-    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, true>), grid, block, H2_LDS, st, p, a);
+    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, true, NCT>), grid, block, lds, st, p, a);
+    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, true, NCT>), grid, block, lds, st, p, a);
   } else {
-    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, false>), grid, block, H2_LDS, st, p, a);
-    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, false>), grid, block, H2_LDS, st, p, a);
+    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, false, NCT>), grid, block, lds, st, p, a);
+    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, false, NCT>), grid, block, lds, st, p, a);
   }
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+
+// tail == nullptr: the residual stack only (skip sum to p.skip); else the sampler step's tail runs in the same launch (TailArgs of THIS
+// launch's rows: x, noise, xa_next, history pointers and quad_row0 already offset to its first row).  nct = column tiles of 32 frames per
+// workgroup: p.tiles_per_row / p.n_tiles count tiles of 32 * nct frames
+int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct) {
+  static int fair = -1;
+  if (fair < 0) { const char* e = getenv("BSG_H2_FAIR"); fair = e ? atoi(e) : 1; }
+  return nct == 1 ? h2_launch<1>(p, tail, st, fair) : h2_launch<2>(p, tail, st, fair);
 }
 
 // the three projections of the step tail as split-fp16 fragments + their scale table [3][2]; maxbits: [3] scratch

@@ -67,7 +67,7 @@ int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf
 
 // fp32 stack launch on the 16-bit matrix pipe: operands split exactly into hi + lo fp16 terms (diffnet_h2.hip); 64-frame tiles, one
 // workgroup per CU; grid = p.n_tiles rounded up to 8
-int stack_h2_occupancy();
+int stack_h2_occupancy(int nct);   // nct = column tiles of 32 frames per workgroup (1 or 2)
 int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* maxbits, float* tab, hipStream_t st);
 int pack_a_frag_h2(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
                    int is_gemm2, hipStream_t st);

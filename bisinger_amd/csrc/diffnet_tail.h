@@ -106,7 +106,7 @@ __device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigne
 
 
 // split-fp16 stack launch (diffnet_h2.hip), optionally with the step tail in the same launch
-int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st);
+int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct);
 int h2_tail_pack(const float* ws, const float* wo96, const float* wi96, unsigned short* out_ws, unsigned short* out_wo, unsigned short* out_wi,
                  unsigned* maxbits, float* tab, hipStream_t st);
 

@@ -129,6 +129,11 @@ class DiffNet(nn.Module):
         elif self.compute_dtype not in self._COMPUTE:
             raise _lib.BsgError(f"diff_compute_dtype={self.compute_dtype!r}: expected 'fp32' or 'bf16'")
 
+    def set_split_fp16(self, enable):
+        """False: this handle's residual stack multiplies on the fp32 matrix pipe only (Winograd kernels: channel-split launches at small
+        batch, F(4,3) stack launch when it fills the chip, per-layer launches otherwise) — what BSG_H2=0 does for the whole process."""
+        _lib.check(_lib.load().bsg_diffnet_set_h2(self.handle(), int(bool(enable))), 'bsg_diffnet_set_h2')
+
     def release(self):
         if self._h is not None:
             _lib.load().bsg_diffnet_destroy(self._h)

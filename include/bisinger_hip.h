@@ -340,6 +340,7 @@ int bsg_gemm_f32(const float* A, const float* Bm, float* C, const float* bias_m,
  * clipped silently: bsg_gemm_range_events waits for `stream`, returns the count (and resets it), and bsg_gemm_set_split(0) moves every
  * later GEMM to the fp32 matrix pipe — what the Python drop-ins do before they repeat the call (bisinger_amd/diffnet.py guarded). */
 int bsg_gemm_set_split(int32_t enable);
+int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable);   /* 0: this handle's residual stack on the fp32 matrix pipe only (as BSG_H2=0) */
 int bsg_gemm_range_events(int32_t* events, int32_t reset, void* stream);
 
 #ifdef __cplusplus

@@ -151,23 +151,32 @@ def test_bf16_config_full_size():
 
 
 def test_split_launch_equals_regular_launch(model, data):
-    """Small launches (<= 128 tiles) run a tile as a PAIR of workgroups with a z hand-off (residual_split_kernel); the
-    arithmetic per output element is the same k-ordered chain, so row 3 alone (B=1: split) must equal row 3 inside the
-    B=16 batch (512 tiles: one workgroup per tile) bit for bit, and no hand-off may have timed out."""
+    """The kernels of the fp32 matrix pipe (DiffNet.set_split_fp16(False), what BSG_H2=0 selects for a whole process).  Small launches
+    (<= 128 tiles) run a tile as a PAIR (or four) of workgroups with a z hand-off (residual_split_kernel); the arithmetic per output
+    element is the same k-ordered chain as the one-workgroup-per-tile launch, so row 3 alone (B=1: split) must equal row 3 inside a B=8
+    batch (256 tiles: one workgroup per tile) bit for bit, and no hand-off may have timed out.  B=16 fills the chip and runs the F(4,3)
+    stack launch: another rounding of the same sums (1e-5)."""
     x, cond, t = data
     net = model.denoise_fn
-    full = net(x, t, cond).clone()
-    other = net.last_path() in ('stack_f43', 'stack_h2')
-    one = net(x[3:4].contiguous(), t[3:4].contiguous(), cond[3:4].contiguous()).clone()
-    assert net.last_path().startswith('split')
-    if other:   # the default at B=16 (split-fp16 or F(4,3) stack launch) against the split kernels' F(2,3): two roundings of the same sums
-        assert maxabs(one[0], full[3]) <= 1e-5
-    else:
-        assert torch.equal(one[0], full[3])
-    half = net(x[:8].contiguous(), t[:8].contiguous(), cond[:8].contiguous()).clone()      # 256 tiles of 32 frames (or a half-full stack launch)
-    if net.last_path().startswith('stack'):
-        assert maxabs(one[0], half[3]) <= 1e-5
-        assert torch.equal(half[3], full[3]) or net.last_path() != 'stack_h2'    # the same stack form: a row does not depend on the batch around it
-    else:
+    net.set_split_fp16(False)
+    try:
+        full = net(x, t, cond).clone()
+        assert net.last_path() in ('stack_f43', 'layer')
+        f43 = net.last_path() == 'stack_f43'
+        one = net(x[3:4].contiguous(), t[3:4].contiguous(), cond[3:4].contiguous()).clone()
+        assert net.last_path().startswith('split')
+        if f43:
+            assert maxabs(one[0], full[3]) <= 1e-5
+        else:
+            assert torch.equal(one[0], full[3])
+        half = net(x[:8].contiguous(), t[:8].contiguous(), cond[:8].contiguous()).clone()      # 256 tiles of 32 frames, one workgroup per tile
+        assert not net.last_path().startswith('stack')
         assert torch.equal(one[0], half[3])
-    assert net.handoff_timeouts() == 0
+        assert net.handoff_timeouts() == 0
+    finally:
+        net.set_split_fp16(True)
+    # and the default form (split-fp16 stack launch, 32- or 64-frame tiles by batch size): a row does not depend on the batch around it
+    a = net(x, t, cond).clone()
+    b1 = net(x[3:4].contiguous(), t[3:4].contiguous(), cond[3:4].contiguous()).clone()
+    assert net.last_path() == 'stack_h2' and maxabs(b1[0], a[3]) <= 1e-5      # 32-frame against 64-frame tiles: the same sums, fp32 accumulation order alike
+    assert maxabs(b1[0], one[0]) <= 1e-5

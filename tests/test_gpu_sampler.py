@@ -146,12 +146,15 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     (2, 31, F23, dict(F43, BSG_STACK43='2'), 'stack_f43', 1e-5),         # T < one tile
     # the split-fp16 stack launch (diffnet_h2.hip, the default for launch groups that are at least half full): the direct K=768 form with
     # every fp32 operand as hi + lo fp16 terms on the 16-bit matrix pipe — a third rounding of the same sums
-    (16, 1000, F23, H2, 'stack_h2', 1e-5),
+    (16, 1000, F23, H2, 'stack_h2', 1e-5),                               # 64-frame tiles: 256 workgroups
     (32, 997, F23, H2, 'stack_h2', 1e-5),
-    (8, 1000, F23, H2, 'stack_h2', 1e-5),                                # a half-full launch group
-    (3, 77, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),
+    (8, 1000, F23, H2, 'stack_h2', 1e-5),                                # 32-frame tiles (the 64-frame ones would fill half of the CUs)
+    (16, 1000, F23, dict(H2, BSG_H2_NCT='1'), 'stack_h2', 1e-5),         # forced 32-frame tiles: two launch groups of 8 rows
+    (3, 77, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),                # forced for a few tiles (32-frame), partial tile
     (5, 333, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),
-    (2, 31, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2'), 'stack_h2', 1e-5),                # T < one tile
+    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),   # the same with 64-frame tiles
+    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),
 ])
 def test_stack_launch_matches_per_layer_launches(B, T, base, stack, path, tol, tmp_path):
     """The on-chip stack launches (all 20 layers in one launch, x on chip, neighbour tiles exchanging 8-frame edges every

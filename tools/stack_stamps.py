@@ -30,6 +30,9 @@ torch.cuda.synchronize()
 F43 = net.last_path() == 'stack_f43'
 H2 = net.last_path() == 'stack_h2'   # split-fp16 form: same stamp slots as the bf16 stack launch
 NTILE = 64 if DT == 'bf16' or F43 or H2 else 32
+if H2:   # the split-fp16 launch picks 32-frame tiles when the 64-frame ones would fill at most half of the CUs (stack_rows, diffnet.hip)
+    nct = int(os.environ.get('BSG_H2_NCT', '0')) or (2 if B * ((T + 63) // 64) * 2 > 256 else 1)
+    NTILE = 32 * nct
 tiles, L = B * ((T + NTILE - 1) // NTILE), 20
 st = torch.zeros(tiles * L * 8, dtype=torch.int64, device=dev)
 for rep in range(3):
