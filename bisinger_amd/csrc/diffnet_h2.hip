@@ -1,7 +1,8 @@
 // fp32 DiffNet residual stack on the 16-bit matrix pipe: every fp32 operand split EXACTLY into two fp16 terms.
 //
-// Same contract, tensors and results (to fp32 rounding) as the fp32-matrix-pipe stack launch (diffnet_f43.hip; reference semantics /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130).  gfx950 multiplies fp32
-// operands at 256 FLOP/clk/CU (v_mfma_f32_32x32x2_f32) and fp16 operands at 4096 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  An
+// Same contract, tensors and results (to fp32 rounding) as the fp32-matrix-pipe stack launch (diffnet_f43.hip; reference semantics
+// /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130; with TAIL also net.py:126-129 and the sampler update,
+// usr/diff/shallow_diffusion_tts.py:149-201).  gfx950 multiplies fp32 operands at 256 FLOP/clk/CU (v_mfma_f32_32x32x2_f32) and fp16 operands at 4096 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  An
 // fp32 value a is hi + lo with hi = fp16(a), lo = fp16(a - hi): 11 + 11 significand bits plus the sign of lo cover the 24 of fp32, so
 // |a - hi - lo| <= 2^-24 |a| (half an fp32 ulp) as long as lo is a normal fp16.  A product of two such values is
 //     a b = ah bh + ah bl + al bh   (+ al bl, <= 2^-24 |a b|: dropped)
@@ -22,6 +23,10 @@
 // channels-last) by the waves that own the channels; neighbours exchange the two 8-frame edges of both planes through L2 (16 KB per
 // tile and layer) under the centre tap of GEMM1; the conditioner term (fp32, 2 KB per frame and layer: the only HBM stream) is
 // requested into the free accumulators a phase ahead.  LDS: 2 x 42,240 (image) + 2 x 33,792 (z) + 3 KB of tables = 155,136 B.
+// Template NCT = 1 is the same program on 32-frame tiles (one column tile per wave; for batches whose 64-frame tiles would leave CUs
+// idle); TAIL appends the sampler step's tail on the tile (skip / output / input projections, DDPM or PLMS update).
+// NOTE for whoever edits the kernel: the NCT = 2 form needs all 256 VGPRs and its register allocation has no slack — check the spill
+// count after every change (tests/test_build_resources.py; ~10-17 spilled registers outside the matrix loops are the good state).
 #include "diffnet_res.h"
 #include "diffnet_tail.h"
 
