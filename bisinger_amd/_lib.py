@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
 if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
     LIB_PATH = os.environ['BSG_LIB']
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BsgError(RuntimeError):

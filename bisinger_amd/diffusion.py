@@ -122,14 +122,29 @@ class GaussianDiffusion(nn.Module):
             if hparams.get('pndm_speedup'):
                 raise NotImplementedError('PLMS is fused with the wavenet denoiser only')
             n = t if n_steps is None else n_steps
-            Bt = B if B_total is None else B_total
-            with torch.cuda.device(x.device):
-                for k in range(n):
-                    i = t - 1 - k
-                    eps = self.denoise_fn(x, torch.full((B,), i, device=x.device, dtype=torch.long), cond)
-                    nz = None if noise is None else noise[k].contiguous()
-                    _lib.check(lib.bsg_ddpm_step(_lib.ptr(x), _lib.ptr(eps.contiguous()), _lib.ptr(nz), byref(s), i, x.numel(), seed,
-                                                 row0 * M * T, _lib.stream_ptr()), 'bsg_ddpm_step')
+            capturing = torch.cuda.is_current_stream_capturing()
+            keep = None if capturing else x.clone()
+
+            def loop():
+                with torch.cuda.device(x.device):
+                    for k in range(n):
+                        i = t - 1 - k
+                        eps = self.denoise_fn(x, torch.full((B,), i, device=x.device, dtype=torch.long), cond)
+                        nz = None if noise is None else noise[k].contiguous()
+                        _lib.check(lib.bsg_ddpm_step(_lib.ptr(x), _lib.ptr(eps.contiguous()), _lib.ptr(nz), byref(s), i, x.numel(), seed,
+                                                     row0 * M * T, _lib.stream_ptr()), 'bsg_ddpm_step')
+            loop()
+            # this denoiser is GEMMs only: the range guard of the split-fp16 GEMMs (an operand beyond the fp16 range is counted, not
+            # clipped) is read once per call; on an event every GEMM moves to the fp32 matrix pipe and the loop is repeated from x_T
+            if not capturing and _lib.gemm_range_take():
+                import warnings
+                warnings.warn('bisinger_amd: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4094); GEMMs now run on the '
+                              'fp32 matrix pipe and the sampler loop is repeated')
+                _lib.check(lib.bsg_gemm_set_split(0), 'bsg_gemm_set_split')
+                _lib.range_retries += 1
+                x.copy_(keep)
+                self.denoise_fn.prepare(cond)
+                loop()
             return x
         n = t if n_steps is None else n_steps
         if noise is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSG_ABI_VERSION 2
+#define BSG_ABI_VERSION 3
 
 #define BSG_OK 0
 #define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
