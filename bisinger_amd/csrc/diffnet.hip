@@ -626,7 +626,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 1024 / NPART, 4) void residual_split_
       if (s.inject) atomicAdd(s.status, 1u);
       while (!s.inject && __hip_atomic_load(f + o * NPART + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s.epoch) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a partner is not resident
+        // ~ seconds: never reached unless a partner is not resident; once any wait of this handle has given up (status != 0: the host
+        // repeats the call without hand-offs anyway) the others stop within a thousand polls
+        if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(s.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
           atomicAdd(s.status, 1u);
           break;
         }

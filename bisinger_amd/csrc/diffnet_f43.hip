@@ -751,7 +751,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 22)) {   // ~ seconds: never reached unless a workgroup is not resident
+          // ~ seconds: never reached unless a workgroup is not resident.  Once ANY wait of this handle has given up (status != 0: the host
+          // repeats the call without hand-offs anyway) the others stop waiting within a thousand polls instead of seconds each
+          if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             atomicAdd(p.status, 1u);
             break;
           }
