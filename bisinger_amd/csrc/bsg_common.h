@@ -71,5 +71,9 @@ struct GemmArgs {
   int batch;
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);
+// the split-fp16 forms (gemm.hip, fs2.hip flash attention): true while products are formed on the 16-bit matrix pipe (BSG_GEMM_SPLIT,
+// bsg_gemm_set_split); an operand that cannot be split is counted in the range-event counter (bsg_gemm_range_events)
+bool gemm_split_enabled();
+unsigned* gemm_range_counter();   // device address of the range-event counter (null on error): kernels of other translation units add to it
 
 }  // namespace bsg

@@ -190,6 +190,163 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(const float* __r
   }
 }
 
+// ---- the same fused attention with every product on the 16-bit matrix pipe (split-fp16, see gemm.hip / diffnet_h2.hip) --------------
+// Q, K, V are scaled by 2^4 and split exactly into hi + lo fp16 terms (Q once, into registers; K and V while their 32-key block is staged:
+// K as [key][128 d] planes, V TRANSPOSED as [d][32 keys] planes), the probabilities P = exp(S - m) in [0, 1] by 2^10 and split in
+// registers; every fp32 product is hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 48 MFMAs of 32 matrix cycles
+// per key block and wave instead of 128 of 64.  The softmax runs in fp32 on the un-scaled scores exactly as above.
+//   S^T[key, q]: A = K fragment (lane = key, 8 consecutive d per lane half), B = Q fragment of the lane's query.
+//   O^T[d, q] += V^T[d, key] P[key, q]: the lane's 16 probabilities are keys (r&3) + 8 (r>>2) + 4 lh; MFMA step t takes its registers
+//   8t .. 8t+7 as the 8 k-values of the lane half, so the A fragment of V^T is read with that key order: two 8-byte pieces of a [d] row.
+// Operands beyond the fp16 range (|v| >= 4094) are counted in the GEMMs' range-event counter (the host repeats the call on the
+// fp32 pipe).
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ keep,
+                                                                      float* __restrict__ out, int T, int heads, int ld, int ldo,
+                                                                      unsigned* __restrict__ range_events) {
+  constexpr int D = 128, BK = 32, KROW = 2 * D + 16, VROW = 2 * BK + 16;   // bytes per LDS row: 272 (68 dwords = 4 mod 64), 80
+  constexpr float SIN = 16.0f, PSC = 1024.0f;
+  __shared__ __attribute__((aligned(16))) char Kp[2 * BK * KROW];    // hi plane, lo plane
+  __shared__ __attribute__((aligned(16))) char Vp[2 * D * VROW];
+  __shared__ float kp[BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / heads, hh = blockIdx.y - b * heads;
+  const int q_row = (blockIdx.x * NW + wave) * 32 + l31;
+  const bool q_ok = q_row < T;
+  const float* __restrict__ base = qkv + (long long)b * T * ld + hh * D;
+  bool bad = false;
+  auto split8 = [&](const f32x4 a, const f32x4 c, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (e < 4 ? a[e] : c[e - 4]) * SIN;
+      bad |= !(fabsf(x) < 65000.0f);
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+  };
+  f16x8 qh[8], ql[8];   // d = 16 s + 8 lh + 0..7
+  {
+    const float* __restrict__ qp = base + (long long)(q_ok ? q_row : T - 1) * ld + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      split8(*reinterpret_cast<const f32x4*>(qp + 16 * s), *reinterpret_cast<const f32x4*>(qp + 16 * s + 4), qh[s], ql[s]);
+  }
+  f32x16 O[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int H3 = ld / 3;
+  for (int k0 = 0; k0 < T; k0 += BK) {
+    __syncthreads();   // the previous block's tiles are consumed
+#pragma unroll 2
+    for (int j = 0; j < 1024 / (64 * NW); ++j) {
+      const int idx = tid + 64 * NW * j;
+      const int key = idx >> 5, c4 = (idx & 31) << 2;
+      const int kt = k0 + key;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (kt < T) {
+        const float* __restrict__ rp = base + (long long)kt * ld + c4;
+        kv = *reinterpret_cast<const f32x4*>(rp + H3);
+        vv = *reinterpret_cast<const f32x4*>(rp + 2 * H3);
+      }
+      f16x4 kh4, kl4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = kv[e] * SIN, y = vv[e] * SIN;
+        bad |= !(fabsf(x) < 65000.0f) || !(fabsf(y) < 65000.0f);
+        kh4[e] = (_Float16)x;
+        kl4[e] = (_Float16)(x - (float)kh4[e]);
+        const _Float16 vh = (_Float16)y, vl = (_Float16)(y - (float)vh);
+        *reinterpret_cast<_Float16*>(Vp + (c4 + e) * VROW + key * 2) = vh;
+        *reinterpret_cast<_Float16*>(Vp + D * VROW + (c4 + e) * VROW + key * 2) = vl;
+      }
+      *reinterpret_cast<f16x4*>(Kp + key * KROW + c4 * 2) = kh4;
+      *reinterpret_cast<f16x4*>(Kp + BK * KROW + key * KROW + c4 * 2) = kl4;
+    }
+    if (tid < BK) kp[tid] = (k0 + tid < T) ? keep[(long long)b * T + k0 + tid] : 0.f;
+    __syncthreads();
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    {
+      const char* kr = Kp + l31 * KROW + 16 * lh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(kr + 32 * s);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(kr + 32 * s + BK * KROW);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], S, 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] *= 1.0f / (SIN * SIN);
+      if (kp[acc_row(r, lh)] == 0.f) S[r] = -INFINITY;
+      mx = fmaxf(mx, S[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float ms = m_new == -INFINITY ? 0.f : m_new;     // a block of masked keys only must not produce inf - inf
+    const float scale = expf(m - ms);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = expf(S[r] - ms);
+      ps += S[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    l = l * scale + ps;
+    m = m_new;
+    f16x8 ph[2], pl[2];   // step t: registers 8t .. 8t+7 = keys 16 t + 4 lh + (j & 3) + 8 (j >> 2)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = S[8 * t + j] * PSC;
+        ph[t][j] = (_Float16)x;
+        pl[t][j] = (_Float16)(x - (float)ph[t][j]);
+      }
+    const bool rescale = __any(scale != 1.0f);   // wave-uniform: once the running maxima have settled nothing is rescaled
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (rescale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] *= scale;
+      }
+      const char* vr = Vp + (32 * dt + l31) * VROW + 8 * lh;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u32x2_t h0 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t), h1 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + 16);
+        const u32x2_t l0 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + D * VROW), l1 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + 16 + D * VROW);
+        const f16x8 ah = __builtin_bit_cast(f16x8, u32x4_t{h0[0], h0[1], h1[0], h1[1]});
+        const f16x8 al = __builtin_bit_cast(f16x8, u32x4_t{l0[0], l0[1], l1[0], l1[1]});
+        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph[t], O[dt], 0, 0, 0);
+        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl[t], O[dt], 0, 0, 0);
+        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph[t], O[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(range_events, 1u);
+  if (q_ok) {
+    const float inv = 1.0f / (l * SIN * PSC);
+    float* __restrict__ op = out + ((long long)b * T + q_row) * ldo + hh * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) op[32 * dt + acc_row(r, lh)] = O[dt][r] * inv;
+  }
+}
+
 // ---- token embeddings ----------------------------------------------------------------------------
 // x0 = sqrt(H) * E_tok[txt]; lang_e = E_lang[lang]                      (diffsinger_midi/fs2.py:28,122)
 __global__ void embed_tokens_kernel(const long long* __restrict__ txt, const long long* __restrict__ lang,
@@ -622,7 +779,12 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
     if (hd == 128 && !getenv("BSG_NO_FLASH_ATTN")) {
       // fused attention: no [B*heads, T, T] score tensor (flash_attn_kernel); 2 waves per workgroup when 4 would leave CUs idle
       const long long wg4 = (long long)cdiv(T, 128) * B * heads;
-      if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
+      static int fsplit = -1;   // BSG_FLASH_SPLIT=0: the fp32-MFMA form even while the GEMMs run split-fp16
+      if (fsplit < 0) { const char* e = getenv("BSG_FLASH_SPLIT"); fsplit = e ? atoi(e) : 1; }
+      if (fsplit && gemm_split_enabled()) {
+        if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H, gemm_range_counter());
+        else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H, gemm_range_counter());
+      } else if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
       else hipLaunchKernelGGL(flash_attn_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
       BSG_LAUNCH_CHECK();
     } else {

@@ -585,6 +585,17 @@ int launch_fast(const GemmArgs& g, hipStream_t st) {
 
 static int g_split = -1;   // -1: not read yet (environment); set by bsg_gemm_set_split
 
+unsigned* gemm_range_counter() {
+  static unsigned* p = nullptr;   // (one device per process in this library's use; the symbol address is per device)
+  if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_gemm_range_events)) != hipSuccess) p = nullptr;
+  return p;
+}
+
+bool gemm_split_enabled() {
+  if (g_split < 0) { const char* e = getenv("BSG_GEMM_SPLIT"); g_split = e ? atoi(e) : 1; }
+  return g_split != 0;
+}
+
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   BSG_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.taps > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
   BSG_REQUIRE(g.batch <= 65535, "gemm: batch %d > 65535", g.batch);
