@@ -154,6 +154,7 @@ struct PairArgs {
   float out_div;        // y /= out_div (num_kernels after the last resblock, :167)
   float slope;
   int L, dil;
+  unsigned* range_events;   // split-fp16 form: counter of operands beyond the fp16 range (gemm_range_counter())
 };
 
 template <int K, int C, int TT>
@@ -646,6 +647,239 @@ int launch_pair_k(const PairArgs& a, int C, int B, hipStream_t st) {
     default: return BSG_EINVAL;
   }
 }
+// ------------------------------------------------------------------------------------------------
+// The same fused pair with every product on the 16-bit matrix pipe (split-fp16: gemm.hip / diffnet_h2.hip have the argument).  Weights
+// x 2^8 and activations x 2^4 are split exactly into hi + lo fp16 terms — the weights once at create (pack_conv_h2_kernel), lrelu(x) while
+// it is staged, the intermediate t1 in registers — and each fp32 product is hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation (the accumulators carry 2^12): per tap and 16 input channels 3 MFMAs of 32 matrix cycles instead of 8 of 64.  The LDS
+// images are channels-last [position][C fp16 + 16 B] planes (an MFMA B fragment = 8 consecutive input channels of one position = one
+// ds_read_b128; the row stride of 36 / 20 dwords keeps the 16 rows of a lane group on different bank quads); the staging transposes on
+// the fly (lanes = consecutive positions: coalesced rows of [C][L]; a thread packs 4 channels into one 8-byte write per plane).
+// ------------------------------------------------------------------------------------------------
+using hf16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using hf16x4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr float HG_WSC = 256.0f, HG_ASC = 16.0f;
+
+// out[((((rt*K + k)*(C/16) + ks)*2 + plane)*64 + lane)*8 + j] = hi / lo of 2^8 W[co = 32 rt + (lane & 31)][ci = 16 ks + 8 (lane >> 5) + j][k]
+__global__ void pack_conv_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int C, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * C * K) return;
+  const int j = i & 7, lane = (i >> 3) & 63, rest = i >> 9;
+  const int KS = C / 16;
+  const int ks = rest % KS, k = (rest / KS) % K, rt = rest / (KS * K);
+  const float v = w[((long long)(32 * rt + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5) + j) * K + k] * HG_WSC;
+  const _Float16 hi = (_Float16)v;
+  const long long base = ((((long long)(rt * K + k) * KS + ks) * 2) * 64 + lane) * 8 + j;
+  out[base] = hi;
+  out[base + 512] = (_Float16)(v - (float)hi);
+}
+
+// acc[rt][nb] += W * img for one conv: img = LDS planes [rows][rowb] (lo plane at + plane), this wave's positions start at row n0; tap k
+// reads row p + k * dil
+template <int K, int C, int NB>
+__device__ __forceinline__ void conv_h2(f32x16 (&acc)[C / 32][NB], const _Float16* __restrict__ wpk, const char* img, int rowb, int plane,
+                                        int n0, int dil, int lane) {
+  constexpr int RT = C / 32, KS = C / 16;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const hf16x8* __restrict__ wp = reinterpret_cast<const hf16x8*>(wpk) + lane;
+  const char* bp = img + (n0 + l31) * rowb + lh * 16;
+  hf16x8 A[2][RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    A[0][rt][0] = wp[((rt * K) * KS) * 128];
+    A[0][rt][1] = wp[((rt * K) * KS) * 128 + 64];
+  }
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    const char* bk = bp + k * dil * rowb;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // weights of the next k-step (the first of the next tap after the last of this one; a harmless repeat at the very end)
+      const int kn = ks + 1 < KS ? k : (k + 1 < K ? k + 1 : k), sn = ks + 1 < KS ? ks + 1 : (k + 1 < K ? 0 : ks);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        A[(ks + 1) & 1][rt][0] = wp[((rt * K + kn) * KS + sn) * 128];
+        A[(ks + 1) & 1][rt][1] = wp[((rt * K + kn) * KS + sn) * 128 + 64];
+      }
+      hf16x8 bh[NB], bl[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        bh[nb] = *reinterpret_cast<const hf16x8*>(bk + 32 * nb * rowb + ks * 32);
+        bl[nb] = *reinterpret_cast<const hf16x8*>(bk + 32 * nb * rowb + ks * 32 + plane);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][rt][0], bh[nb], acc[rt][nb], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][rt][0], bl[nb], acc[rt][nb], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][rt][1], bh[nb], acc[rt][nb], 0, 0, 0);
+    }
+  }
+}
+
+template <int K, int C, int NB>
+__global__ __launch_bounds__(256) void resblock_pair_h2_kernel(PairArgs a) {
+  constexpr int PT = 128 * NB, H2 = (K - 1) / 2, POUT = PT - (K - 1), RT = C / 32, TS = PT + 16, ROWB = 2 * C + 16;
+  constexpr float ACC_SC = HG_WSC * HG_ASC, ACC_INV = 1.0f / (HG_WSC * HG_ASC);
+  static_assert(C % 32 == 0, "channel count");
+  extern __shared__ __attribute__((aligned(16))) char hlds[];   // lrelu(x) planes [span][ROWB], then t1 planes [TS][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int t0 = blockIdx.x * POUT, b = blockIdx.y;
+  const int h1 = H2 * a.dil, span = PT + 2 * h1;
+  const int plane = (span > TS ? span : TS) * ROWB;
+  const float* __restrict__ xb = a.x + (long long)b * C * a.L;
+  const float slope = a.slope;
+  bool bad = false;
+  auto split4 = [&](const float (&v)[4], hf16x4& hi, hf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * HG_ASC;
+      bad |= !(fabsf(x) < 65000.0f);
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+  };
+  // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
+  for (int idx = tid; idx < (C / 4) * span; idx += 256) {
+    const int cq = idx / span, jx = idx - cq * span;
+    const int t = t0 - H2 - h1 + jx;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = (t >= 0 && t < a.L) ? xb[(long long)(4 * cq + e) * a.L + t] : 0.f;
+      v[e] = fmaxf(x, x * slope);
+    }
+    hf16x4 hi, lo;
+    split4(v, hi, lo);
+    *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
+    *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+  }
+  const int n0 = 32 * NB * wave;
+  f32x16 acc[RT][NB];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bv = a.b1[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh] * ACC_SC;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb][r] = bv;
+    }
+  __syncthreads();
+  // ---- conv1 (dilation d) at t1 positions u = t0 - H2 + p: reads x row p + k d ------------------------------------------------------
+  conv_h2<K, C, NB>(acc, reinterpret_cast<const _Float16*>(a.w1), hlds, ROWB, plane, n0, a.dil, lane);
+  __syncthreads();   // every wave is done reading x
+  // ---- t1 = lrelu(conv1), zero outside [0, L) (conv2 pads its input) -> LDS planes [TS][ROWB] -----------------------------------------
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int pcol = n0 + 32 * nb + l31, u = t0 - H2 + pcol;
+    const bool in = u >= 0 && u < a.L;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = acc[rt][nb][4 * g + e] * ACC_INV;
+          v[e] = in ? fmaxf(y, y * slope) : 0.f;
+        }
+        hf16x4 hi, lo;
+        split4(v, hi, lo);
+        char* dst = hlds + pcol * ROWB + (32 * rt + 8 * g + 4 * lh) * 2;
+        *reinterpret_cast<hf16x4*>(dst) = hi;
+        *reinterpret_cast<hf16x4*>(dst + plane) = lo;
+      }
+  }
+  // rows PT .. TS-1 are read by the (masked) last K-1 positions of the tile: keep them finite (both planes)
+  for (int idx = tid; idx < (TS - PT) * (ROWB / 4); idx += 256) {
+    const int row = PT + idx / (ROWB / 4), c = idx % (ROWB / 4);
+    *reinterpret_cast<unsigned*>(hlds + row * ROWB + c * 4) = 0u;
+    *reinterpret_cast<unsigned*>(hlds + plane + row * ROWB + c * 4) = 0u;
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bv = a.b2[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh] * ACC_SC;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb][r] = bv;
+    }
+  __syncthreads();
+  // ---- conv2 (dilation 1) at output positions t = t0 + p: reads t1 row p + k ----------------------------------------------------------
+  conv_h2<K, C, NB>(acc, reinterpret_cast<const _Float16*>(a.w2), hlds, ROWB, plane, n0, 1, lane);
+  if (a.range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(a.range_events, 1u);
+  // ---- residual, MRF sum, store ----------------------------------------------------------------------------------------------------------
+  const bool has_acc = a.acc_in != nullptr, has_div = a.out_div != 1.0f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int pcol = n0 + 32 * nb + l31, t = t0 + pcol;
+    if (pcol >= POUT || t >= a.L) continue;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const long long i0 = ((long long)b * C + 32 * rt + 4 * lh) * a.L + t;
+      float xr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xr[r] = a.x[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L];
+      if (has_acc) {
+        float ar[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ar[r] = a.acc_in[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = ar[r] + (acc[rt][nb][r] * ACC_INV + xr[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = acc[rt][nb][r] * ACC_INV + xr[r];
+      }
+      if (has_div) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = xr[r] / a.out_div;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a.y[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L] = xr[r];
+    }
+  }
+}
+
+template <int K, int C, int NB>
+int launch_pair_h2_t(const PairArgs& a, int B, hipStream_t st) {
+  constexpr int PT = 128 * NB, POUT = PT - (K - 1), ROWB = 2 * C + 16;
+  const int span = PT + 2 * ((K - 1) / 2 * a.dil);
+  const size_t lds = (size_t)2 * (span > PT + 16 ? span : PT + 16) * ROWB;
+  static size_t attr = 0;
+  if (lds > attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)resblock_pair_h2_kernel<K, C, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL((resblock_pair_h2_kernel<K, C, NB>), dim3(cdiv(a.L, POUT), B), dim3(256), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+template <int K, int C>
+int launch_pair_h2_kc(const PairArgs& a, int B, hipStream_t st) {
+  if ((long long)cdiv(a.L, 256 - (K - 1)) * B >= 256) return launch_pair_h2_t<K, C, 2>(a, B, st);
+  return launch_pair_h2_t<K, C, 1>(a, B, st);
+}
+int launch_pair_h2(const PairArgs& a, int K, int C, int B, hipStream_t st) {
+  if (C == 32) {
+    if (K == 3) return launch_pair_h2_kc<3, 32>(a, B, st);
+    if (K == 7) return launch_pair_h2_kc<7, 32>(a, B, st);
+    if (K == 11) return launch_pair_h2_kc<11, 32>(a, B, st);
+  } else if (C == 64) {
+    if (K == 3) return launch_pair_h2_kc<3, 64>(a, B, st);
+    if (K == 7) return launch_pair_h2_kc<7, 64>(a, B, st);
+    if (K == 11) return launch_pair_h2_kc<11, 64>(a, B, st);
+  }
+  set_error("hifigan: no split-fp16 pair kernel for K=%d C=%d", K, C);
+  return BSG_EINVAL;
+}
+
 template <int K, int C, int NB>
 int launch_pair_mfma_t(const PairArgs& a, int B, hipStream_t st) {
   constexpr int PT = 128 * NB, POUT = PT - (K - 1);
@@ -721,6 +955,7 @@ struct ConvW {
   float* wpk = nullptr;   // Conv1d only: repacked for conv1d_kernel (CO_BLK = 16 if cout >= 16 else 8)
   float* wpc = nullptr;   // ResBlock convs: [cin][k][cout] for resblock_pair_kernel
   float* wpm = nullptr;   // ResBlock convs with 32 / 64 channels: MFMA fragment order for resblock_pair_mfma_kernel
+  float* wps = nullptr;   // the same as hi / lo fp16 fragments (x 2^8) for resblock_pair_h2_kernel (m floats = 2 planes of m halves)
   float* wpu = nullptr;   // ConvTranspose1d with K = 2u: per-phase 2-tap weights in CO-blocks of 8 for upsample_kernel
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
@@ -789,6 +1024,9 @@ static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st, bool pair = false
     if (pair_mfma_supported(c.k, c.cout)) {
       TRY(hg_alloc(h, &c.wpm, m));
       hipLaunchKernelGGL(pack_conv_mfma_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, c.wpm, c.cout, c.k);
+      BSG_LAUNCH_CHECK();
+      TRY(hg_alloc(h, &c.wps, m));
+      hipLaunchKernelGGL(pack_conv_h2_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, reinterpret_cast<_Float16*>(c.wps), c.cout, c.k);
       BSG_LAUNCH_CHECK();
     }
   }
@@ -999,7 +1237,12 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
           pa.acc_in = (last && j > 0) ? sum : nullptr;
           pa.out_div = (last && j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f;
           pa.slope = slope; pa.L = L; pa.dil = c.resblock_dilations[j][m];
-          if (use_mfma) {
+          static int h2_env = -1;   // BSG_HG_SPLIT=0: the fp32-MFMA form even while the GEMMs run split-fp16
+          if (h2_env < 0) { const char* e = getenv("BSG_HG_SPLIT"); h2_env = e ? atoi(e) : 1; }
+          if (use_mfma && h2_env && c1.wps && c2.wps && gemm_split_enabled()) {
+            pa.w1 = c1.wps; pa.w2 = c2.wps; pa.range_events = gemm_range_counter();
+            TRY(launch_pair_h2(pa, c1.k, c1.cout, B, st));
+          } else if (use_mfma) {
             pa.w1 = c1.wpm; pa.w2 = c2.wpm;
             TRY(launch_pair_mfma(pa, c1.k, c1.cout, B, st));
           } else {
