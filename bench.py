@@ -216,22 +216,33 @@ def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps, repeats=3):
 # ------------------------------------------------------------------------------------------------------------------
 # rooflines
 # ------------------------------------------------------------------------------------------------------------------
+def build_digest():
+    """Source digest of the library that is loaded (bisinger_amd/lib/build.sha256, written by bisinger_amd/build.py)."""
+    try:
+        return open(os.path.join(ROOT, 'bisinger_amd', 'lib', 'build.sha256')).read().strip()
+    except OSError:
+        return None
+
+
 def traffic_from_profiles(bf16, frames_per_launch, path=None):
     """HBM-side bytes of the dominant kernel from the committed PMC summary (profiles/traffic*.json, written by
-    tools/summarize_profiles.py) — only when that summary describes the launch form that just ran (`path`) at this size."""
+    tools/summarize_profiles.py) — only when that summary describes the launch form that just ran (`path`) at this size.
+    -> (bytes or None, digest of the build the PMC passes ran on or None)."""
     tpath = os.path.join(ROOT, 'profiles', 'traffic_bf16.json' if bf16 else 'traffic.json')
     if not os.path.exists(tpath):
-        return None
+        return None, None
     tj = json.load(open(tpath))
-    if tj.get('path', 'bf16' if bf16 else 'layer') != (path or ('bf16' if bf16 else 'layer')).replace('_tail', ''):
-        return None
+    form = lambda q: q.replace('_tail', '')
+    if form(tj.get('path', 'bf16' if bf16 else 'layer')) != form(path or ('bf16' if bf16 else 'layer')):
+        return None, tj.get('build_sha256')
     if abs(tj.get('frames_per_launch', 16000) - frames_per_launch) < 1:
-        return tj.get('residual_layer_kernel_hbm_bytes_per_launch')
-    return None
+        return tj.get('residual_layer_kernel_hbm_bytes_per_launch'), tj.get('build_sha256')
+    return None, tj.get('build_sha256')
 
 
-def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
-    """Roofline object of the dominant kernel from the live HIP-event timing of its launches."""
+def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None, clock=None):
+    """Roofline object of the dominant kernel from the live HIP-event timing of its launches.  `clock` = (MHz, span us) of
+    DiffNet.clock_read(): the shader clock the chip held over the last timed stack launch."""
     if not n_layer:
         return None
     avg_ms = layer_ms / n_layer
@@ -242,9 +253,15 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
     concurrent = max(1, round(b_per_gpu * T_FRAMES / frames_per_launch))
     per_launch = FLOP_PER_FRAME_LAYER * frames_per_launch / (avg_ms * 1e-3) / 1e12
     achieved = per_launch * concurrent
-    traffic = traffic_from_profiles(bf16, frames_per_launch, path)
+    traffic, traffic_build = traffic_from_profiles(bf16, frames_per_launch, path)
     common = {'avg_launch_us': avg_ms * 1e3, 'launches_timed': n_layer, 'frames_per_launch': frames_per_launch,
               'concurrent_launches': concurrent, 'traffic': traffic,
+              # the PMC passes behind `traffic` ran on the build with this source digest; false = the counters describe another build of
+              # the library than the one that was just timed (re-run tools/run_profiles.sh)
+              'traffic_build_sha256': traffic_build, 'traffic_build_matches': bool(traffic_build) and traffic_build == build_digest(),
+              # s_memtime / s_memrealtime over one whole timed launch of the dominant kernel (tile 0): the clock the chip sustains under it
+              'sustained_mhz': round(clock[0], 1) if clock and clock[0] else None,
+              'sustained_clock_span_us': round(clock[1], 1) if clock and clock[0] else None,
               'traffic_condition': ('PMC passes of the same command (profiles/traffic*.json): HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, '
                                     'MI355X_MICROARCH.md) of the stack launch / 20 layers x launch groups; the stack path has one launch in '
                                     'flight, so the serialised PMC run is the timed condition') if (path or '').startswith('stack') else
@@ -276,8 +293,9 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
         # split-fp16 stack launch (diffnet_h2.hip): every fp32 product as 3 fp16 MFMA products (hi hi, hi lo, lo hi), fp32 accumulate, so
         # the matrix pipe in use is the 16-bit one.  One launch = all 20 layers of up to 256 64-frame tiles; avg_ms = one layer over all rows
         executed = 3.0 * achieved
-        return dict(common, kernel='residual_stack_h2_kernel (20 fused DiffNet residual blocks per launch; fp32 operands split exactly into hi + lo '
+        return dict(common, kernel='residual_stack_h2_kernel (20 fused DiffNet residual blocks + the step tail per launch; fp32 operands split exactly into hi + lo '
                                    'fp16 terms, 3 fp16 MFMAs per fp32 product, fp32 accumulate; x and the skip sum on chip; figures per layer)',
+                    frac_executed_at_sustained_clock=(executed / (PEAK_BF16_MFMA_TFLOPS * clock[0] / 2400.0)) if clock and clock[0] else None,
                     bound='mfma', achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_BF16_MFMA_TFLOPS,
                     executed_tflops=executed, frac_executed=executed / PEAK_BF16_MFMA_TFLOPS,
                     achieved_over_fp32_mfma_peak=achieved / PEAK_F32_MFMA_TFLOPS,
@@ -319,8 +337,10 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None):
 class Workload:
     """Synthetic batch of B_total utterances resident in HBM; this rank generates `rows`."""
 
-    def __init__(self, model, device, B_total, rank, world):
+    def __init__(self, model, device, B_total, rank, world, emulate=False):
+        """emulate: this process plays rank `rank` of `world` on its own — rows as that rank, no collective (secondary.cfg3_rank)."""
         import torch
+        self.emulate = emulate
         from bisinger_amd import dist as bdist, synth
         self.model, self.B_total, self.rank, self.world = model, B_total, rank, world
         self.inp_np = synth.synth_inputs(B_total, T_TXT, T_FRAMES, seed=1)
@@ -334,6 +354,8 @@ class Workload:
         d = self.d
         out = self.model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True, seed=seed,
                          rows=self.rows if self.world > 1 else None, **self.kw)
+        if self.emulate:
+            return out['mel_out']
         return bdist.all_gather_rows(out['mel_out'], self.B_total, self.world, self.rank)
 
 
@@ -367,6 +389,7 @@ def secondary_bf16(model, device, fence):
         dt, layer_ms, n_layer, mel = timed(wl, 3, 1, fence)
         ok = bool(torch.isfinite(mel).all())
         path = net.last_path()
+        clock = net.clock_read()
     finally:
         net.set_compute('fp32')
     del wl
@@ -375,12 +398,80 @@ def secondary_bf16(model, device, fence):
                                    'operands / fp32 accumulate in the residual layers (FS2, projections, sampler fp32)'},
             'dtype': 'bf16', 'metric': 'mel_frames_per_sec', 'value': 64 * T_FRAMES * 3 / dt, 'unit': 'mel-frames/s',
             'steps': 3, 'warmup': 1, 'ms_per_step': dt / 3 * 1e3, 'finite': ok, 'path': path,
-            'roofline': roofline(True, layer_ms, n_layer, 3, 64, path)}
+            'roofline': roofline(True, layer_ms, n_layer, 3, 64, path, clock)}
+
+
+def secondary_cfg3_rank(model, device, fence):
+    """BASELINE configs[3] as ONE of its 8 ranks sees it, on one GPU and without the collective: B_total = 64, the token-level front on all
+    64 rows, frames and sampler on rows 8..15.  Beside it the same 64 utterances on one GPU; their ratio is what 8-GPU strong scaling
+    can reach at most (the all-gather of 8 x 2.56 MB over xGMI is not in it)."""
+    import torch
+    net = model.denoise_fn
+    wl = Workload(model, device, B_CFG3_TOTAL, 1, 8, emulate=True)
+    dt, layer_ms, n_layer, mel = timed(wl, 3, 1, fence)
+    path = net.last_path()
+    ok = bool(torch.isfinite(mel).all()) and tuple(mel.shape) == (8, T_FRAMES, N_MEL)
+    wl1 = Workload(model, device, B_CFG3_TOTAL, 0, 1)
+    dt1, _, _, mel1 = timed(wl1, 2, 1, fence, profile=False)
+    same = float((mel1[wl.rows] - mel).abs().max())        # Philox is indexed by the global row: the shard reproduces the unsharded rows
+    del wl, wl1
+    torch.cuda.empty_cache()
+    t_rank, t_one = dt / 3 * 1e3, dt1 / 2 * 1e3
+    return {'config': {'workload': 'BASELINE.json configs[3], one rank emulated on one GPU: B=64 total, FS2 token front on 64 rows, frame-level '
+                                   'FS2 + 100-step DDPM sampler on rows 8..15 (8 utterances x T=1000), fp32, no collective'},
+            'dtype': 'f32', 'metric': 'mel_frames_per_sec', 'value': 8 * T_FRAMES * 3 / dt, 'unit': 'mel-frames/s (this rank\'s 8 utterances)',
+            'steps': 3, 'warmup': 1, 'ms_per_step': t_rank, 'finite': ok, 'path': path,
+            'ms_per_step_b64_one_gpu': t_one, 'value_b64_one_gpu': B_CFG3_TOTAL * T_FRAMES / (t_one * 1e-3),
+            'predicted_strong_scaling_8': t_one / t_rank, 'target_strong_scaling_8': 6.5,
+            'shard_vs_unsharded_rows_max_abs': same,
+            'avg_layer_us': layer_ms / n_layer * 1e3 if n_layer else None, 'handoff_timeouts': net.handoff_timeouts()}
+
+
+def secondary_captured(model, device, fence):
+    """What a stream-captured sampler loop runs: launches that keep epoch flags (the stack launches) are never taken inside a capture, so a
+    captured GaussianDiffusion.sample() runs per-layer launches on the fp32 matrix pipe.  Captured once, replayed 3 times, at the headline shape."""
+    import torch
+    net = model.denoise_fn
+    B, T = B_CFG1, T_FRAMES
+    cond = torch.randn(B, 256, T, device=device)
+    x0 = torch.randn(B, 1, N_MEL, T, device=device)
+    model.sample(cond, x0.clone(), seed=3)                   # eager: binds, warms up
+    fence()
+    eager_path = net.last_path()
+    xg = x0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                model.sample(cond, xg, seed=3)
+            cap_path = net.last_path()
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+        torch.cuda.current_stream().wait_stream(side)
+        return {'what': 'hipGraph capture of the 100-step sampler loop at B=16, T=1000 (sampler only: no FS2), replayed 3 times',
+                'captured_path': cap_path, 'eager_path': eager_path, 'ms_per_replay': dt * 1e3,
+                'sampler_frames_per_sec_captured': B * T / dt, 'finite': bool(torch.isfinite(xg).all())}
+    except Exception as e:      # a secondary must never take the headline down
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library into the process: a child benchmark would inherit it (and its counter passes)."""
+    return any(k.startswith(('ROCPROF', 'ROCP_', 'ROCPROFILER')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', '')
 
 
 def secondary_fp32_pipe():
     """The headline workload with every product on the fp32 matrix pipe (BSG_H2=0: F(4,3) stack launch, BSG_GEMM_SPLIT=0: fp32-MFMA GEMMs)
     — a child process, because the launch-form switches are read once per process.  3 timed passes, no secondaries, no CPU leg."""
+    if under_profiler():
+        return {'skipped': 'running under a profiler'}
     env = dict(os.environ, BSG_H2='0', BSG_GEMM_SPLIT='0')
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), '--no-secondary', '--cpu-steps', '0', '--steps', '3', '--warmup', '1'],
@@ -451,7 +542,20 @@ def self_launch(args, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
     out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    rcs = [procs[0].returncode]
+    # rank 0 is back: the others finish with it (they share its barriers).  If it died before the rendezvous they would sit in the
+    # RCCL / gloo initialisation for minutes — give them a short grace period, then end exactly the processes started here
+    grace = 30 if procs[0].returncode == 0 else 5
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=grace))
+        except subprocess.TimeoutExpired:
+            p.terminate()
+            try:
+                rcs.append(p.wait(timeout=10))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                rcs.append(p.wait())
     lines = [l for l in (out0 or '').splitlines() if l.strip()]
     rec = next((l for l in reversed(lines) if l.startswith('{')), None)
     for l in lines:
@@ -468,8 +572,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--cpu-steps', type=int, default=8,
-                    help='sampler steps of the CPU-baseline sample, run 3 times (0 = skip; 100 = the full pass, ~1.5 min per run)')
+    ap.add_argument('--cpu-steps', type=int, default=25,
+                    help='sampler steps of the CPU-baseline sample, run 3 times (0 = skip; 100 = the full pass, ~1.5 min per run); the '
+                         'default of 25 keeps the extrapolation to 100 steps at x4')
     ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
                     help='arithmetic of the fused residual layers of the HEADLINE: f32 = configs[1] (default); bf16 = configs[2] (with --batch 64)')
     ap.add_argument('--batch', type=int, default=None, help='utterances per GPU of the headline (default: 16 at N=1, 64/N at N>1)')
@@ -545,6 +650,7 @@ def main():
             return full
         wl.step = step_fd
     dt, layer_ms, n_layer, mel = timed(wl, args.steps, args.warmup, fence)
+    clock = model.denoise_fn.clock_read()
     dt = max_over_ranks(dt)
     assert mel.shape == (B_total, T_FRAMES, N_MEL) and bool(torch.isfinite(mel).all())
     timeouts = model.denoise_fn.handoff_timeouts()
@@ -581,7 +687,7 @@ def main():
                                       if bf16 else 'fp32') + ', formula weights',
                        'global_batch': B_total, 'utterances_per_gpu': wl.b_local, 'frames_per_utt': T_FRAMES, 'diffusion_steps': N_DIFF_STEPS,
                        'parallelism': f'utterance-sharded x{world}, one RCCL all-gather of the mels per pass' if world > 1 else 'single GPU'},
-            'roofline': roofline(bf16, layer_ms, n_layer, args.steps, wl.b_local, model.denoise_fn.last_path()),
+            'roofline': roofline(bf16, layer_ms, n_layer, args.steps, wl.b_local, model.denoise_fn.last_path(), clock),
             'handoff_timeouts': timeouts,
         }
         if not bf16 and model.denoise_fn.last_path().startswith('stack_h2'):
@@ -596,12 +702,18 @@ def main():
             rec['weak_scaling'] = weak
         if world == 1 and not args.no_secondary and not bf16 and args.batch is None:
             rec['secondary'] = {'bf16_b64': secondary_bf16(model, device, fence), 'e2e_rtf_b1': secondary_e2e(model, device, fence),
+                                'cfg3_rank': secondary_cfg3_rank(model, device, fence),
+                                'captured_sampler': secondary_captured(model, device, fence),
                                 'f32_matrix_pipe': secondary_fp32_pipe()}
         if world == 1 and args.cpu_steps > 0:
             base, parity = cpu_baseline_and_parity(model, wl.inp_np, device, args.cpu_steps)
             rec['cpu_baseline'] = base
             rec['parity'] = parity
             rec['gpu_over_cpu'] = value / base['value']
+            # the same ratio against the CPU's FASTEST thread setting of the sweep (SURVEY §8d defines the baseline at one socket's
+            # physical cores, where PyTorch-CPU is not at its best on a many-core host): quote this one
+            if base.get('value_at_fastest_sweep_setting'):
+                rec['gpu_over_cpu_at_fastest_cpu_setting'] = value / base['value_at_fastest_sweep_setting']
             if not parity['ok']:
                 print(f'bench.py: PARITY FAILED {json.dumps(parity)}', file=sys.stderr)
                 rc = 1

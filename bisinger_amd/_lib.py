@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
 if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
     LIB_PATH = os.environ['BSG_LIB']
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class BsgError(RuntimeError):
@@ -70,11 +70,13 @@ _SIGS = {
     'bsg_mel_start': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_mel_finish': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_diffnet_last_path': (c_char_p, [c_void_p]),
+    'bsg_diffnet_clock_read': (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     'bsg_diffnet_debug_stack_stamps': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'bsg_diffnet_status': (c_int32, [c_void_p, POINTER(c_int32)]),
     'bsg_diffnet_set_compute': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_status_async': (c_int32, [c_void_p, c_void_p, c_void_p]),
     'bsg_diffnet_handoff_take': (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
+    'bsg_diffnet_health_take': (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
     'bsg_diffnet_uses_handoffs': (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32)]),
     'bsg_diffnet_set_split': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_debug_inject_giveup': (c_int32, [c_void_p, c_int32]),
@@ -129,6 +131,9 @@ def load():
 
 
 range_retries = 0      # calls repeated on the fp32 matrix pipe because an operand left the fp16 range of the split-fp16 GEMMs
+_range_depth = 0       # > 0 inside a range_guarded() call: nested entries leave the check to the outermost one
+_range_strikes = 0     # range events seen by this process; from RANGE_STRIKES_MAX on the GEMMs stay on the fp32 matrix pipe
+RANGE_STRIKES_MAX = 3
 
 
 def gemm_range_take():
@@ -136,6 +141,46 @@ def gemm_range_take():
     n = c_int32()
     check(load().bsg_gemm_range_events(ctypes.byref(n), 1, stream_ptr()), 'bsg_gemm_range_events')
     return n.value
+
+
+def gemm_range_peek():
+    """The same count without resetting it (a nested guard looks at it and leaves the take to the outermost one)."""
+    n = c_int32()
+    check(load().bsg_gemm_range_events(ctypes.byref(n), 0, stream_ptr()), 'bsg_gemm_range_events')
+    return n.value
+
+
+def range_guarded(run, what, on_retry=None):
+    """Every public entry that may enqueue split-fp16 products outside the residual stack (FS2 linears and fused attention, the
+    conditioner / input projections, HiFi-GAN's ResBlock pairs, PitchExtractor, the FFT denoiser) goes through here, so that an operand
+    beyond the fp16 range of the split (|v| >= 4094 after scaling: counted by the kernels, never clipped) cannot leave the call as a
+    silent NaN: the OUTERMOST guarded call waits for its stream once, and on an event moves every GEMM to the fp32 matrix pipe
+    (bsg_gemm_set_split(0)), warns and runs `run()` again (`on_retry()` first restores what run() consumed).  The split form comes
+    back for the next call — the event was a property of this input — until RANGE_STRIKES_MAX events have been seen in the process.
+    Inside a stream capture nothing can wait: the counter is left for the next guarded call (which then repeats its own work)."""
+    global _range_depth, range_retries, _range_strikes
+    import torch
+    if _range_depth > 0 or torch.cuda.is_current_stream_capturing():
+        return run()
+    _range_depth += 1
+    try:
+        out = run()
+        if gemm_range_take():
+            import warnings
+            warnings.warn(f'bisinger_amd: {what}: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4094); the call is '
+                          f'repeated with every GEMM on the fp32 matrix pipe')
+            check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
+            range_retries += 1
+            _range_strikes += 1
+            if on_retry is not None:
+                on_retry()
+            out = run()
+            gemm_range_take()
+            if _range_strikes < RANGE_STRIKES_MAX and os.environ.get('BSG_GEMM_SPLIT', '1') != '0':
+                check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
+    finally:
+        _range_depth -= 1
+    return out
 
 
 def declared_symbols():

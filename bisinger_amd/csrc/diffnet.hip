@@ -1067,6 +1067,7 @@ struct bsg_diffnet {
   unsigned* flags = nullptr;
   size_t flags_cap = 0;                // tiles the exchange array and the flags are sized for
   unsigned stack_epoch = 0;
+  unsigned long long* clk = nullptr;   // [4] s_memtime / s_memrealtime at the start and end of tile 0 of the last profiled stack launch
   int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
   int occ_stack43 = -1;                // the same for residual_stack_f43_kernel
   bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
@@ -1355,6 +1356,10 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       BSG_HIP(hipMemsetAsync(h->flags, 0, (need + 4) * sizeof(unsigned), st));
       BSG_HIP(hipMalloc((void**)&h->hx, 2 * need * 2 * C * 8 * sizeof(float)));
       h->flags_cap = need;
+      if (!h->clk) {
+        BSG_HIP(hipMalloc((void**)&h->clk, 4 * sizeof(unsigned long long)));
+        BSG_HIP(hipMemsetAsync(h->clk, 0, 4 * sizeof(unsigned long long), st));
+      }
     }
     const size_t tiles = (size_t)B * cdiv(T, 32);
     if (tiles > h->split_cap) {
@@ -1590,6 +1595,19 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
   return 0;
 }
 
+// flag values of one stack launch: fbase + layers published (L < 64)
+constexpr unsigned kFlagSpan = 64;
+// next launch epoch of the handle's flags; before the 32-bit flag values could come round to a slot that was last written long ago
+// (a large tile index after > 2^25 launches of smaller batches) the flags are zeroed, in stream order, and the epochs start again
+static int next_stack_epoch(bsg_diffnet* h, hipStream_t st, unsigned* fbase) {
+  if (++h->stack_epoch >= (1u << 25)) {
+    BSG_HIP(hipMemsetAsync(h->flags, 0, h->flags_cap * sizeof(unsigned), st));
+    h->stack_epoch = 1;
+  }
+  *fbase = h->stack_epoch * kFlagSpan;
+  return BSG_OK;
+}
+
 static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
                         unsigned long long* stamps = nullptr, const TailArgs* tail = nullptr) {
   const bool f43 = h->stack_is_f43, h2 = h->stack_is_h2;   // the decision of the stack_rows() call that returned rows_per_launch
@@ -1610,10 +1628,10 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.n_tiles = nb * tpr; p.cycle = h->cfg.dilation_cycle_length;
     BSG_REQUIRE((size_t)p.n_tiles <= h->flags_cap && h->L < 64, "stack launch: %d tiles exceed the exchange array (%zu)", p.n_tiles, h->flags_cap);
     p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
-    if (++h->stack_epoch == 0) h->stack_epoch = 1;
-    p.fbase = h->stack_epoch * 64u;
+    TRY(next_stack_epoch(h, st, &p.fbase));
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
+    p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
@@ -1681,8 +1699,7 @@ static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_unifo
     p.n_tiles = nb * tpr; p.cycle = h->cfg.dilation_cycle_length;
     BSG_REQUIRE((size_t)p.n_tiles <= h->flags_cap && h->L < 64, "bf16 stack launch: %d tiles exceed the exchange array (%zu)", p.n_tiles, h->flags_cap);
     p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
-    if (++h->stack_epoch == 0) h->stack_epoch = 1;
-    p.fbase = h->stack_epoch * 64u;
+    TRY(next_stack_epoch(h, st, &p.fbase));
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     TRY(launch_residual_stack_bf16(p, st));
@@ -1992,9 +2009,9 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
   BSG_REQUIRE(h && handoff_timeouts, "diffnet_status: null argument");
   *handoff_timeouts = 0;
   if (h->flags) {
-    unsigned v = 0;
-    BSG_HIP(hipMemcpy(&v, h->flags + h->flags_cap, sizeof(unsigned), hipMemcpyDeviceToHost));
-    *handoff_timeouts = (int32_t)v;
+    unsigned v[2] = {0, 0};   // word 0: hand-off give-ups, word 1: values beyond the fp16 range of the split-fp16 launch
+    BSG_HIP(hipMemcpy(v, h->flags + h->flags_cap, 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    *handoff_timeouts = (int32_t)(v[0] + v[1]);
   }
   if (h->split_flags) {
     unsigned v = 0;
@@ -2004,17 +2021,26 @@ extern "C" int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts) {
   return BSG_OK;
 }
 
+extern "C" int bsg_diffnet_health_take(bsg_diffnet* h, int32_t* counts, void* stream) {
+  BSG_REQUIRE(h && counts, "diffnet_health_take: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  counts[0] = counts[1] = 0;
+  unsigned v[3] = {0, 0, 0};
+  if (h->flags) BSG_HIP(hipMemcpyAsync(&v[0], h->flags + h->flags_cap, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (h->split_flags) BSG_HIP(hipMemcpyAsync(&v[2], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  BSG_HIP(hipStreamSynchronize(st));
+  if (v[0] | v[1]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap, 0, 2 * sizeof(unsigned), st));
+  if (v[2]) BSG_HIP(hipMemsetAsync(h->split_flags + 16 * h->split_cap, 0, sizeof(unsigned), st));
+  counts[0] = (int32_t)(v[0] + v[2]);
+  counts[1] = (int32_t)v[1];
+  return BSG_OK;
+}
+
 extern "C" int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeouts, void* stream) {
   BSG_REQUIRE(h && handoff_timeouts, "diffnet_handoff_take: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  *handoff_timeouts = 0;
-  unsigned v[2] = {0, 0};
-  if (h->flags) BSG_HIP(hipMemcpyAsync(&v[0], h->flags + h->flags_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  if (h->split_flags) BSG_HIP(hipMemcpyAsync(&v[1], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  BSG_HIP(hipStreamSynchronize(st));
-  if (v[0]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap, 0, sizeof(unsigned), st));
-  if (v[1]) BSG_HIP(hipMemsetAsync(h->split_flags + 16 * h->split_cap, 0, sizeof(unsigned), st));
-  *handoff_timeouts = (int32_t)(v[0] + v[1]);
+  int32_t c[2] = {0, 0};
+  TRY(bsg_diffnet_health_take(h, c, stream));
+  *handoff_timeouts = c[0] + c[1];
   return BSG_OK;
 }
 
@@ -2073,6 +2099,20 @@ extern "C" int bsg_diffnet_debug_stack_stamps(bsg_diffnet* h, int32_t t_uniform,
 }
 
 extern "C" const char* bsg_diffnet_last_path(bsg_diffnet* h) { return h ? h->last_path : "none"; }
+
+extern "C" int bsg_diffnet_clock_read(bsg_diffnet* h, double* shader_mhz, double* span_us) {
+  BSG_REQUIRE(h && shader_mhz && span_us, "diffnet_clock_read: null argument");
+  *shader_mhz = 0.0;
+  *span_us = 0.0;
+  if (!h->clk) return BSG_OK;
+  unsigned long long v[4] = {0, 0, 0, 0};
+  BSG_HIP(hipMemcpy(v, h->clk, sizeof(v), hipMemcpyDeviceToHost));
+  if (v[3] > v[1] && v[2] > v[0]) {
+    *span_us = (double)(v[3] - v[1]) / 100.0;            // s_memrealtime counts at 100 MHz
+    *shader_mhz = (double)(v[2] - v[0]) / *span_us;      // s_memtime counts shader clocks
+  }
+  return BSG_OK;
+}
 
 extern "C" int bsg_diffnet_profile(bsg_diffnet* h, int32_t enable) {
   BSG_REQUIRE(h, "diffnet_profile: null handle");

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
   if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
+  if (p.clk && tile_id == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll 1
   for (int l = 0; l < L; ++l) {
     const int dil = 1 << (l % p.cycle);
@@ -515,8 +516,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   }
 #undef STK_STAMP
   if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock: end of the last layer ...
+  if (p.clk && tile_id == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if constexpr (!TAIL) {
-    if (range_flag && lane == 0) atomicAdd(p.status, 1u);
+    if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);   // word 1: range events (word 0: hand-off give-ups)
     // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
     const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
     const float rdiv = 1.0f / sqrtf((float)L);
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
       }
     }
-    if (range_flag && lane == 0) atomicAdd(p.status, 1u);
+    if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);   // word 1: range events (word 0: hand-off give-ups)
     if (!a.do_head) return;
     // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded) ------------------------------------
     {

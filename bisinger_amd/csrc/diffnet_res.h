@@ -59,6 +59,7 @@ struct StackArgs {
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
+  unsigned long long* clk;      // null, or [4]: tile 0 stores s_memtime / s_memrealtime at its start and end (sustained shader clock, bench.py)
 };
 
 // bf16 stack launch: 64-frame tiles, one workgroup per CU (see diffnet_bf16.hip); grid = p.n_tiles rounded up to 8

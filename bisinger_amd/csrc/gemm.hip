@@ -586,9 +586,12 @@ int launch_fast(const GemmArgs& g, hipStream_t st) {
 static int g_split = -1;   // -1: not read yet (environment); set by bsg_gemm_set_split
 
 unsigned* gemm_range_counter() {
-  static unsigned* p = nullptr;   // (one device per process in this library's use; the symbol address is per device)
-  if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_gemm_range_events)) != hipSuccess) p = nullptr;
-  return p;
+  // the symbol lives once per device: cache its address per device id (the Python wrappers switch devices per call)
+  static unsigned* p[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!p[dev] && hipGetSymbolAddress((void**)&p[dev], HIP_SYMBOL(g_gemm_range_events)) != hipSuccess) p[dev] = nullptr;
+  return p[dev];
 }
 
 bool gemm_split_enabled() {

@@ -661,13 +661,15 @@ using hf16x4 = __attribute__((ext_vector_type(4))) _Float16;
 constexpr float HG_WSC = 256.0f, HG_ASC = 16.0f;
 
 // out[((((rt*K + k)*(C/16) + ks)*2 + plane)*64 + lane)*8 + j] = hi / lo of 2^8 W[co = 32 rt + (lane & 31)][ci = 16 ks + 8 (lane >> 5) + j][k]
-__global__ void pack_conv_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int C, int K) {
+// `bad` counts weights whose scaled value leaves the fp16 range (or is not finite): the handle then keeps the fp32-MFMA form
+__global__ void pack_conv_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int C, int K, unsigned* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * C * K) return;
   const int j = i & 7, lane = (i >> 3) & 63, rest = i >> 9;
   const int KS = C / 16;
   const int ks = rest % KS, k = (rest / KS) % K, rt = rest / (KS * K);
   const float v = w[((long long)(32 * rt + (lane & 31)) * C + 16 * ks + 8 * (lane >> 5) + j) * K + k] * HG_WSC;
+  if (!(fabsf(v) < 60000.0f)) atomicAdd(bad, 1u);
   const _Float16 hi = (_Float16)v;
   const long long base = ((((long long)(rt * K + k) * KS + ks) * 2) * 64 + lane) * 8 + j;
   out[base] = hi;
@@ -974,6 +976,10 @@ struct bsg_hifigan {
   std::vector<ConvW> noise_convs;
   size_t cap_src = 0;
   float *sw_tmp = nullptr, *har = nullptr;
+  // split-fp16 pairs: weights are packed as hi + lo fp16 of 2^8 w at create; w_range_bad (device) counts weights beyond that range, and
+  // h2_ok says whether the packed form may be used (else the fp32-MFMA pairs: never a clipped weight)
+  unsigned* w_range_bad = nullptr;
+  bool h2_ok = true;
 };
 
 extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
@@ -1026,7 +1032,8 @@ static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st, bool pair = false
       hipLaunchKernelGGL(pack_conv_mfma_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, c.wpm, c.cout, c.k);
       BSG_LAUNCH_CHECK();
       TRY(hg_alloc(h, &c.wps, m));
-      hipLaunchKernelGGL(pack_conv_h2_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, reinterpret_cast<_Float16*>(c.wps), c.cout, c.k);
+      hipLaunchKernelGGL(pack_conv_h2_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, reinterpret_cast<_Float16*>(c.wps), c.cout, c.k,
+                         h->w_range_bad);
       BSG_LAUNCH_CHECK();
     }
   }
@@ -1089,6 +1096,12 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   int rc = BSG_OK;
   auto fail = [&](int code) { bsg_hifigan_destroy(h); return code; };
   const int C0 = cfg->upsample_initial_channel;
+  {
+    float* cnt = nullptr;
+    if ((rc = hg_alloc(h, &cnt, 1)) != BSG_OK) return fail(rc);
+    h->w_range_bad = reinterpret_cast<unsigned*>(cnt);
+    if (hipMemsetAsync(h->w_range_bad, 0, sizeof(unsigned), st) != hipSuccess) { set_error("hifigan_create: memset failed"); return fail(BSG_EHIP); }
+  }
   if (cfg->use_nsf) {
     // m_source.l_linear.{weight [1,NH], bias [1]}, noise_convs.i.{weight [c,1,k], bias [c]} precede conv_pre (hifigan.py:111-132)
     const int NH = cfg->harmonic_num + 1;
@@ -1138,6 +1151,11 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   if ((rc = take_conv(h, h->post, w, 1, h->post.cin * 7, st)) != BSG_OK) return fail(rc);
   if ((rc = pack_conv(h, h->post, st)) != BSG_OK) return fail(rc);
   if (hipStreamSynchronize(st) != hipSuccess) { set_error("hifigan_create: stream sync failed"); return fail(BSG_EHIP); }
+  {
+    unsigned nbad = 0;
+    if (hipMemcpy(&nbad, h->w_range_bad, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hifigan_create: copy failed"); return fail(BSG_EHIP); }
+    h->h2_ok = nbad == 0;   // a ResBlock weight with |w| * 2^8 >= 60000 (or not finite): the pairs stay on the fp32 matrix pipe
+  }
   *out = h;
   return BSG_OK;
 }
@@ -1239,7 +1257,7 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
           pa.slope = slope; pa.L = L; pa.dil = c.resblock_dilations[j][m];
           static int h2_env = -1;   // BSG_HG_SPLIT=0: the fp32-MFMA form even while the GEMMs run split-fp16
           if (h2_env < 0) { const char* e = getenv("BSG_HG_SPLIT"); h2_env = e ? atoi(e) : 1; }
-          if (use_mfma && h2_env && c1.wps && c2.wps && gemm_split_enabled()) {
+          if (use_mfma && h2_env && h->h2_ok && c1.wps && c2.wps && gemm_split_enabled()) {
             pa.w1 = c1.wps; pa.w2 = c2.wps; pa.range_events = gemm_range_counter();
             TRY(launch_pair_h2(pa, c1.k, c1.cout, B, st));
           } else if (use_mfma) {

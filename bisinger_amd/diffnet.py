@@ -133,6 +133,7 @@ class DiffNet(nn.Module):
         """False: this handle's residual stack multiplies on the fp32 matrix pipe only (Winograd kernels: channel-split launches at small
         batch, F(4,3) stack launch when it fills the chip, per-layer launches otherwise) — what BSG_H2=0 does for the whole process."""
         _lib.check(_lib.load().bsg_diffnet_set_h2(self.handle(), int(bool(enable))), 'bsg_diffnet_set_h2')
+        self._h2_range_off = False
 
     def release(self):
         if self._h is not None:
@@ -148,6 +149,9 @@ class DiffNet(nn.Module):
     def prepare(self, cond):
         """Bind ``cond`` [B,H,T]: hoists every layer's conditioner projection out of the step loop."""
         h = self.handle()
+        if getattr(self, '_h2_range_off', False):       # a range event of the split-fp16 launch was a property of the previous condition
+            _lib.check(_lib.load().bsg_diffnet_set_h2(h, 1), 'bsg_diffnet_set_h2')
+            self._h2_range_off = False
         cond = cond.contiguous().float()
         B, H, T = cond.shape
         assert H == self.encoder_hidden
@@ -193,51 +197,86 @@ class DiffNet(nn.Module):
         return bool(u.value)
 
     def take_handoff_timeouts(self):
-        """Wait for the current stream; return (and reset) the number of hand-off spins that gave up since the last take."""
+        """Wait for the current stream; return (and reset) the number of hand-off spins that gave up since the last take
+        (plus range events of the split-fp16 launch)."""
+        give, rng = self.take_health()
+        return give + rng
+
+    def take_health(self):
+        """Wait for the current stream; (hand-off spins that gave up, values beyond the fp16 range seen by the split-fp16 stack launch)
+        since the last take; resets both."""
         from ctypes import c_int32
-        n = c_int32()
-        _lib.check(_lib.load().bsg_diffnet_handoff_take(self._h, byref(n), _lib.stream_ptr()), 'bsg_diffnet_handoff_take')
-        return n.value
+        c = (c_int32 * 2)()
+        _lib.check(_lib.load().bsg_diffnet_health_take(self._h, c, _lib.stream_ptr()), 'bsg_diffnet_health_take')
+        return c[0], c[1]
+
+    CLEAN_CALLS_TO_REENABLE = 32     # guarded calls without a give-up after which a demoted handle tries hand-off launches again
 
     def guarded(self, run, B, T, restore=None):
-        """Run ``run()`` (which enqueues evaluations on this handle) so that an invalid result never leaves the call: if a
-        workgroup of a split launch gave up waiting for its partner (a partner not resident: the GPU shared with another
-        process), split launches are switched off for this handle — one workgroup per tile, no hand-offs — and the work is
-        run again (``restore()`` first puts back inputs that run() modified in place).  Costs one stream synchronisation
-        per call, and only for launch shapes that use hand-offs at all; never inside a stream capture."""
-        run()
-        if torch.cuda.is_current_stream_capturing() or not self.uses_handoffs(B, T):
+        """Run ``run()`` (which enqueues evaluations on this handle) so that an invalid result never leaves the call.  Three events are
+        told apart, each detected on the device and healed here before anything is returned (``restore()`` first puts back inputs that
+        run() modified in place); one stream synchronisation per call, none inside a stream capture (a captured call cannot wait, and
+        runs the kernels that need no guard: per-layer launches of the fp32 matrix pipe):
+          * an operand of a split-fp16 GEMM (input / conditioner projections) left the fp16 range -> _lib.range_guarded: every GEMM on
+            the fp32 matrix pipe, the bound condition projected again, the work repeated.  Read on EVERY path, also for launch shapes
+            without hand-offs; nested in an outer guarded call (GaussianDiffusion.forward, which also has to repeat FS2) it is left to it;
+          * a value beyond the fp16 range inside the split-fp16 stack launch (|x + d| >= 60000) -> this handle runs the kernels of the
+            fp32 matrix pipe until the next prepare() (the event is a property of the bound input), and the work is repeated;
+          * a workgroup gave up waiting for its neighbour (not resident: the GPU is shared with another process) -> hand-off launches
+            off for this handle (one workgroup per tile), the work repeated; they are tried again after CLEAN_CALLS_TO_REENABLE clean calls."""
+        if torch.cuda.is_current_stream_capturing():
+            run()
             return
-        n = self.take_handoff_timeouts()
-        if _lib.gemm_range_take():
-            # an operand of a split-fp16 GEMM (input / conditioner projections, FS2) left the fp16 range: every GEMM moves to the fp32
-            # matrix pipe, the bound condition is projected again and the work repeated; a caller that produced `cond` with those GEMMs
-            # (GaussianDiffusion.forward) sees _lib.range_retries change and repeats its own part
-            import warnings
-            warnings.warn('bisinger_amd: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4094); GEMMs now run on the fp32 '
-                          'matrix pipe and the evaluation is repeated')
-            _lib.check(_lib.load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
-            _lib.range_retries += 1
+
+        def again():
             if self._bound is not None:
                 self.prepare(self._bound[0])
             if restore is not None:
                 restore()
-            run()
-            n = self.take_handoff_timeouts()
-        if n == 0:
-            return
+        _lib.range_guarded(lambda: self._guarded_handoffs(run, B, T, restore), 'DiffNet', on_retry=again)
+
+    def _guarded_handoffs(self, run, B, T, restore):
         import warnings
-        warnings.warn(f'bisinger_amd: {n} inter-workgroup hand-offs gave up (a partner workgroup was not resident) or an activation '
-                      f'left the fp16 range of the split-fp16 launch; channel-split and stack launches are now off for this DiffNet '
-                      f'handle (per-layer launches on the fp32 matrix pipe) and the evaluation is repeated')
+        run()
+        if not self.uses_handoffs(B, T):
+            return
+        give, rng = self.take_health()
+        if not give and not rng:
+            if getattr(self, 'split_disabled', False):
+                self._clean_calls = getattr(self, '_clean_calls', 0) + 1
+                if self._clean_calls >= self.CLEAN_CALLS_TO_REENABLE:
+                    _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
+                    self.split_disabled, self._clean_calls = False, 0
+            return
+        if rng and not give and _lib.gemm_range_peek():
+            # the launch saw huge / non-finite values BECAUSE a GEMM above it (condition or input projection) left its range: not this
+            # handle's fault — the GEMM guard around this call repeats everything on the fp32 matrix pipe
+            return
+        if rng and not give:
+            warnings.warn(f'bisinger_amd: {rng} waves of the split-fp16 stack launch saw an activation beyond its fp16 range (|x + d| >= '
+                          f'60000); this DiffNet handle runs the kernels of the fp32 matrix pipe for this condition and the evaluation '
+                          f'is repeated')
+            _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
+            self._h2_range_off = True
+            if restore is not None:
+                restore()
+            run()
+            if not self.uses_handoffs(B, T):
+                return
+            give, rng = self.take_health()
+            if not give:
+                return
+        warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up (a partner workgroup was not resident); channel-split and '
+                      f'stack launches are off for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (per-layer launches '
+                      f'on the fp32 matrix pipe) and the evaluation is repeated')
         _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
-        self.split_disabled = True
+        self.split_disabled, self._clean_calls = True, 0
         if restore is not None:
             restore()
         run()
-        n = self.take_handoff_timeouts()
-        if n:
-            raise _lib.BsgError(f'{n} inter-workgroup hand-offs gave up with split launches off: the result is invalid')
+        give, rng = self.take_health()
+        if give or rng:
+            raise _lib.BsgError(f'{give + rng} inter-workgroup hand-offs gave up with split launches off: the result is invalid')
 
     def debug_inject_giveup(self, n_launches):
         """Fault injection (tests): the next ``n_launches`` channel-split launches give up their hand-offs without waiting."""
@@ -257,6 +296,13 @@ class DiffNet(nn.Module):
         n = c_int32()
         _lib.check(_lib.load().bsg_diffnet_status(self._h, byref(n)), 'bsg_diffnet_status')
         return n.value
+
+    def clock_read(self):
+        """-> (shader MHz held over the last profiled stack launch, its in-kernel span in us); (0, 0) when none ran.  Synchronises."""
+        from ctypes import c_double
+        mhz, span = c_double(), c_double()
+        _lib.check(_lib.load().bsg_diffnet_clock_read(self._h, byref(mhz), byref(span)), 'bsg_diffnet_clock_read')
+        return mhz.value, span.value
 
     def profile_read(self):
         """-> (summed device ms of the recorded residual-layer chains, number of layer launches covered)."""

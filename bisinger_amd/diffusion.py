@@ -133,18 +133,12 @@ class GaussianDiffusion(nn.Module):
                         nz = None if noise is None else noise[k].contiguous()
                         _lib.check(lib.bsg_ddpm_step(_lib.ptr(x), _lib.ptr(eps.contiguous()), _lib.ptr(nz), byref(s), i, x.numel(), seed,
                                                      row0 * M * T, _lib.stream_ptr()), 'bsg_ddpm_step')
-            loop()
             # this denoiser is GEMMs only: the range guard of the split-fp16 GEMMs (an operand beyond the fp16 range is counted, not
             # clipped) is read once per call; on an event every GEMM moves to the fp32 matrix pipe and the loop is repeated from x_T
-            if not capturing and _lib.gemm_range_take():
-                import warnings
-                warnings.warn('bisinger_amd: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4094); GEMMs now run on the '
-                              'fp32 matrix pipe and the sampler loop is repeated')
-                _lib.check(lib.bsg_gemm_set_split(0), 'bsg_gemm_set_split')
-                _lib.range_retries += 1
+            def again():
                 x.copy_(keep)
                 self.denoise_fn.prepare(cond)
-                loop()
+            _lib.range_guarded(loop, 'FFT denoiser sampler loop', on_retry=None if capturing else again)
             return x
         n = t if n_steps is None else n_steps
         if noise is not None:
@@ -159,9 +153,9 @@ class GaussianDiffusion(nn.Module):
                 else:
                     _lib.check(lib.bsg_ddpm_sample(h, byref(s), _lib.ptr(x), _lib.ptr(noise), seed, t - 1, n, B, T, row0,
                                                    B if B_total is None else B_total, _lib.stream_ptr()), 'bsg_ddpm_sample')
-        # the loop updates x in place: keep x_T (B*M*T floats, small-batch shapes only) so that the call can repeat itself
-        # without split launches if a hand-off gave up — an invalid x never leaves this function
-        keep = x.clone() if (self.denoise_fn.uses_handoffs(B, T) and not torch.cuda.is_current_stream_capturing()) else None
+        # the loop updates x in place: keep x_T (B*M*T floats) so that the call can repeat itself — without hand-off launches if a
+        # workgroup gave up, on the fp32 matrix pipe if a value left the fp16 range — and an invalid x never leaves this function
+        keep = None if torch.cuda.is_current_stream_capturing() else x.clone()
         self.denoise_fn.guarded(run, B, T, restore=None if keep is None else (lambda: x.copy_(keep)))
         return x
 
@@ -202,13 +196,10 @@ class GaussianDiffusion(nn.Module):
         have len(rows) rows and reproduce the same rows of the unsharded call — SURVEY.md §8e)."""
         if not infer:
             raise NotImplementedError('training (p_losses) is outside the accelerated hot path (SURVEY.md §8)')
-        # range guard of the split-fp16 GEMMs: when the sampler's guard had to move the GEMMs to the fp32 matrix pipe (an operand beyond
-        # the fp16 range; bisinger_amd/diffnet.py guarded), FS2 above it ran with the same GEMMs: repeat the whole call once
-        retries = _lib.range_retries
-        ret = self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs)
-        if _lib.range_retries != retries:
-            ret = self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs)
-        return ret
+        # one range guard around the whole call (FS2, the conditioner projections, the sampler): an operand beyond the fp16 range of the
+        # split-fp16 GEMMs repeats all of it on the fp32 matrix pipe (_lib.range_guarded; the nested guards leave the check to this one)
+        return _lib.range_guarded(lambda: self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows,
+                                                              **kwargs), 'GaussianDiffusion.forward')
 
     def _forward_infer(self, txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs):
         B_total = txt_tokens.shape[0]

@@ -328,6 +328,10 @@ class FastSpeech2MIDI(nn.Module):
                 skip_decoder=False, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, rows=None, **kwargs):
         """``rows`` (slice, extension): decode only these batch rows — the token-level front still sees the whole
         batch, which is what keeps a sharded run identical to the unsharded reference."""
+        return _lib.range_guarded(lambda: self._forward(txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs),
+                                  'FastSpeech2MIDI.forward')
+
+    def _forward(self, txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs):
         ret = {}
         enc = self.encode(txt_tokens, spk_embed, predict_dur=mel2ph is None, **kwargs)
         if mel2ph is None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSG_ABI_VERSION 3
+#define BSG_ABI_VERSION 4
 
 #define BSG_OK 0
 #define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
@@ -161,6 +161,11 @@ int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream)
  * bsg_diffnet_set_split(h, 0) makes the handle use one-workgroup-per-tile launches only (no hand-offs): the caller's
  * recovery after a non-zero take is set_split(0) + re-running the evaluation, which then cannot give up. */
 int bsg_diffnet_handoff_take(bsg_diffnet* h, int32_t* handoff_timeouts, void* stream);
+/* The same take with the two causes apart (ABI v4): counts[0] = hand-off spins that gave up (a partner workgroup was not resident:
+ * recovery = bsg_diffnet_set_split(h, 0)); counts[1] = values beyond the fp16 range seen by the split-fp16 stack launch (data, not
+ * residency: recovery = bsg_diffnet_set_h2(h, 0), the fp32-matrix-pipe kernels, for this input only).  Waits for `stream`; resets both.
+ * bsg_diffnet_handoff_take returns their sum. */
+int bsg_diffnet_health_take(bsg_diffnet* h, int32_t* counts, void* stream);
 int bsg_diffnet_uses_handoffs(bsg_diffnet* h, int32_t B, int32_t T, int32_t* uses);
 int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable);
 /* Fault injection for tests: in the next n_launches channel-split (or stack) launches on the handle the consumers give up every
@@ -171,6 +176,10 @@ int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches);
  * stream on chip), "layer" (one launch per layer, one workgroup per tile), "split2" / "split4" (a tile as 2 / 4 workgroups),
  * "wide" (one 16-wave workgroup per tile), "bf16", or "none".  Static string. */
 const char* bsg_diffnet_last_path(bsg_diffnet* h);
+/* Shader clock the chip held over the last PROFILED stack launch (bsg_diffnet_profile on): tile 0 of the launch stores s_memtime (shader
+ * clocks) and s_memrealtime (100 MHz) at its start and end; shader_mhz = their ratio, span_us = the launch's in-kernel span.  Synchronous
+ * copy; 0 when no profiled stack launch has run (ABI v4). */
+int bsg_diffnet_clock_read(bsg_diffnet* h, double* shader_mhz, double* span_us);
 
 /* Diagnostic run of the stack launch on whatever h->xa holds (timing only): the L layers of the bound batch (which must fit one
  * launch) at timestep t_uniform, with s_memrealtime (100 MHz) stamps per tile and layer at

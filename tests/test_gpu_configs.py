@@ -107,3 +107,40 @@ def test_config2_bf16_full_size_vs_emulating_oracle():
     # statistical: closer (rms) to the emulation than the emulation is to fp32, and a max-abs of the same order as the
     # roundings' own — a wrong tile, tap or channel order shows as O(eps rms) = 0.1
     assert rms <= rms_q and e <= 2.0 * q and e <= 0.1 * rms_eps
+
+
+def test_config3_rank_rows_of_64():
+    """BASELINE configs[3] as ONE rank sees it (B_total = 64 utterances sharded 8 per GPU over 8 GPUs): the token-level front
+    (embeddings, ESM over the batch axis — common_layers.py:848-860 — and the encoder) runs on all 64 rows, the frame-level part and the
+    100-step sampler on this rank's rows 8..15 only (shallow_diffusion_tts.py:230-273 with rows=slice(8, 16)).
+      * against the same rows of the UNSHARDED B=64 run on this GPU (the 8-row shard takes 32-frame tiles, the unsharded run 64-frame
+        tiles in four launch groups: another summation order of the same sums): <= 1e-5 of the de-normalised mel;
+      * against the CPU oracle with the full-batch front and the same supplied noise: <= 1e-3 (north_star's bar)."""
+    from oracle import fs2 as ofs2
+    B, T, Tt = 64, 1000, 100
+    rows = slice(8, 16)
+    c = dict(CFG0, B=B, T=T, T_txt=Tt)
+    model = build_model(c)
+    inp = synth.synth_inputs(B, Tt, T, seed=3)
+    noise = synth.synth_noise(100, B, 80, T, seed=3)
+    d = {k: T_(v).cuda() for k, v in inp.items()}
+    kw = {k: d[k] for k in KEYS}
+    nz = T_(noise).cuda()
+    full = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True, noise=nz, **kw)['mel_out'].clone()
+    path_full = model.denoise_fn.last_path()
+    part = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True, noise=nz, rows=rows, **kw)
+    path_part = model.denoise_fn.last_path()
+    torch.cuda.synchronize()
+    assert part['mel_out'].shape == (8, T, 80) and full.shape == (B, T, 80)
+    dev_shard = maxabs(part['mel_out'], full[rows])
+    sd = cpu_sd(model)
+    inp_t = {k: T_(v) for k, v in inp.items()}
+    fs2_out = ofs2.fs2_forward(sd, inp_t, 'fs2.', rows=rows)          # the front on 64 rows, the decoder on rows 8..15
+    want = omg.mel_gen(sd, dict(inp_t, mel2ph=inp_t['mel2ph'][rows]), T_(noise[:, rows]), fs2_out=fs2_out)
+    dev = maxabs(part['mel_out'], want['mel_out'])
+    dci = maxabs(part['decoder_inp'], want['decoder_inp'])
+    print(f'configs[3] rank (rows 8..15 of B=64, T=1000, 100 steps; launch forms {path_part} / unsharded {path_full}): vs the same rows of the '
+          f'unsharded run {dev_shard:.3e}; vs the oracle with the 64-row front {dev:.3e} (decoder_inp {dci:.3e})')
+    assert dev_shard <= 1e-5
+    assert dev <= 1e-3 and dci <= 1e-3
+    assert model.denoise_fn.handoff_timeouts() == 0

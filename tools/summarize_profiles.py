@@ -20,6 +20,11 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:      # source digest of the library the passes ran on (bisinger_amd/build.py): bench.py compares it with the build it times
+    BUILD = open(os.path.join(ROOT, 'bisinger_amd', 'lib', 'build.sha256')).read().strip()
+except OSError:
+    BUILD = None
 
 
 def short(name):
@@ -97,7 +102,7 @@ for cfg in ('f32', 'bf16', 'voc'):
             frames = batch_frames * 2000 // max(n, 1)     # one pass = 100 steps x 20 layers; more launches = half-batch chains
             alg_form = (4 if cfg == 'bf16' else 6) * 256 * 4 * frames
         alg = (4 if cfg == 'bf16' else 6) * 256 * 4 * frames   # one fused kernel per layer
-        summ['traffic'] = {'kernel': dom, 'path': path, 'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg,
+        summ['traffic'] = {'kernel': dom, 'path': path, 'build_sha256': BUILD, 'frames_per_launch': frames, 'algorithmic_bytes_per_launch': alg,
                            'algorithmic_bytes_of_this_form': alg_form,
                            'residual_layer_kernel_hbm_bytes_per_launch': by,
                            'traffic_over_algorithmic': round(by / alg, 3),
@@ -106,4 +111,7 @@ for cfg in ('f32', 'bf16', 'voc'):
                            'condition': 'solo launch (PMC passes serialise kernels)'}
         break
     json.dump(summ, open(f'{dst}/bench_{cfg}_pmc_summary.json', 'w'), indent=1)
+    if 'traffic' in summ and cfg in ('f32', 'bf16'):   # what bench.py reads (profiles/traffic.json, profiles/traffic_bf16.json)
+        json.dump(dict(summ['traffic'], source=f'bench_{cfg}_pmc_summary.json of the same passes (tools/run_profiles.sh)'),
+                  open(f'{dst}/traffic' + ('_bf16' if cfg == 'bf16' else '') + '.json', 'w'), indent=1)
     print(cfg, json.dumps(summ.get('traffic', {k: v for k, v in list(per_kernel.items())[:3]}), indent=1)[:1500])
