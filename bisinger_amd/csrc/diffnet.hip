@@ -1634,6 +1634,11 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
+      static int fsh = -1, ft1 = -1, ft2 = -1;   // BSG_H2_FAIR_SHIFT / _TAIL1 / _TAIL2 (StackArgs::fair_*)
+      if (fsh < 0) { const char* e = getenv("BSG_H2_FAIR_SHIFT"); fsh = e ? atoi(e) : 12; if (fsh < 6 || fsh > 20) fsh = 12; }
+      if (ft1 < 0) { const char* e = getenv("BSG_H2_FAIR_TAIL1"); ft1 = e ? atoi(e) : 0; }
+      if (ft2 < 0) { const char* e = getenv("BSG_H2_FAIR_TAIL2"); ft2 = e ? atoi(e) : 0; }
+      p.fair_shift = fsh; p.fair_tail1 = ft1; p.fair_tail2 = ft2;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
         TailArgs a = *tail;
         const size_t mo = (size_t)r0 * h->M * T;

@@ -125,7 +125,7 @@ __device__ __forceinline__ int kmap(int i) {
 // FAIRB: the two waves of a SIMD take turns at issue priority (see f43_gemm1, diffnet_f43.hip).
 template <int ROT, bool FAIRB, int NCT, typename LDB, typename MID>
 __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT], f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
-                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
+                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half, int fshift, int ftail) {
   // c0[ct] / c1[ct]: row tile 0 / 1 x column tile ct.  B[..][2 ct] = hi, [2 ct + 1] = lo of column tile ct
   f16x8 B[2][2 * NCT];
   ldb(kmap<ROT>(0), B[0]);
@@ -133,9 +133,14 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += NSH) {
     if (FAIRB) {
-      const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
-      if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(0);
+      if (ks >= n_ks - ftail) {   // final stretch: waves 0..3 first (they reach the VALU phase behind this GEMM `ftail` k-steps early)
+        if (half == 0) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+      } else {
+        const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+        if (((tnow >> fshift) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+      }
     }
     if (ROT > 0 && ks == ROT) {
       mid();
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         __syncthreads();   // (A) halo rows in place
         STK_STAMP(2);
       };
-      mfma_pipe_h2<16, FAIRB, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
+      mfma_pipe_h2<16, FAIRB, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2, p.fair_shift, p.fair_tail1);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB + ZP);
         }
       };
-      mfma_pipe_h2<0, FAIRB, NCT>(yg, yf, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
+      mfma_pipe_h2<0, FAIRB, NCT>(yg, yf, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2, p.fair_shift, p.fair_tail2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (l + 1 < L) prefetch_a1(l + 1);

@@ -58,6 +58,10 @@ struct StackArgs {
   int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
+  // split-fp16 launch, issue priority between the two waves of a SIMD (FAIRB): slices of 2^fair_shift shader clocks taken in turns, and
+  // for the last fair_tail1 / fair_tail2 k-steps of GEMM1 / GEMM2 strict priority for waves 0..3 — they finish that many k-steps
+  // ahead of their SIMD partners and run their VALU phase (gate; x update + image) under the partners' last MFMAs
+  int fair_shift, fair_tail1, fair_tail2;
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
   unsigned long long* clk;      // null, or [4]: tile 0 stores s_memtime / s_memrealtime at its start and end (sustained shader clock, bench.py)
 };

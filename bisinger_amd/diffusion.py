@@ -221,7 +221,9 @@ class GaussianDiffusion(nn.Module):
             noise = noise.to(cond.device, torch.float32)
             if rows is not None and noise.shape[1] == B_total:
                 noise = noise[:, rows]
-            draw0, steps = noise[0][:, None].contiguous(), noise[1:]
+            # x_T is updated in place by the sampler: it must be a COPY — `noise` may be the caller's own device tensor (.to() and the
+            # row slice are views), and a second call with the same tensor would start from the first call's result
+            draw0, steps = noise[0][:, None].clone(memory_format=torch.contiguous_format), noise[1:]
         else:
             off = row0 * M * T
             draw0 = self.philox_normal((B, 1, M, T), cond.device, seed, 0, off)
