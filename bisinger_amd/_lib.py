@@ -153,7 +153,7 @@ def gemm_range_peek():
 def range_guarded(run, what, on_retry=None):
     """Every public entry that may enqueue split-fp16 products outside the residual stack (FS2 linears and fused attention, the
     conditioner / input projections, HiFi-GAN's ResBlock pairs, PitchExtractor, the FFT denoiser) goes through here, so that an operand
-    beyond the fp16 range of the split (|v| >= 4094 after scaling: counted by the kernels, never clipped) cannot leave the call as a
+    beyond the fp16 range of the split (|v| >= 4062 after scaling: counted by the kernels, never clipped) cannot leave the call as a
     silent NaN: the OUTERMOST guarded call waits for its stream once, and on an event moves every GEMM to the fp32 matrix pipe
     (bsg_gemm_set_split(0)), warns and runs `run()` again (`on_retry()` first restores what run() consumed).  The split form comes
     back for the next call — the event was a property of this input — until RANGE_STRIKES_MAX events have been seen in the process.
@@ -167,7 +167,7 @@ def range_guarded(run, what, on_retry=None):
         out = run()
         if gemm_range_take():
             import warnings
-            warnings.warn(f'bisinger_amd: {what}: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4094); the call is '
+            warnings.warn(f'bisinger_amd: {what}: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4062); the call is '
                           f'repeated with every GEMM on the fp32 matrix pipe')
             check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
             range_retries += 1

@@ -1395,8 +1395,7 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
 }
 
 // GEMM1 of the residual block: BSG_WINO unset = 2: Winograd F(2,3) kernels, and the F(4,3) stack launch (diffnet_f43.hip) for launches
-// that fill the chip with 64-frame tiles (stack_rows); 1: F(2,3) only; 43: F(4,3) wherever it applies (stack launch, else the per-layer
-// F(4,3) kernel for launches that are not channel-split); 0: the direct K=768 form
+// that fill the chip with 64-frame tiles (stack_rows; BSG_STACK43=2: for any shape); 1: F(2,3) only; 0: the direct K=768 form
 static int wino_env() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("BSG_WINO"); v = e ? atoi(e) : 2; }
@@ -1504,11 +1503,6 @@ static int launch_layer(bsg_diffnet* h, int layer, const float* x_in, const long
     if (ext) TRY(quad_bf16_to_f32(h->skip_h, skip, B, C, T, st));
     return BSG_OK;
   }
-  if (wino_env() == 43) {
-    TRY(launch_residual_layer_f43(a, st));
-    h->last_path = "layer_f43";
-    return BSG_OK;
-  }
   // 32-frame tiles: 48 KB of LDS -> 3 workgroups per CU.  (Wider tiles of 64 / 128 frames were built and
   // measured in round 1: 0-50 % slower at every batch size, because fewer workgroups per CU hide less of the
   // L2 latency of the weight stream.)
@@ -1569,7 +1563,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       }
     }
   }
-  if (wino_env() == 43 || wino_env() == 2) {
+  if (wino_env() == 2) {
     // F(4,3) form (diffnet_f43.hip): 64-frame tiles, one workgroup per CU, whole rows per launch group; BSG_STACK43=0 keeps per-layer
     // launches.  A launch group takes the same time whatever part of the chip it fills, so the form is taken when the groups are
     // >= 90 % full (B = 15, 16, 29..32, .. at T = 1000): it is ~6 % faster than two chains of per-layer F(2,3) launches, not more.
@@ -1590,7 +1584,6 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
         }
       }
     }
-    if (wino_env() == 43) return 0;
   }
   return 0;
 }
@@ -1634,11 +1627,6 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
-      static int fsh = -1, ft1 = -1, ft2 = -1;   // BSG_H2_FAIR_SHIFT / _TAIL1 / _TAIL2 (StackArgs::fair_*)
-      if (fsh < 0) { const char* e = getenv("BSG_H2_FAIR_SHIFT"); fsh = e ? atoi(e) : 12; if (fsh < 6 || fsh > 20) fsh = 12; }
-      if (ft1 < 0) { const char* e = getenv("BSG_H2_FAIR_TAIL1"); ft1 = e ? atoi(e) : 0; }
-      if (ft2 < 0) { const char* e = getenv("BSG_H2_FAIR_TAIL2"); ft2 = e ? atoi(e) : 0; }
-      p.fair_shift = fsh; p.fair_tail1 = ft1; p.fair_tail2 = ft2;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
         TailArgs a = *tail;
         const size_t mo = (size_t)r0 * h->M * T;

@@ -889,8 +889,7 @@ int launch_step_tail_bf16(const TailArgs& a_in, hipStream_t st) {
 int stack_bf16_occupancy() {
   const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel<true>, 512, lds) != hipSuccess)
     return 0;
   return o;
@@ -898,10 +897,7 @@ int stack_bf16_occupancy() {
 
 int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st) {
   const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
-  static int fair = -1;
-  if (fair < 0) { const char* e = getenv("BSG_BF16_FAIR"); fair = e ? atoi(e) : 1; }
-  if (fair) hipLaunchKernelGGL(residual_stack_bf16_kernel<true>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
-  else hipLaunchKernelGGL(residual_stack_bf16_kernel<false>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(residual_stack_bf16_kernel<true>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

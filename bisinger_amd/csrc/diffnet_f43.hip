@@ -243,238 +243,17 @@ __device__ __forceinline__ void f43_prefetch(f32x4 (&AW)[2][2][4], const rsrc_t 
   }
 }
 
-#define F43_STAMP(i)                                                                                   \
-  do {                                                                                                 \
-    if (STAMP) {                                                                                       \
-      __builtin_amdgcn_sched_barrier(0);                                                               \
-      const unsigned long long _t = __builtin_amdgcn_s_memtime();                                      \
-      __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
-      if (lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + (i)] = _t;                      \
-      __builtin_amdgcn_sched_barrier(0);                                                               \
-    }                                                                                                  \
-  } while (0)
-
-template <bool STAMP, int DBG = 0>   // STAMP: diagnostic build with s_memtime stamps at the phase boundaries (tools/stamp_layer.py); DBG (timing
-                                     // experiments, wrong results): 1 = no weight refills, 2 = no raw reads / transform in GEMM1
-__global__ __launch_bounds__(512, 2) void residual_layer_f43_kernel(ResArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;   // x + d_l, frames t0-8 .. t0+71, zero outside [0, T); layout below (stage)
-  float* zs = lds;   // [C][64]: gated activation; aliases xs after the barrier that ends GEMM1
-
-  const int n_tiles = a.B * a.tiles_per_row, per_xcd = (n_tiles + 7) >> 3;
-  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);   // XCD-aware order, as residual_layer_kernel
-  if (tile_id >= n_tiles) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int b = tile_id / a.tiles_per_row;
-  const int t0 = (tile_id - b * a.tiles_per_row) * NT6;
-  const int T = a.T;
-  const int tb = a.t_dev ? (int)a.t_dev[b] : a.t_uniform;
-
-  const unsigned plane = (unsigned)C * T * 4;
-  const rsrc_t rs_x = mk_rsrc(a.x_in + (long long)b * C * T, plane);
-  const rsrc_t rs_xo = mk_rsrc(a.x_out + (long long)b * C * T, plane);
-  const rsrc_t rs_sk = mk_rsrc(a.skip + (long long)b * C * T, plane);
-  const rsrc_t rs_ct = mk_rsrc(a.condterm + (long long)b * 2 * C * T, 2 * plane);
-  const rsrc_t rs_aw = mk_rsrc(a.apackw43, 6 * 2 * C * C * 4);
-  const rsrc_t rs_a2 = mk_rsrc(a.apack2, 2 * C * C * 4);
-  const rsrc_t rs_bo = mk_rsrc(a.bias_out, 2 * C * 4);
-  const rsrc_t rs_dp = mk_rsrc(a.dproj + ((long long)tb * a.L + a.layer) * C, C * 4);
-  const int rowT = T * 4, vfrag = lane * 16;
-
-  F43_STAMP(0);
-  if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 8] = __builtin_amdgcn_s_memrealtime();
-  // ---- (1) the first weights fly while the x tile is staged --------------------------------------------------------------
-  // 4 row tiles of 16 per wave: gate 32w, gate 32w + 16, filter 256 + 32w, filter + 16
-  int sw[4];
-  if (DBG & 4) { sw[0] = 0; sw[1] = 16 * 1024; sw[2] = 32 * 1024; sw[3] = 48 * 1024; } else {
-  sw[0] = (2 * wave) * 16 * 1024; sw[1] = (2 * wave + 1) * 16 * 1024;
-  sw[2] = (16 + 2 * wave) * 16 * 1024; sw[3] = (16 + 2 * wave + 1) * 16 * 1024;
-  }
-  f32x4 AW[2][2][4];   // [ring slot = step & 1][component a / b of the pair][row tile]
-  f43_prefetch(AW, rs_aw, vfrag, sw);
-
-  // ---- (2) stage xs = x + d (zero padded) ---------------------------------------------------------------------------------------
-  // Layout [g = c / 16][lq = c % 4][frame 0..79 (+8 pad)][jj = (c / 4) % 4]: the 4 channels 16 g + 4 jj + lq that one lane feeds to the 4
-  // MFMAs of a channel group are one 16-byte LDS read.  An item = 4 frames of one (g, lq) row: 4 float4 loads along the frames (one per
-  // jj), transposed in registers, 4 float4 stores.
-  if ((T & 3) == 0) {
-#pragma unroll 1
-    for (int it = tid; it < 64 * 20; it += 512) {
-      const int row = it / 20, j4 = it - row * 20;   // row = g * 4 + lq
-      const int c0 = 16 * (row >> 2) + (row & 3);    // channel of jj = 0; jj adds 4
-      const int t = t0 - HALO + 4 * j4;
-      const bool ok = t >= 0 && t < T;               // a float4 is entirely inside or entirely outside [0, T)
-      f32x4 v[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        v[jj] = ldf4(rs_x, ok ? ((c0 + 4 * jj) * T + t) * 4 : 0, 0);
-        v[jj] += ldf(rs_dp, (c0 + 4 * jj) * 4, 0);
-        if (!ok) v[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<f32x4*>(xs + ((row * FS6 + 4 * j4 + k) << 2)) = f32x4{v[0][k], v[1][k], v[2][k], v[3][k]};
-    }
-  } else {
-#pragma unroll 4
-    for (int idx = tid; idx < C * 80; idx += 512) {
-      const int c = idx / 80, j = idx - c * 80;
-      const int t = t0 - HALO + j;
-      const bool ok = t >= 0 && t < T;
-      const float v = ldf(rs_x, ok ? (c * T + t) * 4 : 0, 0) + ldf(rs_dp, c * 4, 0);
-      xs[(((((c >> 4) << 2) + (c & 3)) * FS6 + j) << 2) + ((c >> 2) & 3)] = ok ? v : 0.f;
-    }
-  }
-  __syncthreads();
-  F43_STAMP(1);
-  F43_STAMP(2);
-
-  // ---- (3) GEMM1 as F(4,3): lane = (quad p = lane & 15, k-row lq = lane >> 4); quad p of dilation d starts at tp = (p / d) 4d + p % d ----
-  const int p16 = lane & 15, lq = lane >> 4, dil = a.dil;
-  const int ld = dil == 1 ? 0 : dil == 2 ? 1 : dil == 4 ? 2 : 3;
-  const int tp = ((p16 >> ld) << (ld + 2)) + (p16 & (dil - 1));
-  f32x4 y[4][4];   // [output j][row tile]
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f43_gemm1<DBG>(y, AW, xs, lq * FS6 + HALO + tp, dil, rs_aw, vfrag, sw);
-
-  F43_STAMP(3);
-  // ---- (4) + hoisted conditioner term, gate: z = sigmoid(gate) * tanh(filter)   (net.py:71-74) ------------------------------
-  // GEMM2's first weights fly across the gate and the two barriers
-  const int sb_r = wave * 32 * 1024, sb_s = (8 + wave) * 32 * 1024;   // residual / skip row tile of the packed output projection
-  f32x4 Ag[2], Af[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    Ag[k] = ldf4(rs_a2, vfrag, sb_r + k * 1024);
-    Af[k] = ldf4(rs_a2, vfrag, sb_s + k * 1024);
-  }
-  float z[4][8];   // [output j][row tile pair i (2) x r (4)]
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int f = t0 + tp + j * dil;
-    const int vc = (lq * 4 * T + (f < T ? f : T - 1)) * 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int so_g = (32 * wave + 16 * i + r) * rowT;
-        const float cg = ldf(rs_ct, vc, so_g), cf = ldf(rs_ct, vc, so_g + C * rowT);
-        z[j][4 * i + r] = fast_sigmoid(y[j][i][r] + cg) * fast_tanh(y[j][2 + i][r] + cf);
-      }
-  }
-  F43_STAMP(4);
-  // accumulator columns of GEMM2: frame t0 + 32 ct + l31
-  int vcol[2], vst[2];
-  bool col_ok[2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int col = t0 + 32 * ct + l31;
-    col_ok[ct] = col < T;
-    vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
-    vst[ct] = (lh * 4 * T + col) * 4;
-  }
-  // residual rows start from x + b_out, skip rows from b_out
-  f32x16 r0, r1, s0, s1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int so = (32 * wave + acc_row0(r)) * rowT;
-    r0[r] = ldf(rs_x, vcol[0], so);
-    r1[r] = ldf(rs_x, vcol[1], so);
-    s0[r] = s1[r] = ldf(rs_bo, lh * 16, (C + 32 * wave + acc_row0(r)) * 4);
-  }
-  __syncthreads();   // every wave is done reading xs
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) zs[(32 * wave + 16 * i + 4 * lq + r) * LDZ6 + tp + j * dil] = z[j][4 * i + r];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float br = ldf(rs_bo, lh * 16, (32 * wave + acc_row0(r)) * 4);
-    r0[r] += br;
-    r1[r] += br;
-  }
-  __syncthreads();
-  F43_STAMP(5);
-
-  // ---- (5) GEMM2: o = W_out z, 32 groups of 8 channels; two column tiles share the A fragments ------------------------------
-  float prev0[16], prev1[16];
-  {
-    const float* zrow = zs + lh * LDZ6 + l31;
-    auto ldb = [&](int q, int ct) {
-      const float* p = zrow + 8 * q * LDZ6 + 32 * ct;
-      return f32x4{p[0], p[2 * LDZ6], p[4 * LDZ6], p[6 * LDZ6]};
-    };
-    f32x4 B0[2], B1[2];
-    B0[0] = ldb(0, 0);
-    B1[0] = ldb(0, 1);
-#pragma unroll 1
-    for (int q = 0; q < 32; q += 2) {
-      if (q == 16) {   // the running skip sum is added after the chain (keeps the small products out of a large accumulator)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int so = (32 * wave + acc_row0(r)) * rowT;
-          prev0[r] = ldf(rs_sk, vcol[0], so);
-          prev1[r] = ldf(rs_sk, vcol[1], so);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int qn = q + s + 1 <= 31 ? q + s + 1 : 31;
-        B0[(s + 1) & 1] = ldb(qn, 0);
-        B1[(s + 1) & 1] = ldb(qn, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          BSG_MFMA32(r0, Ag[s][k], B0[s & 1][k]);
-          BSG_MFMA32(s0, Af[s][k], B0[s & 1][k]);
-          BSG_MFMA32(r1, Ag[s][k], B1[s & 1][k]);
-          BSG_MFMA32(s1, Af[s][k], B1[s & 1][k]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int qr = q + s + 2 <= 31 ? q + s + 2 : 31;
-        Ag[s] = ldf4(rs_a2, vfrag, sb_r + qr * 1024);
-        Af[s] = ldf4(rs_a2, vfrag, sb_s + qr * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
-  F43_STAMP(6);
-  // ---- (6) epilogue ----------------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-    if (col_ok[ct]) {
-      const f32x16& rr = ct ? r1 : r0;
-      const f32x16& ss = ct ? s1 : s0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int so = (32 * wave + acc_row0(r)) * rowT;
-        const float pv = a.first ? 0.f : (ct ? prev1[r] : prev0[r]);
-        stf(rr[r] / 1.41421356237309504880f, rs_xo, vst[ct], so);   // (x + residual) / sqrt(2), net.py:78
-        stf((pv + ss[r]) / a.skip_div, rs_sk, vst[ct], so);          // running skip sum (/ sqrt(L) last, :126)
-      }
-    }
-  F43_STAMP(7);
-  if (STAMP && lane == 0) a.stamps[((long long)tile_id * 8 + wave) * 10 + 9] = __builtin_amdgcn_s_memrealtime();
-}
-#undef F43_STAMP
 // ------------------------------------------------------------------------------------------------
 // All L layers of one 64-frame tile in ONE launch, residual stream on chip (the fp32-matrix-pipe sibling of diffnet_h2.hip;
 // same hand-off protocol — write-through stores, drain, barrier, flag with the launch epoch, bounded poll, sc1 loads — see there).
-// One workgroup per CU; every tile of the launch must be resident (the host checks).  Per layer the per-layer kernel above pays the
-// staging of x (HBM round trip with the matrix pipe idle: one workgroup per CU has nothing to overlap it with), the store of x, and
-// the gap between two launches; here
+// One workgroup per CU; every tile of the launch must be resident (the host checks).
 //   * the conv input image x + d_l (fp32) stays in LDS in GEMM1's layout and is rewritten in place by the residual rows of GEMM2
 //     (x itself is recovered as image - d_l: one rounding of x + d, 6e-8 relative, per layer);
 //   * neighbours exchange the two 8-frame edges of the new image (2 x 8 KB per tile) through L2; GEMM2 runs its residual rows first,
 //     publishes, and only then its skip rows, so that the edges fly under the skip rows' MFMAs;
-//   * the running skip sum stays in HBM (read-modify-write per layer, as the per-layer kernel): registers are what this kernel is out of.
+//   * the running skip sum stays in HBM (read-modify-write per layer): registers are what this kernel is out of.
 // HBM bytes per frame and layer: conditioner term 2 KB + skip 2 KB (+ edges 0.5 KB through L2) instead of 6 KB.
+// (Round 2 also had a per-layer kernel with this GEMM1; it was neither a default nor a fallback and was removed in round 3.)
 // ------------------------------------------------------------------------------------------------
 constexpr int XS4_FLOATS = 64 * FS6 * 4;                        // 22,528
 constexpr size_t STACK43_LDS = (size_t)(XS4_FLOATS + C * LDZ6 + 2 * C) * sizeof(float);   // 88 KB + 64 KB + 2 KB = 157,696 B
@@ -482,7 +261,7 @@ constexpr size_t STACK43_LDS = (size_t)(XS4_FLOATS + C * LDZ6 + 2 * C) * sizeof(
 template <int FAIR>
 __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;                       // image x + d_l, layout [g][lq][frame 0..79 (+8)][jj] (residual_layer_f43_kernel)
+  float* xs = lds;                       // image x + d_l, layout [g][lq][frame 0..79 (+8)][jj]
   float* zs = lds + XS4_FLOATS;          // [C][64] gated activation
   float* dcur = zs + C * LDZ6;           // [C] d_l
   float* dnxt = dcur + C;                // [C] d_{l+1}
@@ -789,54 +568,20 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
 
 int stack_f43_occupancy() {
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_f43_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STACK43_LDS) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_f43_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STACK43_LDS) != hipSuccess ||
+  if (hipFuncSetAttribute((const void*)residual_stack_f43_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STACK43_LDS) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_f43_kernel<1>, 512, STACK43_LDS) != hipSuccess)
     return 0;
   return o;
 }
 
 int launch_residual_stack_f43(const StackArgs& p, hipStream_t st) {
-  static int fair = -1;
-  if (fair < 0) { const char* e = getenv("BSG_F43_FAIR"); fair = e ? atoi(e) : 1; }
-  if (fair) hipLaunchKernelGGL(residual_stack_f43_kernel<1>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), STACK43_LDS, st, p);
-  else hipLaunchKernelGGL(residual_stack_f43_kernel<0>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), STACK43_LDS, st, p);
+  hipLaunchKernelGGL(residual_stack_f43_kernel<1>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), STACK43_LDS, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
 
 int pack_wino43(const float* w, float* out, hipStream_t st) {
   hipLaunchKernelGGL(pack_wino43_kernel, dim3(cdiv(6LL * 2 * C * C, 256)), dim3(256), 0, st, w, out);
-  BSG_LAUNCH_CHECK();
-  return BSG_OK;
-}
-
-// `a.tiles_per_row` is set here: this form tiles an utterance in 64-frame pieces
-int launch_residual_layer_f43(const ResArgs& a_in, hipStream_t st) {
-  ResArgs a = a_in;
-  a.tiles_per_row = cdiv(a.T, NT6);
-  const size_t lds = (size_t)64 * FS6 * 4 * sizeof(float);   // 88 KB (the [256][64] z tile aliases it)
-  static bool attr_set = false;
-  if (!attr_set) {
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_f43_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_f43_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  const dim3 grid(8 * cdiv(a.B * a.tiles_per_row, 8));
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("BSG_F43_DBG"); dbg = e ? atoi(e) : 0; }
-  if (a.stamps && dbg) {
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_f43_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_f43_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_f43_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (dbg == 1) hipLaunchKernelGGL((residual_layer_f43_kernel<true, 1>), grid, dim3(512), lds, st, a);
-    else if (dbg == 2) hipLaunchKernelGGL((residual_layer_f43_kernel<true, 2>), grid, dim3(512), lds, st, a);
-    else if (dbg == 4) {
-      BSG_HIP(hipFuncSetAttribute((const void*)residual_layer_f43_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((residual_layer_f43_kernel<true, 4>), grid, dim3(512), lds, st, a);
-    } else hipLaunchKernelGGL((residual_layer_f43_kernel<true, 3>), grid, dim3(512), lds, st, a);
-  } else if (a.stamps) hipLaunchKernelGGL(residual_layer_f43_kernel<true>, grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL(residual_layer_f43_kernel<false>, grid, dim3(512), lds, st, a);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

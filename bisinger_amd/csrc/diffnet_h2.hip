@@ -43,7 +43,8 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 constexpr int ROWB = 2 * C + 16;          // LDS image row: 256 fp16 + 16 B pad = 528 B (132 dwords = 4 mod 64)
 constexpr int h2_xp(int nct) { return (32 * nct + 2 * HALO) * ROWB; }   // bytes per plane of the image: 42,240 (NCT = 2)
 constexpr int h2_zp(int nct) { return 32 * nct * ROWB; }                // bytes per plane of z: 33,792 (NCT = 2)
-constexpr int NSH = 4;                    // weight ring (k-steps)
+constexpr int NSH = 4;                    // weight ring (k-steps).  A ring of 8 for the 32-frame form (it has the registers) measured 5-7 % SLOWER at
+                                          // B = 1, 4, 8 (profiles/r03_ab_ring.log): the L2 latency of the weight stream is already covered
 constexpr int PLB = 16 * 1024;            // bytes per plane of a k-step slab (16 row tiles x 1 KB)
 constexpr int KSB2 = 2 * PLB;             // bytes per k-step: hi slab, lo slab
 constexpr float ZSCALE = 1024.0f;         // z in (-1, 1) is split as z x 2^10
@@ -125,7 +126,7 @@ __device__ __forceinline__ int kmap(int i) {
 // FAIRB: the two waves of a SIMD take turns at issue priority (see f43_gemm1, diffnet_f43.hip).
 template <int ROT, bool FAIRB, int NCT, typename LDB, typename MID>
 __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT], f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag,
-                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half, int fshift, int ftail) {
+                                             int sa0, int sa1, int n_ks, LDB ldb, MID mid, int half) {
   // c0[ct] / c1[ct]: row tile 0 / 1 x column tile ct.  B[..][2 ct] = hi, [2 ct + 1] = lo of column tile ct
   f16x8 B[2][2 * NCT];
   ldb(kmap<ROT>(0), B[0]);
@@ -133,14 +134,9 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += NSH) {
     if (FAIRB) {
-      if (ks >= n_ks - ftail) {   // final stretch: waves 0..3 first (they reach the VALU phase behind this GEMM `ftail` k-steps early)
-        if (half == 0) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(0);
-      } else {
-        const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
-        if (((tnow >> fshift) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(0);
-      }
+      const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+      if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
     }
     if (ROT > 0 && ks == ROT) {
       mid();
@@ -425,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         __syncthreads();   // (A) halo rows in place
         STK_STAMP(2);
       };
-      mfma_pipe_h2<16, FAIRB, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2, p.fair_shift, p.fair_tail1);
+      mfma_pipe_h2<16, FAIRB, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -477,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(q + 32 * ct * ROWB + ZP);
         }
       };
-      mfma_pipe_h2<0, FAIRB, NCT>(yg, yf, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2, p.fair_shift, p.fair_tail2);
+      mfma_pipe_h2<0, FAIRB, NCT>(yg, yf, A, rs_a2, vfrag, sb_r, sb_s, 16, ldb, [] {}, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (l + 1 < L) prefetch_a1(l + 1);

@@ -58,10 +58,6 @@ struct StackArgs {
   int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
-  // split-fp16 launch, issue priority between the two waves of a SIMD (FAIRB): slices of 2^fair_shift shader clocks taken in turns, and
-  // for the last fair_tail1 / fair_tail2 k-steps of GEMM1 / GEMM2 strict priority for waves 0..3 — they finish that many k-steps
-  // ahead of their SIMD partners and run their VALU phase (gate; x update + image) under the partners' last MFMAs
-  int fair_shift, fair_tail1, fair_tail2;
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
   unsigned long long* clk;      // null, or [4]: tile 0 stores s_memtime / s_memrealtime at its start and end (sustained shader clock, bench.py)
 };
@@ -77,8 +73,6 @@ int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* m
 int pack_a_frag_h2(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
                    int is_gemm2, hipStream_t st);
 
-// fp32 residual layer with GEMM1 as Winograd F(4,3) (diffnet_f43.hip); same tensors, 64-frame tiles, one workgroup per CU
-int launch_residual_layer_f43(const ResArgs& a, hipStream_t st);
 int pack_wino43(const float* w, float* out, hipStream_t st);   // [2C][C][3] -> [6][32][16][64][4]
 // F(4,3) stack launch: all L layers of 64-frame tiles, one workgroup per CU (diffnet_f43.hip); grid = p.n_tiles rounded up to 8
 int launch_residual_stack_f43(const StackArgs& p, hipStream_t st);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(const float* __r
 //   S^T[key, q]: A = K fragment (lane = key, 8 consecutive d per lane half), B = Q fragment of the lane's query.
 //   O^T[d, q] += V^T[d, key] P[key, q]: the lane's 16 probabilities are keys (r&3) + 8 (r>>2) + 4 lh; MFMA step t takes its registers
 //   8t .. 8t+7 as the 8 k-values of the lane half, so the A fragment of V^T is read with that key order: two 8-byte pieces of a [d] row.
-// Operands beyond the fp16 range (|v| >= 4094) are counted in the GEMMs' range-event counter (the host repeats the call on the
+// Operands beyond the fp16 range (|v| >= 4062) are counted in the GEMMs' range-event counter (the host repeats the call on the
 // fp32 pipe).
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs g) {
 // while they are staged (a = ah + al to 2^-24 |a|; see diffnet_h2.hip for the argument), and every fp32 product is formed as
 // ah bh + ah bl + al bh by three v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3/16 of the matrix cycles of the fp32 MFMA form.
 // Operands are scaled by 2^4 on the way in (products by 2^8, removed from the accumulator: exact) so that the lo terms of values down
-// to 2^-6 are normal fp16 numbers; below that they carry an absolute error <= 2^-29.  |operand| must stay below 4094.
+// to 2^-6 are normal fp16 numbers; below that they carry an absolute error <= 2^-29.  |operand| must stay below 4062 (the guard trips at 65000 / 16).
 // Tile BM x 128 x 16 per 256-thread workgroup, double-buffered LDS: per stage and operand two planes of [rows][16 fp16 + 8 pad] (48-byte
 // rows: the 16 rows of a ds_read_b128 lane group fall on 16 different bank quads); an MFMA fragment = 8 consecutive k = one 16-byte
 // read.  !TRANS_B ([K][N] operand, N contiguous): a thread gathers 8 consecutive k of one column with 8 coalesced dword loads.
@@ -602,13 +602,11 @@ bool gemm_split_enabled() {
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   BSG_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.taps > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
   BSG_REQUIRE(g.batch <= 65535, "gemm: batch %d > 65535", g.batch);
-  static int v1 = -1;   // BSG_GEMM_V1=1: round 1's kernel for every problem (A/B measurements)
-  if (v1 < 0) { const char* e = getenv("BSG_GEMM_V1"); v1 = e ? atoi(e) : 0; }
   // the fast kernel moves 16-byte pieces: every operand row and every batch / tap offset must keep 16-byte alignment
   auto al4 = [](long long v) { return (v & 3) == 0; };
   const bool aligned = al4(g.K) && al4(g.lda) && al4(g.ldb) && al4(g.sA) && al4(g.sA2) && al4(g.sB) && al4(g.sB2) && al4(g.sTapB) &&
                        (g.trans_b || al4(g.N)) && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0;
-  if (aligned && !v1) {
+  if (aligned) {
     // 64-row tiles when 128-row tiles would not give every CU two workgroups (e.g. [16000 x 256] outputs: 250 -> 500 workgroups)
     const long long wg128 = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
     const bool small = wg128 < 2 * 256;
@@ -619,12 +617,6 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
       const bool sm = wgs < 3 * 256;
       if (g.trans_b) return sm ? launch_split<64, true>(g, st) : launch_split<128, true>(g, st);
       return sm ? launch_split<64, false>(g, st) : launch_split<128, false>(g, st);
-    }
-    static int bk = -1;   // BSG_GEMM_BK=32: 32-deep LDS stages (two workgroups per CU instead of three)
-    if (bk < 0) { const char* e = getenv("BSG_GEMM_BK"); bk = e ? atoi(e) : 16; }
-    if (bk == 32) {
-      if (g.trans_b) return small ? launch_fast<64, 32, true>(g, st) : launch_fast<128, 32, true>(g, st);
-      return small ? launch_fast<64, 32, false>(g, st) : launch_fast<128, 32, false>(g, st);
     }
     if (g.trans_b) return small ? launch_fast<64, 16, true>(g, st) : launch_fast<128, 16, true>(g, st);
     return small ? launch_fast<64, 16, false>(g, st) : launch_fast<128, 16, false>(g, st);

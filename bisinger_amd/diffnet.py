@@ -149,7 +149,8 @@ class DiffNet(nn.Module):
     def prepare(self, cond):
         """Bind ``cond`` [B,H,T]: hoists every layer's conditioner projection out of the step loop."""
         h = self.handle()
-        if getattr(self, '_h2_range_off', False):       # a range event of the split-fp16 launch was a property of the previous condition
+        off = getattr(self, '_h2_range_off', False)
+        if off is not False and off is not cond:        # a range event of the split-fp16 launch was a property of the condition bound then
             _lib.check(_lib.load().bsg_diffnet_set_h2(h, 1), 'bsg_diffnet_set_h2')
             self._h2_range_off = False
         cond = cond.contiguous().float()
@@ -248,16 +249,17 @@ class DiffNet(nn.Module):
                     _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
                     self.split_disabled, self._clean_calls = False, 0
             return
-        if rng and not give and _lib.gemm_range_peek():
-            # the launch saw huge / non-finite values BECAUSE a GEMM above it (condition or input projection) left its range: not this
-            # handle's fault — the GEMM guard around this call repeats everything on the fp32 matrix pipe
-            return
         if rng and not give:
-            warnings.warn(f'bisinger_amd: {rng} waves of the split-fp16 stack launch saw an activation beyond its fp16 range (|x + d| >= '
-                          f'60000); this DiffNet handle runs the kernels of the fp32 matrix pipe for this condition and the evaluation '
-                          f'is repeated')
+            warnings.warn(f'bisinger_amd: {rng} waves saw an activation beyond the fp16 range of the split-fp16 launch (|x + d| >= 60000); '
+                          f'this DiffNet handle runs the kernels of the fp32 matrix pipe while this condition is bound and the '
+                          f'evaluation is repeated')
             _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
-            self._h2_range_off = True
+            self._h2_range_off = self._bound[0] if self._bound is not None else True
+            if _lib.gemm_range_peek():
+                # a split-fp16 GEMM counted an operand too.  Cause and effect cannot be told apart here (a NaN condition makes the launch
+                # trip; a launch that tripped feeds NaN to the GEMMs behind it): the GEMM guard around this call repeats everything
+                # with the GEMMs on the fp32 matrix pipe — and this handle off the 16-bit pipe — in ONE more pass
+                return
             if restore is not None:
                 restore()
             run()

@@ -345,7 +345,7 @@ int bsg_gemm_f32(const float* A, const float* Bm, float* C, const float* bias_m,
                  void* stream);
 
 /* The GEMMs outside the residual stack form fp32 products on the 16-bit matrix pipe from hi + lo fp16 splits of both operands
- * (csrc/gemm.hip gemm_split_kernel; fp32-grade, |operand| < 4094).  A staged operand outside that range is counted instead of being
+ * (csrc/gemm.hip gemm_split_kernel; fp32-grade, |operand| < 4062).  A staged operand outside that range is counted instead of being
  * clipped silently: bsg_gemm_range_events waits for `stream`, returns the count (and resets it), and bsg_gemm_set_split(0) moves every
  * later GEMM to the fp32 matrix pipe — what the Python drop-ins do before they repeat the call (bisinger_amd/diffnet.py guarded). */
 int bsg_gemm_set_split(int32_t enable);

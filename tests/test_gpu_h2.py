@@ -56,7 +56,7 @@ FORMS = {
     'split_fp16': ({'BSG_H2': '2'}, 'stack_h2'),
     'fp32_direct': ({'BSG_H2': '0', 'BSG_WINO': '0', 'BSG_SPLIT': '0'}, 'layer'),
     'fp32_wino23': ({'BSG_H2': '0', 'BSG_WINO': '1', 'BSG_SPLIT': '0'}, 'layer'),
-    'fp32_wino43': ({'BSG_H2': '0', 'BSG_WINO': '43', 'BSG_STACK43': '2'}, 'stack_f43'),
+    'fp32_wino43': ({'BSG_H2': '0', 'BSG_WINO': '2', 'BSG_STACK43': '2'}, 'stack_f43'),
 }
 
 
@@ -131,10 +131,10 @@ print(json.dumps(out))
 def test_split_gemm_is_fp32_grade():
     """gemm_split_kernel (csrc/gemm.hip: operands split into hi + lo fp16 while staged, 3 fp16 MFMAs per product) against
     gemm_fast_kernel (fp32 MFMAs) on the path's shapes and on operands of other magnitudes (tiny: the lo terms are subnormal fp16;
-    large: close to the documented |operand| < 4094 limit): error vs float64 no worse than the fp32 pipe's."""
+    large: close to the documented |operand| < 4062 limit): error vs float64 no worse than the fp32 pipe's."""
     shapes = [(1000, 768, 256, 1, 1.0), (1000, 256, 1024, 1, 1.0), (512, 1000, 256, 0, 1.0), (777, 80, 256, 1, 1.0),
               (640, 256, 2304, 1, 1e-3), (640, 256, 256, 1, 500.0),
-              (640, 256, 256, 1, -4090.0)]       # negative: uniform in (-4090, 4090), i.e. operands up to the documented |v| < 4094
+              (640, 256, 256, 1, -4060.0)]       # negative: uniform in (-4060, 4060), i.e. operands up to the documented |v| < 4062
     code = GEMM_CHILD % (ROOT, shapes)
     res = {}
     for name, env in (('split', {'BSG_GEMM_SPLIT': '1'}), ('fp32', {'BSG_GEMM_SPLIT': '0'})):
@@ -153,7 +153,7 @@ def test_split_gemm_is_fp32_grade():
 def test_range_guards_repeat_on_the_fp32_pipe(mode):
     """Operands beyond the fp16 range cannot be split.  'stack': inside the stack launch (|x + d| >= 60000, here through the bias of one
     layer's diffusion projection) the launch reports it through the hand-off status word; 'gemm': in the split-fp16 GEMMs (|operand| >=
-    4094, here the input projection of a huge x) a device counter does.  Either way the evaluation is repeated on the fp32 matrix pipe in
+    4062, here the input projection of a huge x) a device counter does.  Either way the evaluation is repeated on the fp32 matrix pipe in
     the same call, with a warning, and agrees with a handle that never used the 16-bit pipe.  Child process: the switches are process-wide
     once they have tripped."""
     code = r'''

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the parts of a mel-generation pass that are NOT the sampler loop: FS2-MIDI encoder + decoder and the hoisted conditioner
-projections (bsg_diffnet_prepare), at the bench shapes (T = 1000).  BSG_GEMM_V1=1 selects round 1's GEMM kernel for an A/B.
+projections (bsg_diffnet_prepare), at the bench shapes (T = 1000).  BSG_GEMM_SPLIT=0 selects the fp32-matrix-pipe GEMM for an A/B.
     python tools/bench_fs2.py [B ...]          (default 16 64)"""
 import json
 import os

@@ -25,7 +25,7 @@ out = torch.empty_like(x)
 skip = torch.zeros(B, 256, T, device='cuda')
 t = torch.full((B,), 50, dtype=torch.long, device='cuda')
 net.prepare(cond)
-NTILE = 64 if DT == 'bf16' or os.environ.get('BSG_WINO') == '43' else 32
+NTILE = 64 if DT == 'bf16' else 32
 nwg = B * ((T + NTILE - 1) // NTILE)
 st = torch.zeros(nwg, 8, 10, dtype=torch.int64, device='cuda')
 lib = _lib.load()
