@@ -704,9 +704,7 @@ template <int NCT>
 static int h2_occupancy() {
   int o = 0;
   const int lds = (int)h2_lds(NCT);
-  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_h2_kernel<false, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+  if (hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
       hipFuncSetAttribute((const void*)residual_stack_h2_kernel<true, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_h2_kernel<true, true, NCT>, 512, h2_lds(NCT)) != hipSuccess)
     return 0;
@@ -715,18 +713,14 @@ static int h2_occupancy() {
 // resident workgroups per CU (0 on error) of the form with `nct` column tiles of 32 frames per workgroup (1 or 2)
 int stack_h2_occupancy(int nct) { return nct == 1 ? h2_occupancy<1>() : h2_occupancy<2>(); }
 
+// (FAIRB = the time-sliced issue priority between the two waves of a SIMD is always on: +1.2 % in round 2's A/B; the switch is gone)
 template <int NCT>
-static int h2_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st, int fair) {
+static int h2_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
   const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
   const TailArgs a = tail ? *tail : TailArgs{};
   const size_t lds = h2_lds(NCT);
-  if (tail) {
-    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, true, NCT>), grid, block, lds, st, p, a);
-    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, true, NCT>), grid, block, lds, st, p, a);
-  } else {
-    if (fair) hipLaunchKernelGGL((residual_stack_h2_kernel<true, false, NCT>), grid, block, lds, st, p, a);
-    else hipLaunchKernelGGL((residual_stack_h2_kernel<false, false, NCT>), grid, block, lds, st, p, a);
-  }
+  if (tail) hipLaunchKernelGGL((residual_stack_h2_kernel<true, true, NCT>), grid, block, lds, st, p, a);
+  else hipLaunchKernelGGL((residual_stack_h2_kernel<true, false, NCT>), grid, block, lds, st, p, a);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
@@ -735,9 +729,7 @@ static int h2_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st, i
 // launch's rows: x, noise, xa_next, history pointers and quad_row0 already offset to its first row).  nct = column tiles of 32 frames per
 // workgroup: p.tiles_per_row / p.n_tiles count tiles of 32 * nct frames
 int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct) {
-  static int fair = -1;
-  if (fair < 0) { const char* e = getenv("BSG_H2_FAIR"); fair = e ? atoi(e) : 1; }
-  return nct == 1 ? h2_launch<1>(p, tail, st, fair) : h2_launch<2>(p, tail, st, fair);
+  return nct == 1 ? h2_launch<1>(p, tail, st) : h2_launch<2>(p, tail, st);
 }
 
 // the three projections of the step tail as split-fp16 fragments + their scale table [3][2]; maxbits: [3] scratch

@@ -198,7 +198,8 @@ out['ref_path'] = ref.last_path()
 out['dev'], out['scale'] = maxabs(y, yr), float(yr.abs().max())
 print(json.dumps(out))
 ''' % ROOT
-    res = subprocess.run([sys.executable, '-c', code, mode], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    # (the split forms explicitly on: this test is about their guards, also when the suite runs under BSG_H2=0 BSG_GEMM_SPLIT=0)
+    res = subprocess.run([sys.executable, '-c', code, mode], env=dict(os.environ, BSG_H2='1', BSG_GEMM_SPLIT='1'), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
     print(out)
