@@ -272,7 +272,7 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None, clock=None):
         # n_layer counts its layers, so avg_ms is the time of one layer over all rows.  1,048,576 FLOP / 1.38 KB = 760 FLOP/B is
         # above the ridge (312 FLOP/B): matrix-pipe bound
         by = HBM_BYTES_PER_FRAME_LAYER_BF16_STACK * frames_per_launch
-        return dict(common, kernel='residual_stack_bf16_kernel (20 fused DiffNet residual blocks + the step tail per launch, bf16 MFMA operands; figures per layer)',
+        return dict(common, kernel='residual_stack_bf16_kernel (20 fused DiffNet residual blocks per launch, bf16 MFMA operands; figures per layer)',
                     bound='mfma', achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_BF16_MFMA_TFLOPS,
                     flop_per_layer=FLOP_PER_FRAME_LAYER * frames_per_launch, hbm_bytes_per_layer=by,
                     hbm_gbs=by * concurrent / (avg_ms * 1e-3) / 1e9, hbm_frac=by * concurrent / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

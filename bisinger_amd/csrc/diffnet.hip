@@ -1674,7 +1674,7 @@ static int stack_rows_bf16(bsg_diffnet* h, int B, int T, hipStream_t st) {
 }
 
 static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_uniform, int B, int T, int rows_per_launch, hipStream_t st,
-                             unsigned long long* stamps = nullptr, const TailArgs* tail = nullptr) {
+                             unsigned long long* stamps = nullptr) {
   const int tpr = cdiv(T, 64);
   const size_t bt = (size_t)h->B * T;
   for (int r0 = 0; r0 < B; r0 += rows_per_launch) {
@@ -1696,21 +1696,9 @@ static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_unifo
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
-    if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
-      TailArgs a = *tail;
-      const size_t mo = (size_t)r0 * h->M * T;
-      a.x += mo; a.xa_next += (size_t)r0 * C * T; a.quad_row0 += mo;
-      if (a.noise) a.noise += mo;
-      if (a.e_new) a.e_new += mo;
-      if (a.h1) a.h1 += mo;
-      if (a.h2) a.h2 += mo;
-      if (a.h3) a.h3 += mo;
-      TRY(launch_residual_stack_bf16(p, st, &a));
-    } else {
-      TRY(launch_residual_stack_bf16(p, st));
-    }
+    TRY(launch_residual_stack_bf16(p, st));
   }
-  h->last_path = tail ? "stack_bf16_tail" : "stack_bf16";
+  h->last_path = "stack_bf16";
   return BSG_OK;
 }
 
@@ -1868,27 +1856,6 @@ static int step_from_xa(bsg_diffnet* h, int t_uniform, TailArgs& a, float* x, in
       BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
       h->prof_used += 2;
       h->prof_launches += h->L;   // layer-equivalents; the launch also carries the step tail (~1 % of its FLOPs)
-    }
-    return BSG_OK;
-  }
-  // bf16-operand configuration: the same fusion (residual_stack_bf16_kernel<.., TAILM>; BSG_BF16_TAIL_FUSED=0: two launches)
-  static int env_bt = -1;
-  if (env_bt < 0) { const char* e = getenv("BSG_BF16_TAIL_FUSED"); env_bt = e ? atoi(e) : 1; }
-  const char* tail_env = getenv("BSG_TAIL_BF16");
-  const int hrows = (env_bt && h->compute == BSG_COMPUTE_BF16 && h->tail_h && h->M <= 96 && !(tail_env && atoi(tail_env) == 0)) ? stack_rows_bf16(h, B, T, st) : 0;
-  if (hrows) {
-    const size_t off = (size_t)h->row_off * C * T;
-    a.x = x; a.xa_next = h->xa + off;
-    a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
-    a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 64);
-    a.ws_h = h->tail_h; a.wo_h = h->tail_h + C * C; a.wi_h = h->tail_h + C * C + 96 * C;
-    const bool prof = h->prof_on && h->prof_used + 2 <= h->prof_ev.size();
-    if (prof) BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used], st));
-    TRY(launch_stack_bf16(h, nullptr, t_uniform, B, T, hrows, st, nullptr, &a));
-    if (prof) {
-      BSG_HIP(hipEventRecord(h->prof_ev[h->prof_used + 1], st));
-      h->prof_used += 2;
-      h->prof_launches += h->L;
     }
     return BSG_OK;
   }

@@ -385,11 +385,8 @@ __device__ __forceinline__ void mfma_pipe_bf8(f32x16& c00, f32x16& c10, f32x16& 
   }
 }
 
-// TAILM: 0 = the residual stack only (skip sum to p.skip_h); 1 / 2 = the sampler step's tail (DDPM / PLMS form) runs on the tile while it is
-// still on chip — what step_tail_bf16_kernel below computes, with s taken from the registers instead of HBM (the same bf16 value), so the
-// results are bit-identical to the two-launch form and a sampler step is ONE launch
-template <bool FAIRB, int TAILM>
-__global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p, TailArgs a) {
+template <bool FAIRB>
+__global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* xs = lds_raw;              // [80 frames][528 B]: bf16(x + d_l), frames t0-8 .. t0+71
   char* zs = lds_raw + XS_BYTES;   // [64 frames][528 B]: gated activation
@@ -650,9 +647,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
   }
 #undef STK_STAMP
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
-  if constexpr (TAILM == 0) {
-    // ---- the skip sum / sqrt(L) (net.py:126): rounded to bf16 ONCE (the per-layer kernel rounds the running sum after every layer) and
-    // stored in channel-quad order, the layout the bf16 step tail stages with 8-byte loads -----------------------------------------
+  // ---- the skip sum / sqrt(L) (net.py:126): rounded to bf16 ONCE (the per-layer kernel rounds the running sum after every layer) and
+  // stored in channel-quad order, the layout the bf16 step tail stages with 8-byte loads -----------------------------------------
+  {
     const rsrc_t rs_sk = mk_rsrc(p.skip_h + (long long)b * C * T, plane / 2);
     const float div = sqrtf((float)L);
 #pragma unroll
@@ -663,155 +660,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
         for (int g = 0; g < 4; ++g)
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2(sk[ct][4 * g] / div, sk[ct][4 * g + 1] / div), pack2(sk[ct][4 * g + 2] / div, sk[ct][4 * g + 3] / div)},
                                                 rs_sk, vqs, (8 * wave + 2 * g) * T * 8, 0);
-      }
-  } else {
-    // ================= fused step tail (step_tail_bf16_kernel below is the two-launch form and the model) =========================
-    constexpr bool PLMS = TAILM == 2;
-    const int M = a.M;
-    const rsrc_t rs_ws = mk_rsrc(a.ws_h, C * C * 2);
-    const rsrc_t rs_wo = mk_rsrc(a.wo_h, 96 * C * 2);
-    const rsrc_t rs_wi = mk_rsrc(a.wi_h, C * 96 * 2);
-    const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
-    const rsrc_t rs_bf = mk_rsrc(a.b_fin, 96 * 4);
-    const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
-    // ---- s = bf16(skip sum / sqrt(L)) -> the image's core rows (the conv image is dead: every wave is behind barrier (B) of the last
-    // layer), zero beyond T; the skip projection's first weights fly meanwhile -------------------------------------------------------
-    bf16x8 At[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) At[k] = lda8(rs_ws, vfrag, wave * 1024 + k * 8 * 1024);
-    {
-      const float div = sqrtf((float)L);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 w2 = u32x2{pack2(sk[ct][4 * g] / div, sk[ct][4 * g + 1] / div), pack2(sk[ct][4 * g + 2] / div, sk[ct][4 * g + 3] / div)};
-          if (!col_ok[ct]) w2 = u32x2{0u, 0u};
-          *reinterpret_cast<u32x2*>(xs + (HALO + 32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) = w2;
-        }
-    }
-    f32x16 h0, h1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h0[r] = h1[r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4);
-    __syncthreads();   // (T1) s complete; every wave is done with GEMM2 of the last layer (zs is free)
-    // ---- h = relu(W_skip s + b): 16 k-steps, this wave's 32 rows x 64 frames -> zs ---------------------------------------------------
-    {
-      const char* sb = xs + (HALO + l31) * ROWB + lh * 16;
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(sb + ks * 32);
-        const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(sb + 32 * ROWB + ks * 32);
-        BSG_MFMA_BF(h0, At[ks & 7], B0);
-        BSG_MFMA_BF(h1, At[ks & 7], B1);
-        if (ks + 8 < 16) At[ks & 7] = lda8(rs_ws, vfrag, wave * 1024 + (ks + 8) * 8 * 1024);
-      }
-    }
-    const int rt = wave % 3, ct2 = wave / 3;   // output projection: 3 row tiles x 2 column tiles on waves 0..5
-    bf16x8 Ao[8];
-    if (wave < 6) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) Ao[k] = lda8(rs_wo, vfrag, rt * 1024 + k * 3 * 1024);
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const f32x16& hh = ct ? h1 : h0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<u32x2*>(zs + (32 * ct + l31) * ROWB + (32 * wave + 8 * g + 4 * lh) * 2) =
-            u32x2{pack2(fmaxf(hh[4 * g], 0.f), fmaxf(hh[4 * g + 1], 0.f)), pack2(fmaxf(hh[4 * g + 2], 0.f), fmaxf(hh[4 * g + 3], 0.f))};
-    }
-    __syncthreads();   // (T2) h complete; every wave is done reading s (the image rows may take the updated x)
-    // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins -----------------------------
-    if (wave < 6) {
-      const int col = t0 + 32 * ct2 + l31;
-      const bool cok = col < T;
-      const int vc = (lh * 4 * T + (cok ? col : T - 1)) * 4, vs = (lh * 4 * T + col) * 4;
-      const rsrc_t rs_xx = mk_rsrc(a.x + (long long)b * M * T, (unsigned)M * T * 4);
-      const rsrc_t rs_n = mk_rsrc(a.noise ? a.noise + (long long)b * M * T : a.x, a.noise ? (unsigned)M * T * 4 : 0u);
-      f32x16 e;
-      float xv[16], nv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // the lane's row is m0 + 4 lh; rows >= M fall outside the descriptor's range and read as 0, and are never stored
-        const int m0 = 32 * rt + acc_row0(r);
-        e[r] = ldf(rs_bf, lh * 16, m0 * 4);
-        xv[r] = ldf(rs_xx, vc, m0 * rowT);
-        nv[r] = a.noise ? ldf(rs_n, vc, m0 * rowT) : 0.f;
-      }
-      float h1v[PLMS ? 16 : 1], h2v[PLMS ? 16 : 1], h3v[PLMS ? 16 : 1];
-      if constexpr (PLMS) {
-        const unsigned hb = (unsigned)M * T * 4;
-        const rsrc_t rs_h1 = mk_rsrc(a.h1 + (long long)b * M * T, hb);
-        const rsrc_t rs_h2 = mk_rsrc(a.plms_hist > 1 ? a.h2 + (long long)b * M * T : a.x, a.plms_hist > 1 ? hb : 0u);
-        const rsrc_t rs_h3 = mk_rsrc(a.plms_hist > 2 ? a.h3 + (long long)b * M * T : a.x, a.plms_hist > 2 ? hb : 0u);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int so = (32 * rt + acc_row0(r)) * rowT;
-          h1v[r] = ldf(rs_h1, vc, so);
-          h2v[r] = ldf(rs_h2, vc, so);   // zero-size descriptors read as 0
-          h3v[r] = ldf(rs_h3, vc, so);
-        }
-      }
-      const char* hb_ = zs + (32 * ct2 + l31) * ROWB + lh * 16;
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(hb_ + ks * 32);
-        BSG_MFMA_BF(e, Ao[ks & 7], B0);
-        if (ks + 8 < 16) Ao[ks & 7] = lda8(rs_wo, vfrag, rt * 1024 + (ks + 8) * 3 * 1024);
-      }
-      const rsrc_t rs_en = mk_rsrc(PLMS ? a.e_new + (long long)b * M * T : a.x, PLMS ? (unsigned)M * T * 4 : 0u);
-      float o[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 32 * rt + acc_row(r, lh);
-        o[r] = 0.f;
-        if (m < M) {
-          if constexpr (PLMS) {
-            o[r] = plms_update(xv[r], e[r], h1v[r], h2v[r], h3v[r], a.plms_hist, a.pk, nullptr);
-            if (cok) stf(e[r], rs_en, vs, (32 * rt + acc_row0(r)) * rowT);
-          } else {
-            float nz = nv[r];
-            if (!a.noise && a.k.sigma != 0.f)
-              nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + (cok ? col : T - 1));
-            float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, e[r]));
-            x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-            const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
-            o[r] = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
-          }
-          if (cok) stf(o[r], rs_xx, vs, (32 * rt + acc_row0(r)) * rowT);
-        }
-      }
-      // the updated x as the input projection's B operand: channels 0..95 of the image's core rows (rows >= M zero)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<u32x2*>(xs + (HALO + 32 * ct2 + l31) * ROWB + (32 * rt + 8 * g + 4 * lh) * 2) =
-            u32x2{pack2(o[4 * g], o[4 * g + 1]), pack2(o[4 * g + 2], o[4 * g + 3])};
-    }
-    if (!a.do_head) return;
-    // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded) --------------------------------
-    bf16x8 Ai[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Ai[k] = lda8(rs_wi, vfrag, wave * 1024 + k * 8 * 1024);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h0[r] = h1[r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4);
-    __syncthreads();   // (T3) the updated x tile is complete
-    {
-      const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {
-        const bf16x8 B0 = *reinterpret_cast<const bf16x8*>(xb + ks * 32);
-        const bf16x8 B1 = *reinterpret_cast<const bf16x8*>(xb + 32 * ROWB + ks * 32);
-        BSG_MFMA_BF(h0, Ai[ks], B0);
-        BSG_MFMA_BF(h1, Ai[ks], B1);
-      }
-    }
-    const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, plane);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-      if (col_ok[ct]) {
-        const f32x16& hh = ct ? h1 : h0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) stf(fmaxf(hh[r], 0.f), rs_xa, vst[ct], (32 * wave + acc_row0(r)) * rowT);
       }
   }
 }
@@ -1043,22 +891,15 @@ int launch_step_tail_bf16(const TailArgs& a_in, hipStream_t st) {
 int stack_bf16_occupancy() {
   const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel<true, 1>, 512, lds) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)residual_stack_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_bf16_kernel<true>, 512, lds) != hipSuccess)
     return 0;
   return o;
 }
 
-// tail == nullptr: the residual stack only (skip sum to p.skip_h); else the sampler step's tail in the same launch (TailArgs of THIS launch's
-// rows: x, noise, xa_next, history pointers and quad_row0 already offset to its first row; ws_h / wo_h / wi_h set)
-int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st, const TailArgs* tail) {
+int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st) {
   const size_t lds = XS_BYTES + ZS_BYTES + 3 * C * 4;
-  const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
-  if (!tail) hipLaunchKernelGGL((residual_stack_bf16_kernel<true, 0>), grid, block, lds, st, p, TailArgs{});
-  else if (tail->plms_hist) hipLaunchKernelGGL((residual_stack_bf16_kernel<true, 2>), grid, block, lds, st, p, *tail);
-  else hipLaunchKernelGGL((residual_stack_bf16_kernel<true, 1>), grid, block, lds, st, p, *tail);
+  hipLaunchKernelGGL(residual_stack_bf16_kernel<true>, dim3(8 * cdiv(p.n_tiles, 8)), dim3(512), lds, st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

@@ -63,8 +63,7 @@ struct StackArgs {
 };
 
 // bf16 stack launch: 64-frame tiles, one workgroup per CU (see diffnet_bf16.hip); grid = p.n_tiles rounded up to 8
-struct TailArgs;
-int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st, const TailArgs* tail = nullptr);
+int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st);
 int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf16_kernel (0 on error)
 
 // fp32 stack launch on the 16-bit matrix pipe: operands split exactly into hi + lo fp16 terms (diffnet_h2.hip); 64-frame tiles, one

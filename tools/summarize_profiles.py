@@ -81,7 +81,7 @@ for cfg in ('f32', 'bf16', 'voc'):
     cands = {'f32': [('residual_stack_h2_kernel<true>', 'stack_h2'), ('residual_stack_h2_kernel<false>', 'stack_h2'),
                      ('residual_stack_f43_kernel<1>', 'stack_f43'), ('residual_stack_f43_kernel<0>', 'stack_f43'),
                      ('residual_layer_kernel<false, true>', 'layer')],
-             'bf16': [('residual_stack_bf16_kernel<true, 1>', 'stack_bf16'), ('residual_stack_bf16_kernel<true, 0>', 'stack_bf16'),
+             'bf16': [('residual_stack_bf16_kernel<true>', 'stack_bf16'), ('residual_stack_bf16_kernel<false>', 'stack_bf16'),
                       ('residual_layer_bf16_kernel<false>', 'bf16')]}.get(cfg, [])
     cands = [(k, 'stack_h2') for k in per_kernel if k.startswith('residual_stack_h2_kernel')] + cands   # any instantiation (<FAIR, TAIL>)
     for dom, path in cands:
