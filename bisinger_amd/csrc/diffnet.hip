@@ -1075,6 +1075,12 @@ struct bsg_diffnet {
   bool h2_off = false;                 // bsg_diffnet_set_h2(h, 0): this handle multiplies on the fp32 matrix pipe only
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
   int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
+  bool stack_pair = false;             // ... the pair form (two workgroups per 32-frame tile, diffnet_h2.hip residual_pair_h2_kernel)
+  int occ_pair = -1;                   // resident workgroups per CU of the pair form (-1: not queried)
+  unsigned short* pair_zx = nullptr;   // pair form: exchange slots of the z halves [tiles][2][2 planes][32][C/2] fp16
+  unsigned short* pair_ix = nullptr;   //            ... of the image halves [2 parities][tiles][2][2 planes][32][C/2]
+  unsigned* pair_flags = nullptr;      //            [2][tiles][2] image / z flags
+  size_t pair_cap = 0;                 // tiles the pair buffers are sized for
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1129,6 +1135,10 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->h2_scale) (void)hipFree(h->h2_scale);
   if (h->tail_s) (void)hipFree(h->tail_s);
   if (h->tail_scale) (void)hipFree(h->tail_scale);
+  if (h->clk) (void)hipFree(h->clk);
+  if (h->pair_zx) (void)hipFree(h->pair_zx);
+  if (h->pair_ix) (void)hipFree(h->pair_ix);
+  if (h->pair_flags) (void)hipFree(h->pair_flags);
   delete h;
 }
 
@@ -1552,6 +1562,23 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       if (env_nct < 0) { const char* e = getenv("BSG_H2_NCT"); env_nct = e ? atoi(e) : 0; }
       int nct = (long long)B * cdiv(T, 32) > h->num_cus ? 2 : 1;
       if (env_nct == 1 || env_nct == 2) nct = env_nct;
+      h->stack_pair = false;
+      {
+        // pair form: when the 32-frame tiles fill at most half of the CUs (B <= 4 at T = 1000), two workgroups on two CUs share a tile, each
+        // half of the channels and half of the weight stream; whole batch in one launch.  BSG_H2_PAIR=0: off
+        static int env_pair = -1;
+        if (env_pair < 0) { const char* e = getenv("BSG_H2_PAIR"); env_pair = e ? atoi(e) : 1; }
+        const long long t32 = (long long)B * cdiv(T, 32);
+        if (env_pair && env_nct == 0 && nct == 1 && 2 * 8 * cdiv(t32, 8) <= h->num_cus) {
+          if (h->occ_pair < 0) h->occ_pair = pair_h2_occupancy() >= 1 ? 1 : 0;
+          if (h->occ_pair >= 1) {
+            h->stack_is_h2 = true;
+            h->stack_nct = 1;
+            h->stack_pair = true;
+            return B;
+          }
+        }
+      }
       if (h->occ_stack_h2[nct] < 0) h->occ_stack_h2[nct] = stack_h2_occupancy(nct) >= 1 ? 1 : 0;
       const int tpr = cdiv(T, 32 * nct);
       if (h->occ_stack_h2[nct] >= 1 && tpr <= h->num_cus) {
@@ -1595,6 +1622,7 @@ constexpr unsigned kFlagSpan = 64;
 static int next_stack_epoch(bsg_diffnet* h, hipStream_t st, unsigned* fbase) {
   if (++h->stack_epoch >= (1u << 25)) {
     BSG_HIP(hipMemsetAsync(h->flags, 0, h->flags_cap * sizeof(unsigned), st));
+    if (h->pair_flags) BSG_HIP(hipMemsetAsync(h->pair_flags, 0, 2 * h->pair_cap * 2 * sizeof(unsigned), st));
     h->stack_epoch = 1;
   }
   *fbase = h->stack_epoch * kFlagSpan;
@@ -1625,7 +1653,26 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
-    if (h2) {
+    if (h2 && h->stack_pair) {
+      BSG_REQUIRE(!tail && nb == B, "pair launch: whole batch, no fused tail");
+      p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
+      if ((size_t)p.n_tiles > h->pair_cap) {
+        BSG_HIP(hipStreamSynchronize(st));
+        if (h->pair_zx) (void)hipFree(h->pair_zx);
+        if (h->pair_ix) (void)hipFree(h->pair_ix);
+        if (h->pair_flags) (void)hipFree(h->pair_flags);
+        h->pair_zx = nullptr; h->pair_ix = nullptr; h->pair_flags = nullptr; h->pair_cap = 0;
+        const size_t cap = (size_t)h->num_cus / 2 > (size_t)p.n_tiles ? (size_t)h->num_cus / 2 : (size_t)p.n_tiles;
+        const size_t slot = (size_t)2 * 32 * (C / 2) * sizeof(unsigned short);   // one half: 2 planes x 32 frames x C/2 fp16 = 16 KB
+        BSG_HIP(hipMalloc((void**)&h->pair_zx, cap * 2 * slot));
+        BSG_HIP(hipMalloc((void**)&h->pair_ix, 2 * cap * 2 * slot));
+        BSG_HIP(hipMalloc((void**)&h->pair_flags, 2 * cap * 2 * sizeof(unsigned)));
+        BSG_HIP(hipMemsetAsync(h->pair_flags, 0, 2 * cap * 2 * sizeof(unsigned), st));   // flag values are launch epoch x 64 + layer: monotonic
+        h->pair_cap = cap;
+      }
+      p.zx = h->pair_zx; p.ix = h->pair_ix; p.pflags = h->pair_flags;
+      TRY(launch_residual_pair_h2(p, st));
+    } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
         TailArgs a = *tail;
@@ -1649,7 +1696,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     }
   }
   BSG_REQUIRE(!tail || h2, "stack launch: a fused tail needs the split-fp16 form");
-  h->last_path = h2 ? (tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
+  h->last_path = h2 ? (h->stack_pair ? "stack_h2_pair" : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
   return BSG_OK;
 }
 
@@ -1843,7 +1890,7 @@ static int step_from_xa(bsg_diffnet* h, int t_uniform, TailArgs& a, float* x, in
   static int env = -1;
   if (env < 0) { const char* e = getenv("BSG_H2_TAIL"); env = e ? atoi(e) : 1; }
   const int srows = (h->no_split || h->compute != BSG_COMPUTE_F32 || !env || !h->tail_s || h->M > 96) ? 0 : stack_rows(h, B, T, st);
-  if (srows && h->stack_is_h2) {
+  if (srows && h->stack_is_h2 && !h->stack_pair) {
     const size_t off = (size_t)h->row_off * C * T;
     a.x = x; a.xa_next = h->xa + off;
     a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;

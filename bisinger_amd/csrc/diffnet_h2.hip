@@ -378,7 +378,31 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       };
       auto mid = [&]() {
         if (l == 0) return;   // layer 0 staged its halo rows from HBM
-        if (tid == 0) {
+        if constexpr (NCT == 1) {   // (measured: +1.1 % for the 32-frame form at B=8, -0.8 % for the 64-frame form at B=16: profiles/r03_ab_poll.log)
+        if (wave == 0) {
+          // lane 0 polls the left neighbour's flag, lane 1 the right one's — both loads in flight together (one L2 round trip, not two)
+          const unsigned want = p.fbase + (unsigned)l;
+          const bool mine = lane == 0 ? has_left : (lane == 1 ? has_right : false);
+          const unsigned* fl = p.flags + (lane == 0 ? tile_id - 1 : tile_id + 1);
+          bool pend = mine;
+          if (p.inject) {
+            if (pend) atomicAdd(p.status, 1u);
+          } else {
+            unsigned spins = 0;
+            while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+              if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
+              if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+              __builtin_amdgcn_s_sleep(2);
+              // ~ seconds: never reached unless a workgroup is not resident.  Once ANY wait of this handle has given up (status != 0: the host
+              // repeats the call without hand-offs anyway) the others stop waiting within a thousand polls instead of seconds each
+              if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (pend) atomicAdd(p.status, 1u);
+                break;
+              }
+            }
+          }
+        }
+        } else if (tid == 0) {
           const unsigned want = p.fbase + (unsigned)l;
 #pragma unroll
           for (int side = 0; side < 2; ++side) {
@@ -388,8 +412,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
               __builtin_amdgcn_s_sleep(2);
-              // ~ seconds: never reached unless a workgroup is not resident.  Once ANY wait of this handle has given up (status != 0: the host
-              // repeats the call without hand-offs anyway) the others stop waiting within a thousand polls instead of seconds each
               if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 atomicAdd(p.status, 1u);
                 break;
@@ -696,6 +718,394 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     }
   }
 }
+// ------------------------------------------------------------------------------------------------
+// PAIR form for small batches (B * ceil(T / 32) <= CUs / 2; B <= 4 at T = 1000).  With one workgroup per 32-frame tile a single utterance
+// keeps 32 of the 256 CUs busy, and each of them is bound by streaming the layer's 2.1 MB of weight fragments out of L2 (the two GEMMs
+// take 18.8 us of a 25.5-us layer where their MFMAs need 10; tools/l2_fill.hip: a CU pulls at most ~64 B/clk).  Here a tile is computed by
+// TWO workgroups of 4 waves on two CUs of one XCD, each owning HALF of the channels — its gate / filter rows of GEMM1, its residual / skip
+// rows of GEMM2, its 128 channels of x and of the skip sum in registers — so every CU streams half of the weights.  What a workgroup
+// lacks it gets from its partner through L2, twice per layer, with the hand-off protocol of the launch above (write-through stores,
+// drain, barrier, flag = launch epoch + layer, bounded poll, sc1 loads):
+//   * after the gate: the partner's half of z (16 KB, both planes) — GEMM2 contracts over all 256 channels;
+//   * after GEMM2: the partner's half of the next image (16 KB) and, from the two neighbouring tiles' workgroups, the 8-frame edges of
+//     both halves — GEMM1 contracts over all 256 channels of 48 frames.  GEMM1 starts with the centre tap of its OWN channels (8 k-steps),
+//     the only part of the image a workgroup has without waiting.
+// The step tail is not fused (its skip projection contracts over both halves): the skip sum goes to HBM and step_tail_kernel follows.
+// ------------------------------------------------------------------------------------------------
+constexpr int PCH = C / 2;   // channels per workgroup of a pair
+
+// i-th executed k-step of GEMM1 -> k-step index (tap-major, 16 channel groups per tap) for part q
+__device__ __forceinline__ int kmap_pair(int i, int q) {
+  if (i < 8) return 16 + 8 * q + i;                  // centre tap, own channels
+  if (i < 16) return 16 + 8 * (1 - q) + (i - 8);     // centre tap, the partner's channels
+  if (i < 32) return i - 16;                         // tap 0
+  return i;                                          // tap 2
+}
+
+// the k-step pipeline of mfma_pipe_h2 for one column tile, with the k-step order given by `km`
+template <int ROT, typename KM, typename LDB, typename MID>
+__device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks,
+                                               KM km, LDB ldb, MID mid) {
+  f16x8 B[2][2];
+  ldb(km(0), B[0]);
+  const int last = n_ks - 1;
+#pragma unroll 1
+  for (int ks = 0; ks < n_ks; ks += NSH) {
+    if (ROT > 0 && ks == ROT) {
+      mid();
+      ldb(km(ks), B[0]);
+    }
+#pragma unroll
+    for (int s = 0; s < NSH; ++s) {
+      const int in = ks + s + 1 <= last ? ks + s + 1 : last;
+      // (never across the hand-off: the k-step behind it is read again above)
+      ldb(km(in), B[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8(&Bc)[2] = B[s & 1];
+      BSG_MFMA_H(c0, A[s][0], Bc[0]);
+      BSG_MFMA_H(c1, A[s][2], Bc[0]);
+      BSG_MFMA_H(c0, A[s][0], Bc[1]);
+      BSG_MFMA_H(c1, A[s][2], Bc[1]);
+      BSG_MFMA_H(c0, A[s][1], Bc[0]);
+      BSG_MFMA_H(c1, A[s][3], Bc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
+      const int kr = km(ir);
+      A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
+      A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
+      A[s][2] = lda8(rs, vfrag, sa1 + kr * KSB2);
+      A[s][3] = lda8(rs, vfrag, sa1 + kr * KSB2 + PLB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
+  constexpr int NT = 32, XP = h2_xp(1), ZP = h2_zp(1);
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;                  // [2 planes][48 frames][528 B]: hi / lo of x + d_l, ALL channels, frames t0-8 .. t0+39
+  char* zs = lds_raw + 2 * XP;         // [2 planes][32 frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
+  float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]
+  float* btab = dtab + C;                                              // [512]
+
+  // workgroup -> (tile, part): the two parts of a tile sit on the same XCD (workgroup i runs on XCD i mod 8)
+  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
+  const int slot = (int)blockIdx.x >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + (slot >> 1);
+  const int q = slot & 1;
+  if ((slot >> 1) >= per_xcd || tile_id >= n_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tpr = p.tiles_per_row, L = p.L, T = p.T;
+  const int b = tile_id / tpr, j = tile_id - b * tpr;
+  const int t0 = j * NT;
+  const int tb = p.t_dev ? (int)p.t_dev[b] : p.t_uniform;
+  const bool has_left = j > 0, has_right = j + 1 < tpr;
+  const int cb = PCH * q + 32 * wave;   // first channel of this wave
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
+  const int rowT = T * 4, vfrag = lane * 16;
+  const int col = t0 + l31;
+  const bool col_ok = col < T;
+  const int vcol = (lh * 4 * T + (col_ok ? col : T - 1)) * 4, vst = (lh * 4 * T + col) * 4;
+  const int sa_g = (4 * q + wave) * 1024, sa_f = (8 + 4 * q + wave) * 1024;   // gate / filter (= residual / skip) row tile inside a plane of a k-step slab
+
+  float xr[16], sk[16];
+  f32x16 yg, yf;
+  int range_flag = 0;
+  auto range_check = [&](unsigned worst) {
+    if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
+  };
+  auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+  unsigned* fx = p.pflags;                   // image flags [n_tiles][2]
+  unsigned* fz = p.pflags + 2 * n_tiles;     // z flags     [n_tiles][2]
+  // a whole wave: every lane with a flag polls its own (all in flight together); bounded like wait_flag
+  auto wait_flags = [&](const unsigned* fl, unsigned want) {
+    bool pend = fl != nullptr;
+    if (p.inject) {
+      if (pend) atomicAdd(p.status, 1u);
+      return;
+    }
+    unsigned spins = 0;
+    while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+      if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
+      if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+      __builtin_amdgcn_s_sleep(2);
+      ++spins;
+      const bool quit = spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+      if (quit) {
+        if (pend) atomicAdd(p.status, 1u);
+        break;
+      }
+    }
+  };
+  auto wait_flag = [&](const unsigned* fl, unsigned want) {   // one lane; bounded (see residual_stack_h2_kernel)
+    if (p.inject) { atomicAdd(p.status, 1u); return; }
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        atomicAdd(p.status, 1u);
+        break;
+      }
+    }
+  };
+
+  auto cond_request = [&](int l) {
+    const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int so = (cb + acc_row0(r)) * rowT;
+      yg[r] = ldf(rs_ct, vcol, so);
+      yf[r] = ldf(rs_ct, vcol, so + C * rowT);
+    }
+  };
+  auto write_core = [&]() {
+    float dv[16];
+    unsigned worst = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[r] = dtab[cb + acc_row(r, lh)];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float v0 = xr[4 * g] + dv[4 * g], v1 = xr[4 * g + 1] + dv[4 * g + 1];
+      const float v2 = xr[4 * g + 2] + dv[4 * g + 2], v3 = xr[4 * g + 3] + dv[4 * g + 3];
+      worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
+      const HiLo s0 = split2(v0, v1);
+      const HiLo s1_ = split2(v2, v3);
+      u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
+      if (!col_ok) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+      char* dst = xs + (HALO + l31) * ROWB + (cb + 8 * g + 4 * lh) * 2;
+      *reinterpret_cast<u32x2*>(dst) = wh;
+      *reinterpret_cast<u32x2*>(dst + XP) = wl;
+    }
+    range_check(worst);
+  };
+  // a half (PCH channels) of `rows` LDS rows starting at row r0, both planes, to / from an exchange slot [plane][rows][PCH]: 16-byte
+  // pieces, write-through stores / sc1 loads (the hand-off form that needs no acquire)
+  auto half_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot) {
+    const rsrc_t rs = mk_rsrc(slot, 2 * NT * PCH * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int piece = k * 256 + tid;   // 2 planes x 32 rows x 16 chunks of 8 channels
+      const int pl = piece >> 9, f = (piece >> 4) & 31, c16 = piece & 15;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (PCH * part + 8 * c16) * 2);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
+    }
+  };
+  auto half_in = [&](char* img, int plane_bytes, int r0, int part, const unsigned short* slot) {
+    const rsrc_t rs = mk_rsrc(slot, 2 * NT * PCH * 2);
+    u32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int piece = k * 256 + tid;
+      const int pl = piece >> 9, f = (piece >> 4) & 31, c16 = piece & 15;
+      v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int piece = k * 256 + tid;
+      const int pl = piece >> 9, f = (piece >> 4) & 31, c16 = piece & 15;
+      *reinterpret_cast<u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (PCH * part + 8 * c16) * 2) = v[k];
+    }
+  };
+  const size_t slot_halfs = (size_t)2 * NT * PCH;   // fp16 elements of one exchange slot
+  auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * 2 + part) * slot_halfs; };
+  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * 2 + part) * slot_halfs; };
+
+  // ---- layer 0: x from HBM — this wave's channels into registers, the WHOLE image (all channels, halo frames included) into LDS ----------
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    xr[r] = ldf(rs_x, vcol, (cb + acc_row0(r)) * rowT);
+    sk[r] = 0.f;
+  }
+  {
+    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
+    unsigned worst = 0;
+#pragma unroll 1
+    for (int it = 0; it < 6; ++it) {   // 32 chunks of 8 channels x 48 frames = 1536 items, lanes = consecutive frames
+      const int item = it * 256 + tid;
+      const int hc = item / 48, row = item - hc * 48;
+      const int th = t0 - HALO + row;
+      const bool hok = th >= 0 && th < T;
+      float hv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
+      if (hok) worst = max(worst, max(max(max(absbits(hv[0]), absbits(hv[1])), max(absbits(hv[2]), absbits(hv[3]))),
+                                      max(max(absbits(hv[4]), absbits(hv[5])), max(absbits(hv[6]), absbits(hv[7])))));
+      const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
+      u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
+      if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
+      *reinterpret_cast<u32x4*>(xs + row * ROWB + hc * 16) = wh;
+      *reinterpret_cast<u32x4*>(xs + XP + row * ROWB + hc * 16) = wl;
+    }
+    range_check(worst);
+  }
+  dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
+  btab[tid] = p.bias_out[tid];
+  btab[tid + 256] = p.bias_out[tid + 256];
+  cond_request(0);
+  f16x8 A[NSH][4];
+  auto prefetch_a1 = [&](int l) {
+    const rsrc_t rs = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) {
+      const int kr = kmap_pair(k, q);
+      A[k][0] = lda8(rs, vfrag, sa_g + kr * KSB2);
+      A[k][1] = lda8(rs, vfrag, sa_g + kr * KSB2 + PLB);
+      A[k][2] = lda8(rs, vfrag, sa_f + kr * KSB2);
+      A[k][3] = lda8(rs, vfrag, sa_f + kr * KSB2 + PLB);
+    }
+  };
+  prefetch_a1(0);
+  __syncthreads();   // the staged image and the tables
+
+#define PAIR_STAMP(i)                                                                                                      \
+  do {                                                                                                                    \
+    if (p.stamps && tid == 0 && q == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int dil = 1 << (l % p.cycle);
+    const rsrc_t rs_a1 = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+    const rsrc_t rs_a2 = mk_rsrc(p.apack2s + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
+    const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
+    const float dnext = l + 1 < L ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;
+    const float bnext0 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
+    const float bnext1 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tid] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { yg[r] *= s1; yf[r] *= s1; }
+    PAIR_STAMP(0);
+    // ---- GEMM1: the centre tap of the own channels first (8 k-steps); behind it the partner's half of the image and the neighbours' edges
+    {
+      const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
+      auto ldb = [&](int ks, f16x8 (&Bf)[2]) {
+        const int tap = ks >> 4, kc = ks & 15;
+        const char* qp = xb + ((tap - 1) * dil) * ROWB + kc * 32;
+        Bf[0] = *reinterpret_cast<const f16x8*>(qp);
+        Bf[1] = *reinterpret_cast<const f16x8*>(qp + XP);
+      };
+      auto mid = [&]() {
+        if (l == 0) return;   // layer 0 staged the whole image from HBM
+        if (wave == 0) {
+          // five flags (the partner's and the two neighbouring tiles' halves), polled by five lanes AT ONCE: one L2 round trip, not five
+          const unsigned want = p.fbase + (unsigned)l;
+          const unsigned* fl = lane == 0 ? fx + 2 * tile_id + (1 - q)
+                               : (lane <= 2 ? (has_left ? fx + 2 * (tile_id - 1) + (lane - 1) : nullptr)
+                                            : (lane <= 4 ? (has_right ? fx + 2 * (tile_id + 1) + (lane - 3) : nullptr) : nullptr));
+          wait_flags(fl, want);
+        }
+        __syncthreads();   // (D) the polling lanes have seen the flags
+        PAIR_STAMP(1);
+        half_in(xs, XP, HALO, 1 - q, ix_slot(l & 1, tile_id, 1 - q));   // the partner's channels of the core frames
+        {
+          // halo rows, both planes, both halves: rows 0..7 = the left tile's frames 24..31, rows 40..47 = the right tile's frames 0..7
+          u32x4 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int piece = k * 256 + tid;   // 2 sides x 2 parts x 2 planes x 8 frames x 16 chunks
+            const int side = piece >> 9, part = (piece >> 8) & 1, pl = (piece >> 7) & 1, f = (piece >> 4) & 7, c16 = piece & 15;
+            const bool have = side == 0 ? has_left : has_right;
+            v[k] = u32x4{0u, 0u, 0u, 0u};
+            if (have) {
+              const rsrc_t rs = mk_rsrc(ix_slot(l & 1, side == 0 ? tile_id - 1 : tile_id + 1, part), 2 * NT * PCH * 2);
+              v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + (side == 0 ? NT - 8 : 0) + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int piece = k * 256 + tid;
+            const int side = piece >> 9, part = (piece >> 8) & 1, pl = (piece >> 7) & 1, f = (piece >> 4) & 7, c16 = piece & 15;
+            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWB + (PCH * part + 8 * c16) * 2) = v[k];
+          }
+        }
+        __syncthreads();   // (A) the whole image is in place
+        PAIR_STAMP(2);
+      };
+      mfma_pipe_pair<8>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, [&](int i) { return kmap_pair(i, q); }, ldb, mid);
+    }
+    PAIR_STAMP(3);
+    // ---- gate -> own half of zs (hi / lo of 2^10 z); GEMM2's first weights fly meanwhile -----------------------------------------
+#pragma unroll
+    for (int k = 0; k < NSH; ++k) {
+      A[k][0] = lda8(rs_a2, vfrag, sa_g + k * KSB2);
+      A[k][1] = lda8(rs_a2, vfrag, sa_g + k * KSB2 + PLB);
+      A[k][2] = lda8(rs_a2, vfrag, sa_f + k * KSB2);
+      A[k][3] = lda8(rs_a2, vfrag, sa_f + k * KSB2 + PLB);
+    }
+    dtab[tid] = dnext;   // read by write_core() behind the barriers below
+    const float rs2 = inv2 * 0.70710678118654752440f;
+    const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x2 z01 = gate2_scaled(f32x2{yg[4 * g], yg[4 * g + 1]}, f32x2{yf[4 * g], yf[4 * g + 1]}, gcg, gcf, glim, ZSCALE);
+      const f32x2 z23 = gate2_scaled(f32x2{yg[4 * g + 2], yg[4 * g + 3]}, f32x2{yf[4 * g + 2], yf[4 * g + 3]}, gcg, gcf, glim, ZSCALE);
+      const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
+      char* dst = zs + l31 * ROWB + (cb + 8 * g + 4 * lh) * 2;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+      *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float br = btab[cb + acc_row(r, lh)], bs = btab[C + cb + acc_row(r, lh)];
+      yg[r] = (xr[r] + br) * s2;
+      yf[r] = bs * s2;
+    }
+    __syncthreads();   // (Z1) the own half of z is complete in LDS; every wave is done reading xs and this layer's biases
+    btab[tid] = bnext0;
+    btab[tid + 256] = bnext1;
+    if (!(p.inject && (tile_id & 1))) half_out(zs, ZP, 0, q, zx_slot(tile_id, q));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores (and GEMM2's first weights) have landed
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(fz + 2 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_flag(fz + 2 * tile_id + (1 - q), p.fbase + (unsigned)(l + 1));
+    }
+    __syncthreads();   // the partner's half of z is published
+    PAIR_STAMP(4);
+    half_in(zs, ZP, 0, 1 - q, zx_slot(tile_id, 1 - q));
+    __syncthreads();   // (B) zs complete
+    PAIR_STAMP(5);
+    // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows of the own channels ----------------------------------------------------
+    {
+      const char* zb = zs + l31 * ROWB + lh * 16;
+      auto ldb = [&](int ks, f16x8 (&Bf)[2]) {
+        Bf[0] = *reinterpret_cast<const f16x8*>(zb + ks * 32);
+        Bf[1] = *reinterpret_cast<const f16x8*>(zb + ks * 32 + ZP);
+      };
+      mfma_pipe_pair<0>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 16, [](int i) { return i; }, ldb, [] {});
+    }
+    if (l + 1 < L) prefetch_a1(l + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xr[r] = yg[r] * rs2;
+      sk[r] += yf[r] * inv2;
+    }
+    PAIR_STAMP(6);
+    if (l + 1 == L) break;
+    // ---- next layer: the own half of the image into LDS and to the exchange slot, the flag — and only then the conditioner term into the
+    // free accumulators: its HBM latency overlaps the wait for the partner's half instead of delaying the own flag (vmcnt counts in order)
+    write_core();
+    __syncthreads();   // (C1) the own half of the core rows is complete
+    if (!(p.inject && (tile_id & 1))) half_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (C)
+    if (tid == 0) __hip_atomic_store(fx + 2 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PAIR_STAMP(7);
+    cond_request(l + 1);
+  }
+#undef PAIR_STAMP
+  if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);
+  // ---- the skip sum / sqrt(L) of the own channels (net.py:126), fp32 [C][T] rows: what step_tail_kernel reads ---------------------------
+  const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
+  const float rdiv = 1.0f / sqrtf((float)L);
+  if (col_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stf(sk[r] * rdiv, rs_sk, vst, (cb + acc_row0(r)) * rowT);
+  }
+}
+
 #undef BSG_MFMA_H
 
 }  // namespace
@@ -730,6 +1140,21 @@ static int h2_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
 // workgroup: p.tiles_per_row / p.n_tiles count tiles of 32 * nct frames
 int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct) {
   return nct == 1 ? h2_launch<1>(p, tail, st) : h2_launch<2>(p, tail, st);
+}
+
+constexpr size_t PAIR_LDS = h2_lds(1) > 84 * 1024 ? h2_lds(1) : 84 * 1024;   // > half of the CU's LDS: one workgroup per CU
+int pair_h2_occupancy() {
+  int o = 0;
+  if (hipFuncSetAttribute((const void*)residual_pair_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_pair_h2_kernel, 256, PAIR_LDS) != hipSuccess)
+    return 0;
+  return o;
+}
+int launch_residual_pair_h2(const StackArgs& p, hipStream_t st) {
+  BSG_REQUIRE(p.zx && p.ix && p.pflags, "pair launch: exchange buffers missing");
+  hipLaunchKernelGGL(residual_pair_h2_kernel, dim3(16 * cdiv(p.n_tiles, 8)), dim3(256), PAIR_LDS, st, p);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
 }
 
 // the three projections of the step tail as split-fp16 fragments + their scale table [3][2]; maxbits: [3] scratch
