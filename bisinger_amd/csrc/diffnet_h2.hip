@@ -742,21 +742,25 @@ __device__ __forceinline__ int kmap_pair(int i, int q) {
   return i;                                          // tap 2
 }
 
+// weight ring of the pair form in k-steps: one wave per SIMD has the registers, and with half as many waves per CU the bytes in flight —
+// not the L2 — bound the weight stream (phase stamps at B=1 with a ring of 4: 0.22 us per k-step where the MFMAs need 0.08)
+constexpr int NSP = 8;   // (measured at B=1, us per layer: ring 4 18.6, ring 8 17.5, ring 16 18.9; three accumulators per row tile instead of one, or an
+                         // L2 prefetch of the next layer's weights, change nothing: profiles/r03_pair_form/)
 // the k-step pipeline of mfma_pipe_h2 for one column tile, with the k-step order given by `km`
 template <int ROT, typename KM, typename LDB, typename MID>
-__device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A)[NSH][4], rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks,
+__device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A)[NSP][4], rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks,
                                                KM km, LDB ldb, MID mid) {
   f16x8 B[2][2];
   ldb(km(0), B[0]);
   const int last = n_ks - 1;
 #pragma unroll 1
-  for (int ks = 0; ks < n_ks; ks += NSH) {
-    if (ROT > 0 && ks == ROT) {
-      mid();
-      ldb(km(ks), B[0]);
-    }
+  for (int ks = 0; ks < n_ks; ks += NSP) {
 #pragma unroll
-    for (int s = 0; s < NSH; ++s) {
+    for (int s = 0; s < NSP; ++s) {
+      if (ROT > 0 && s == ROT % NSP && ks == ROT - ROT % NSP) {   // the hand-off sits behind the first ROT k-steps
+        mid();
+        ldb(km(ks + s), B[s & 1]);
+      }
       const int in = ks + s + 1 <= last ? ks + s + 1 : last;
       // (never across the hand-off: the k-step behind it is read again above)
       ldb(km(in), B[(s + 1) & 1]);
@@ -769,7 +773,7 @@ __device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A
       BSG_MFMA_H(c0, A[s][1], Bc[0]);
       BSG_MFMA_H(c1, A[s][3], Bc[0]);
       __builtin_amdgcn_sched_barrier(0);
-      const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
+      const int ir = ks + s + NSP <= last ? ks + s + NSP : last;
       const int kr = km(ir);
       A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
       A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
@@ -946,11 +950,11 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
   btab[tid] = p.bias_out[tid];
   btab[tid + 256] = p.bias_out[tid + 256];
   cond_request(0);
-  f16x8 A[NSH][4];
+  f16x8 A[NSP][4];
   auto prefetch_a1 = [&](int l) {
     const rsrc_t rs = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
 #pragma unroll
-    for (int k = 0; k < NSH; ++k) {
+    for (int k = 0; k < NSP; ++k) {
       const int kr = kmap_pair(k, q);
       A[k][0] = lda8(rs, vfrag, sa_g + kr * KSB2);
       A[k][1] = lda8(rs, vfrag, sa_g + kr * KSB2 + PLB);
@@ -1026,14 +1030,7 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
       mfma_pipe_pair<8>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, [&](int i) { return kmap_pair(i, q); }, ldb, mid);
     }
     PAIR_STAMP(3);
-    // ---- gate -> own half of zs (hi / lo of 2^10 z); GEMM2's first weights fly meanwhile -----------------------------------------
-#pragma unroll
-    for (int k = 0; k < NSH; ++k) {
-      A[k][0] = lda8(rs_a2, vfrag, sa_g + k * KSB2);
-      A[k][1] = lda8(rs_a2, vfrag, sa_g + k * KSB2 + PLB);
-      A[k][2] = lda8(rs_a2, vfrag, sa_f + k * KSB2);
-      A[k][3] = lda8(rs_a2, vfrag, sa_f + k * KSB2 + PLB);
-    }
+    // ---- gate -> own half of zs (hi / lo of 2^10 z) ---------------------------------------------------------------------------------
     dtab[tid] = dnext;   // read by write_core() behind the barriers below
     const float rs2 = inv2 * 0.70710678118654752440f;
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
@@ -1056,8 +1053,17 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
     btab[tid] = bnext0;
     btab[tid + 256] = bnext1;
     if (!(p.inject && (tile_id & 1))) half_out(zs, ZP, 0, q, zx_slot(tile_id, q));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores (and GEMM2's first weights) have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
     __syncthreads();
+    // GEMM2's first weights are requested only now: in front of the drain they would delay the flag by their own latency (vmcnt counts in
+    // order), here they land while the partner's half of z is on its way
+#pragma unroll
+    for (int k = 0; k < NSP; ++k) {
+      A[k][0] = lda8(rs_a2, vfrag, sa_g + k * KSB2);
+      A[k][1] = lda8(rs_a2, vfrag, sa_g + k * KSB2 + PLB);
+      A[k][2] = lda8(rs_a2, vfrag, sa_f + k * KSB2);
+      A[k][3] = lda8(rs_a2, vfrag, sa_f + k * KSB2 + PLB);
+    }
     if (tid == 0) {
       __hip_atomic_store(fz + 2 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       wait_flag(fz + 2 * tile_id + (1 - q), p.fbase + (unsigned)(l + 1));
@@ -1076,7 +1082,6 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
       };
       mfma_pipe_pair<0>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 16, [](int i) { return i; }, ldb, [] {});
     }
-    if (l + 1 < L) prefetch_a1(l + 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       xr[r] = yg[r] * rs2;
@@ -1094,6 +1099,7 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
     if (tid == 0) __hip_atomic_store(fx + 2 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PAIR_STAMP(7);
     cond_request(l + 1);
+    prefetch_a1(l + 1);   // (behind the drain, like the conditioner term)
   }
 #undef PAIR_STAMP
   if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);
