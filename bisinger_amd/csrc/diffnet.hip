@@ -1076,11 +1076,11 @@ struct bsg_diffnet {
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
   int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
   bool stack_pair = false;             // ... the pair form (two workgroups per 32-frame tile, diffnet_h2.hip residual_pair_h2_kernel)
-  int occ_pair = -1;                   // resident workgroups per CU of the pair form (-1: not queried)
+  int occ_pair[3] = {-1, -1, -1};      // resident workgroups per CU of the pair form by tile width in column tiles (-1: not queried)
   unsigned short* pair_zx = nullptr;   // pair form: exchange slots of the z halves [tiles][2][2 planes][32][C/2] fp16
   unsigned short* pair_ix = nullptr;   //            ... of the image halves [2 parities][tiles][2][2 planes][32][C/2]
   unsigned* pair_flags = nullptr;      //            [2][tiles][2] image / z flags
-  size_t pair_cap = 0;                 // tiles the pair buffers are sized for
+  size_t pair_cap = 0;                 // 32-frame tile equivalents the pair buffers are sized for
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1564,18 +1564,24 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       if (env_nct == 1 || env_nct == 2) nct = env_nct;
       h->stack_pair = false;
       {
-        // pair form: when the 32-frame tiles fill at most half of the CUs (B <= 4 at T = 1000), two workgroups on two CUs share a tile, each
-        // half of the channels and half of the weight stream; whole batch in one launch.  BSG_H2_PAIR=0: off
+        // pair form (residual_pair_h2_kernel): two workgroups on two CUs of an XCD share a tile, each half of the channels and half of the weight
+        // stream; the whole batch in one launch.  Taken while pairs of 32-frame tiles fit the chip: B * ceil(T / 32) <= CUs / 2 (B <= 4 at T = 1000;
+        // ms per 100-step pass at T = 1000, one workgroup per tile / pairs: B=1 54.5 / 44.8, B=2 52.6 / 46.1, B=4 51.5 / 47.7).  Pairs of 64-frame
+        // tiles (B = 5 .. 8) measured SLOWER than one workgroup per 32-frame tile (B=8: 77.4 against 68.1 ms): with one wave per SIMD the matrix
+        // pipe is busy half of a k-step — BSG_H2_PAIR=2 selects them for experiments; BSG_H2_PAIR=0: no pair form at all
         static int env_pair = -1;
         if (env_pair < 0) { const char* e = getenv("BSG_H2_PAIR"); env_pair = e ? atoi(e) : 1; }
-        const long long t32 = (long long)B * cdiv(T, 32);
-        if (env_pair && env_nct == 0 && nct == 1 && 2 * 8 * cdiv(t32, 8) <= h->num_cus) {
-          if (h->occ_pair < 0) h->occ_pair = pair_h2_occupancy() >= 1 ? 1 : 0;
-          if (h->occ_pair >= 1) {
-            h->stack_is_h2 = true;
-            h->stack_nct = 1;
-            h->stack_pair = true;
-            return B;
+        if (env_pair && env_nct == 0) {
+          const long long t32 = (long long)B * cdiv(T, 32), t64 = (long long)B * cdiv(T, 64);
+          const int pn = 2 * 8 * cdiv(t32, 8) <= h->num_cus ? 1 : (env_pair >= 2 && 2 * 8 * cdiv(t64, 8) <= h->num_cus ? 2 : 0);
+          if (pn) {
+            if (h->occ_pair[pn] < 0) h->occ_pair[pn] = pair_h2_occupancy(pn) >= 1 ? 1 : 0;
+            if (h->occ_pair[pn] >= 1) {
+              h->stack_is_h2 = true;
+              h->stack_nct = pn;
+              h->stack_pair = true;
+              return B;
+            }
           }
         }
       }
@@ -1656,14 +1662,15 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     if (h2 && h->stack_pair) {
       BSG_REQUIRE(!tail && nb == B, "pair launch: whole batch, no fused tail");
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
-      if ((size_t)p.n_tiles > h->pair_cap) {
+      const size_t need32 = (size_t)p.n_tiles * nct;   // slots scale with the tile width: size the buffers in 32-frame tile equivalents
+      if (need32 > h->pair_cap) {
         BSG_HIP(hipStreamSynchronize(st));
         if (h->pair_zx) (void)hipFree(h->pair_zx);
         if (h->pair_ix) (void)hipFree(h->pair_ix);
         if (h->pair_flags) (void)hipFree(h->pair_flags);
         h->pair_zx = nullptr; h->pair_ix = nullptr; h->pair_flags = nullptr; h->pair_cap = 0;
-        const size_t cap = (size_t)h->num_cus / 2 > (size_t)p.n_tiles ? (size_t)h->num_cus / 2 : (size_t)p.n_tiles;
-        const size_t slot = (size_t)2 * 32 * (C / 2) * sizeof(unsigned short);   // one half: 2 planes x 32 frames x C/2 fp16 = 16 KB
+        const size_t cap = (size_t)h->num_cus > need32 ? (size_t)h->num_cus : need32;
+        const size_t slot = (size_t)2 * 32 * (C / 2) * sizeof(unsigned short);   // one half of a 32-frame tile: 2 planes x 32 frames x C/2 fp16 = 16 KB
         BSG_HIP(hipMalloc((void**)&h->pair_zx, cap * 2 * slot));
         BSG_HIP(hipMalloc((void**)&h->pair_ix, 2 * cap * 2 * slot));
         BSG_HIP(hipMalloc((void**)&h->pair_flags, 2 * cap * 2 * sizeof(unsigned)));
@@ -1671,7 +1678,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
         h->pair_cap = cap;
       }
       p.zx = h->pair_zx; p.ix = h->pair_ix; p.pflags = h->pair_flags;
-      TRY(launch_residual_pair_h2(p, st));
+      TRY(launch_residual_pair_h2(p, st, nct));
     } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row

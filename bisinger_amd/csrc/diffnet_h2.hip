@@ -746,11 +746,11 @@ __device__ __forceinline__ int kmap_pair(int i, int q) {
 // not the L2 — bound the weight stream (phase stamps at B=1 with a ring of 4: 0.22 us per k-step where the MFMAs need 0.08)
 constexpr int NSP = 8;   // (measured at B=1, us per layer: ring 4 18.6, ring 8 17.5, ring 16 18.9; three accumulators per row tile instead of one, or an
                          // L2 prefetch of the next layer's weights, change nothing: profiles/r03_pair_form/)
-// the k-step pipeline of mfma_pipe_h2 for one column tile, with the k-step order given by `km`
-template <int ROT, typename KM, typename LDB, typename MID>
-__device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A)[NSP][4], rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks,
-                                               KM km, LDB ldb, MID mid) {
-  f16x8 B[2][2];
+// the k-step pipeline of mfma_pipe_h2 with the k-step order given by `km` (NCT column tiles of 32 frames)
+template <int ROT, int NCT, typename KM, typename LDB, typename MID>
+__device__ __forceinline__ void mfma_pipe_pair(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT], f16x8 (&A)[NSP][4], rsrc_t rs, int vfrag, int sa0, int sa1,
+                                               int n_ks, KM km, LDB ldb, MID mid) {
+  f16x8 B[2][2 * NCT];
   ldb(km(0), B[0]);
   const int last = n_ks - 1;
 #pragma unroll 1
@@ -765,13 +765,22 @@ __device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A
       // (never across the hand-off: the k-step behind it is read again above)
       ldb(km(in), B[(s + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      const f16x8(&Bc)[2] = B[s & 1];
-      BSG_MFMA_H(c0, A[s][0], Bc[0]);
-      BSG_MFMA_H(c1, A[s][2], Bc[0]);
-      BSG_MFMA_H(c0, A[s][0], Bc[1]);
-      BSG_MFMA_H(c1, A[s][2], Bc[1]);
-      BSG_MFMA_H(c0, A[s][1], Bc[0]);
-      BSG_MFMA_H(c1, A[s][3], Bc[0]);
+      const f16x8(&Bc)[2 * NCT] = B[s & 1];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // hi hi
+        BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct]);
+        BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // hi lo
+        BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct + 1]);
+        BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct + 1]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // lo hi
+        BSG_MFMA_H(c0[ct], A[s][1], Bc[2 * ct]);
+        BSG_MFMA_H(c1[ct], A[s][3], Bc[2 * ct]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       const int ir = ks + s + NSP <= last ? ks + s + NSP : last;
       const int kr = km(ir);
@@ -784,11 +793,15 @@ __device__ __forceinline__ void mfma_pipe_pair(f32x16& c0, f32x16& c1, f16x8 (&A
   }
 }
 
+// NCT = column tiles of 32 frames per tile: 1 (32-frame tiles: while those fill at most half of the CUs, B <= 4 at T = 1000) or 2 (64-frame
+// tiles: B = 5 .. 8 at T = 1000, where one workgroup per 32-frame tile had every CU stream the whole layer for half the matrix work)
+template <int NCT>
 __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
-  constexpr int NT = 32, XP = h2_xp(1), ZP = h2_zp(1);
+  constexpr int NT = 32 * NCT, XP = h2_xp(NCT), ZP = h2_zp(NCT);
+  constexpr int NPIECE = 2 * NT * 16;   // 16-byte pieces of one exchange slot: 2 planes x NT frames x 16 chunks of 8 channels
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  char* xs = lds_raw;                  // [2 planes][48 frames][528 B]: hi / lo of x + d_l, ALL channels, frames t0-8 .. t0+39
-  char* zs = lds_raw + 2 * XP;         // [2 planes][32 frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
+  char* xs = lds_raw;                  // [2 planes][NT + 16 frames][528 B]: hi / lo of x + d_l, ALL channels, frames t0-8 .. t0+NT+7
+  char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
   float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]
   float* btab = dtab + C;                                              // [512]
 
@@ -811,13 +824,19 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
   const unsigned plane = (unsigned)C * T * 4;
   const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
   const int rowT = T * 4, vfrag = lane * 16;
-  const int col = t0 + l31;
-  const bool col_ok = col < T;
-  const int vcol = (lh * 4 * T + (col_ok ? col : T - 1)) * 4, vst = (lh * 4 * T + col) * 4;
+  int vcol[NCT], vst[NCT];
+  bool col_ok[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int col = t0 + 32 * ct + l31;
+    col_ok[ct] = col < T;
+    vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
+    vst[ct] = (lh * 4 * T + col) * 4;
+  }
   const int sa_g = (4 * q + wave) * 1024, sa_f = (8 + 4 * q + wave) * 1024;   // gate / filter (= residual / skip) row tile inside a plane of a k-step slab
 
-  float xr[16], sk[16];
-  f32x16 yg, yf;
+  float xr[NCT][16], sk[NCT][16];
+  f32x16 yg[NCT], yf[NCT];
   int range_flag = 0;
   auto range_check = [&](unsigned worst) {
     if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
@@ -825,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
   auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
   unsigned* fx = p.pflags;                   // image flags [n_tiles][2]
   unsigned* fz = p.pflags + 2 * n_tiles;     // z flags     [n_tiles][2]
-  // a whole wave: every lane with a flag polls its own (all in flight together); bounded like wait_flag
+  // a whole wave: every lane with a flag polls its own (all in flight together); bounded like the polls of residual_stack_h2_kernel
   auto wait_flags = [&](const unsigned* fl, unsigned want) {
     bool pend = fl != nullptr;
     if (p.inject) {
@@ -845,7 +864,7 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
       }
     }
   };
-  auto wait_flag = [&](const unsigned* fl, unsigned want) {   // one lane; bounded (see residual_stack_h2_kernel)
+  auto wait_flag = [&](const unsigned* fl, unsigned want) {   // one lane
     if (p.inject) { atomicAdd(p.status, 1u); return; }
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
@@ -862,8 +881,11 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int so = (cb + acc_row0(r)) * rowT;
-      yg[r] = ldf(rs_ct, vcol, so);
-      yf[r] = ldf(rs_ct, vcol, so + C * rowT);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        yg[ct][r] = ldf(rs_ct, vcol[ct], so);
+        yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
+      }
     }
   };
   auto write_core = [&]() {
@@ -872,45 +894,47 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv[r] = dtab[cb + acc_row(r, lh)];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float v0 = xr[4 * g] + dv[4 * g], v1 = xr[4 * g + 1] + dv[4 * g + 1];
-      const float v2 = xr[4 * g + 2] + dv[4 * g + 2], v3 = xr[4 * g + 3] + dv[4 * g + 3];
-      worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
-      const HiLo s0 = split2(v0, v1);
-      const HiLo s1_ = split2(v2, v3);
-      u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
-      if (!col_ok) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
-      char* dst = xs + (HALO + l31) * ROWB + (cb + 8 * g + 4 * lh) * 2;
-      *reinterpret_cast<u32x2*>(dst) = wh;
-      *reinterpret_cast<u32x2*>(dst + XP) = wl;
-    }
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = xr[ct][4 * g] + dv[4 * g], v1 = xr[ct][4 * g + 1] + dv[4 * g + 1];
+        const float v2 = xr[ct][4 * g + 2] + dv[4 * g + 2], v3 = xr[ct][4 * g + 3] + dv[4 * g + 3];
+        worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
+        const HiLo s0 = split2(v0, v1);
+        const HiLo s1_ = split2(v2, v3);
+        u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
+        if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+        char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (cb + 8 * g + 4 * lh) * 2;
+        *reinterpret_cast<u32x2*>(dst) = wh;
+        *reinterpret_cast<u32x2*>(dst + XP) = wl;
+      }
     range_check(worst);
   };
-  // a half (PCH channels) of `rows` LDS rows starting at row r0, both planes, to / from an exchange slot [plane][rows][PCH]: 16-byte
-  // pieces, write-through stores / sc1 loads (the hand-off form that needs no acquire)
-  auto half_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot) {
-    const rsrc_t rs = mk_rsrc(slot, 2 * NT * PCH * 2);
+  // a half (PCH channels) of NT LDS rows starting at row r0, both planes, to / from an exchange slot [plane][NT][PCH]: 16-byte pieces,
+  // write-through stores / sc1 loads (the hand-off form that needs no acquire)
+  auto half_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot_p) {
+    const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * PCH * 2);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int piece = k * 256 + tid;   // 2 planes x 32 rows x 16 chunks of 8 channels
-      const int pl = piece >> 9, f = (piece >> 4) & 31, c16 = piece & 15;
+    for (int k = 0; k < NPIECE / 256; ++k) {
+      const int piece = k * 256 + tid;
+      const int pl = piece / (NT * 16), f = (piece >> 4) % NT, c16 = piece & 15;
       const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (PCH * part + 8 * c16) * 2);
       __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
     }
   };
-  auto half_in = [&](char* img, int plane_bytes, int r0, int part, const unsigned short* slot) {
-    const rsrc_t rs = mk_rsrc(slot, 2 * NT * PCH * 2);
-    u32x4 v[4];
+  auto half_in = [&](char* img, int plane_bytes, int r0, int part, const unsigned short* slot_p) {
+    const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * PCH * 2);
+    u32x4 v[NPIECE / 256];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NPIECE / 256; ++k) {
       const int piece = k * 256 + tid;
-      const int pl = piece >> 9, f = (piece >> 4) & 31, c16 = piece & 15;
+      const int pl = piece / (NT * 16), f = (piece >> 4) % NT, c16 = piece & 15;
       v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NPIECE / 256; ++k) {
       const int piece = k * 256 + tid;
-      const int pl = piece >> 9, f = (piece >> 4) & 31, c16 = piece & 15;
+      const int pl = piece / (NT * 16), f = (piece >> 4) % NT, c16 = piece & 15;
       *reinterpret_cast<u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (PCH * part + 8 * c16) * 2) = v[k];
     }
   };
@@ -920,17 +944,20 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
 
   // ---- layer 0: x from HBM — this wave's channels into registers, the WHOLE image (all channels, halo frames included) into LDS ----------
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    xr[r] = ldf(rs_x, vcol, (cb + acc_row0(r)) * rowT);
-    sk[r] = 0.f;
-  }
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xr[ct][r] = ldf(rs_x, vcol[ct], (cb + acc_row0(r)) * rowT);
+      sk[ct][r] = 0.f;
+    }
   {
     const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
     unsigned worst = 0;
+    constexpr int ROWS = NT + 2 * HALO;
 #pragma unroll 1
-    for (int it = 0; it < 6; ++it) {   // 32 chunks of 8 channels x 48 frames = 1536 items, lanes = consecutive frames
+    for (int it = 0; it < 32 * ROWS / 256; ++it) {   // 32 chunks of 8 channels x ROWS frames, lanes = consecutive frames
       const int item = it * 256 + tid;
-      const int hc = item / 48, row = item - hc * 48;
+      const int hc = item / ROWS, row = item - hc * ROWS;
       const int th = t0 - HALO + row;
       const bool hok = th >= 0 && th < T;
       float hv[8];
@@ -979,16 +1006,21 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
     const float bnext0 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
     const float bnext1 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tid] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { yg[r] *= s1; yf[r] *= s1; }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) { yg[ct][r] *= s1; yf[ct][r] *= s1; }
     PAIR_STAMP(0);
     // ---- GEMM1: the centre tap of the own channels first (8 k-steps); behind it the partner's half of the image and the neighbours' edges
     {
       const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[2]) {
+      auto ldb = [&](int ks, f16x8 (&Bf)[2 * NCT]) {
         const int tap = ks >> 4, kc = ks & 15;
         const char* qp = xb + ((tap - 1) * dil) * ROWB + kc * 32;
-        Bf[0] = *reinterpret_cast<const f16x8*>(qp);
-        Bf[1] = *reinterpret_cast<const f16x8*>(qp + XP);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(qp + 32 * ct * ROWB);
+          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(qp + 32 * ct * ROWB + XP);
+        }
       };
       auto mid = [&]() {
         if (l == 0) return;   // layer 0 staged the whole image from HBM
@@ -1004,7 +1036,7 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
         PAIR_STAMP(1);
         half_in(xs, XP, HALO, 1 - q, ix_slot(l & 1, tile_id, 1 - q));   // the partner's channels of the core frames
         {
-          // halo rows, both planes, both halves: rows 0..7 = the left tile's frames 24..31, rows 40..47 = the right tile's frames 0..7
+          // halo rows, both planes, both halves: rows 0..7 = the left tile's last 8 frames, rows NT+8..NT+15 = the right tile's first 8
           u32x4 v[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -1027,7 +1059,7 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
         __syncthreads();   // (A) the whole image is in place
         PAIR_STAMP(2);
       };
-      mfma_pipe_pair<8>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, [&](int i) { return kmap_pair(i, q); }, ldb, mid);
+      mfma_pipe_pair<8, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, [&](int i) { return kmap_pair(i, q); }, ldb, mid);
     }
     PAIR_STAMP(3);
     // ---- gate -> own half of zs (hi / lo of 2^10 z) ---------------------------------------------------------------------------------
@@ -1035,19 +1067,24 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
     const float rs2 = inv2 * 0.70710678118654752440f;
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x2 z01 = gate2_scaled(f32x2{yg[4 * g], yg[4 * g + 1]}, f32x2{yf[4 * g], yf[4 * g + 1]}, gcg, gcf, glim, ZSCALE);
-      const f32x2 z23 = gate2_scaled(f32x2{yg[4 * g + 2], yg[4 * g + 3]}, f32x2{yf[4 * g + 2], yf[4 * g + 3]}, gcg, gcf, glim, ZSCALE);
-      const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
-      char* dst = zs + l31 * ROWB + (cb + 8 * g + 4 * lh) * 2;
-      *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
-      *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
-    }
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x2 z01 = gate2_scaled(f32x2{yg[ct][4 * g], yg[ct][4 * g + 1]}, f32x2{yf[ct][4 * g], yf[ct][4 * g + 1]}, gcg, gcf, glim, ZSCALE);
+        const f32x2 z23 = gate2_scaled(f32x2{yg[ct][4 * g + 2], yg[ct][4 * g + 3]}, f32x2{yf[ct][4 * g + 2], yf[ct][4 * g + 3]}, gcg, gcf, glim, ZSCALE);
+        const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
+        char* dst = zs + (32 * ct + l31) * ROWB + (cb + 8 * g + 4 * lh) * 2;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+        *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
+      }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float br = btab[cb + acc_row(r, lh)], bs = btab[C + cb + acc_row(r, lh)];
-      yg[r] = (xr[r] + br) * s2;
-      yf[r] = bs * s2;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        yg[ct][r] = (xr[ct][r] + br) * s2;
+        yf[ct][r] = bs * s2;
+      }
     }
     __syncthreads();   // (Z1) the own half of z is complete in LDS; every wave is done reading xs and this layer's biases
     btab[tid] = bnext0;
@@ -1076,17 +1113,22 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
     // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows of the own channels ----------------------------------------------------
     {
       const char* zb = zs + l31 * ROWB + lh * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[2]) {
-        Bf[0] = *reinterpret_cast<const f16x8*>(zb + ks * 32);
-        Bf[1] = *reinterpret_cast<const f16x8*>(zb + ks * 32 + ZP);
+      auto ldb = [&](int ks, f16x8 (&Bf)[2 * NCT]) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(zb + 32 * ct * ROWB + ks * 32);
+          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(zb + 32 * ct * ROWB + ks * 32 + ZP);
+        }
       };
-      mfma_pipe_pair<0>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 16, [](int i) { return i; }, ldb, [] {});
+      mfma_pipe_pair<0, NCT>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 16, [](int i) { return i; }, ldb, [] {});
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      xr[r] = yg[r] * rs2;
-      sk[r] += yf[r] * inv2;
-    }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        xr[ct][r] = yg[ct][r] * rs2;
+        sk[ct][r] += yf[ct][r] * inv2;
+      }
     PAIR_STAMP(6);
     if (l + 1 == L) break;
     // ---- next layer: the own half of the image into LDS and to the exchange slot, the flag — and only then the conditioner term into the
@@ -1106,10 +1148,12 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
   // ---- the skip sum / sqrt(L) of the own channels (net.py:126), fp32 [C][T] rows: what step_tail_kernel reads ---------------------------
   const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
   const float rdiv = 1.0f / sqrtf((float)L);
-  if (col_ok) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stf(sk[r] * rdiv, rs_sk, vst, (cb + acc_row0(r)) * rowT);
-  }
+  for (int ct = 0; ct < NCT; ++ct)
+    if (col_ok[ct]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stf(sk[ct][r] * rdiv, rs_sk, vst[ct], (cb + acc_row0(r)) * rowT);
+    }
 }
 
 #undef BSG_MFMA_H
@@ -1148,17 +1192,22 @@ int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream
   return nct == 1 ? h2_launch<1>(p, tail, st) : h2_launch<2>(p, tail, st);
 }
 
-constexpr size_t PAIR_LDS = h2_lds(1) > 84 * 1024 ? h2_lds(1) : 84 * 1024;   // > half of the CU's LDS: one workgroup per CU
-int pair_h2_occupancy() {
+// LDS of the pair form: the image and z of the whole tile (both channel halves), and more than half of the CU's LDS so that a CU holds one workgroup
+constexpr size_t pair_lds(int nct) { return h2_lds(nct) > 84 * 1024 ? h2_lds(nct) : 84 * 1024; }
+template <int NCT>
+static int pair_occ() {
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_pair_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PAIR_LDS) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_pair_h2_kernel, 256, PAIR_LDS) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)residual_pair_h2_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds(NCT)) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_pair_h2_kernel<NCT>, 256, pair_lds(NCT)) != hipSuccess)
     return 0;
   return o;
 }
-int launch_residual_pair_h2(const StackArgs& p, hipStream_t st) {
+int pair_h2_occupancy(int nct) { return nct == 1 ? pair_occ<1>() : pair_occ<2>(); }
+int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct) {
   BSG_REQUIRE(p.zx && p.ix && p.pflags, "pair launch: exchange buffers missing");
-  hipLaunchKernelGGL(residual_pair_h2_kernel, dim3(16 * cdiv(p.n_tiles, 8)), dim3(256), PAIR_LDS, st, p);
+  const dim3 grid(16 * cdiv(p.n_tiles, 8)), block(256);
+  if (nct == 1) hipLaunchKernelGGL(residual_pair_h2_kernel<1>, grid, block, pair_lds(1), st, p);
+  else hipLaunchKernelGGL(residual_pair_h2_kernel<2>, grid, block, pair_lds(2), st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

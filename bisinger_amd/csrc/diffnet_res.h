@@ -59,8 +59,8 @@ struct StackArgs {
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
   // pair form of the split-fp16 launch (residual_pair_h2_kernel, small batches): exchange of the two channel halves of a 32-frame tile
-  unsigned short* zx;     // [n_tiles][2 parts][2 planes][32 frames][C/2] fp16: gated activation halves
-  unsigned short* ix;     // [2 parities][n_tiles][2 parts][2 planes][32 frames][C/2] fp16: image halves (core frames; neighbours read the edges)
+  unsigned short* zx;     // [n_tiles][2 parts][2 planes][tile frames][C/2] fp16: gated activation halves
+  unsigned short* ix;     // [2 parities][n_tiles][2 parts][2 planes][tile frames][C/2] fp16: image halves (core frames; neighbours read the edges)
   unsigned* pflags;       // [2][n_tiles][2 parts]: [0] image flags (layers prepared), [1] z flags
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
   unsigned long long* clk;      // null, or [4]: tile 0 stores s_memtime / s_memrealtime at its start and end (sustained shader clock, bench.py)
@@ -75,8 +75,8 @@ int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf
 int stack_h2_occupancy(int nct);   // nct = column tiles of 32 frames per workgroup (1 or 2)
 // pair form: TWO workgroups of 4 waves (on two CUs of one XCD) per 32-frame tile, each one half of the channels; p.n_tiles tiles -> grid of
 // 16 * ceil(n_tiles / 8) workgroups, all of which must be resident (one per CU).  No fused tail: the skip sum goes to p.skip
-int launch_residual_pair_h2(const StackArgs& p, hipStream_t st);
-int pair_h2_occupancy();
+int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct);   // nct: 32- or 64-frame tiles (p.n_tiles / p.tiles_per_row count those)
+int pair_h2_occupancy(int nct);
 int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* maxbits, float* tab, hipStream_t st);
 int pack_a_frag_h2(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
                    int is_gemm2, hipStream_t st);
