@@ -1568,12 +1568,12 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
         // stream; the whole batch in one launch.  Taken while pairs of 32-frame tiles fit the chip: B * ceil(T / 32) <= CUs / 2 (B <= 4 at T = 1000;
         // ms per 100-step pass at T = 1000, one workgroup per tile / pairs: B=1 54.5 / 44.8, B=2 52.6 / 46.1, B=4 51.5 / 47.7).  Pairs of 64-frame
         // tiles (B = 5 .. 8) measured SLOWER than one workgroup per 32-frame tile (B=8: 77.4 against 68.1 ms): with one wave per SIMD the matrix
-        // pipe is busy half of a k-step — BSG_H2_PAIR=2 selects them for experiments; BSG_H2_PAIR=0: no pair form at all
+        // pipe is busy half of a k-step (profiles/r03_pair_form/) — not built.  BSG_H2_PAIR=0: no pair form at all
         static int env_pair = -1;
         if (env_pair < 0) { const char* e = getenv("BSG_H2_PAIR"); env_pair = e ? atoi(e) : 1; }
         if (env_pair && env_nct == 0) {
-          const long long t32 = (long long)B * cdiv(T, 32), t64 = (long long)B * cdiv(T, 64);
-          const int pn = 2 * 8 * cdiv(t32, 8) <= h->num_cus ? 1 : (env_pair >= 2 && 2 * 8 * cdiv(t64, 8) <= h->num_cus ? 2 : 0);
+          const long long t32 = (long long)B * cdiv(T, 32);
+          const int pn = 2 * 8 * cdiv(t32, 8) <= h->num_cus ? 1 : 0;
           if (pn) {
             if (h->occ_pair[pn] < 0) h->occ_pair[pn] = pair_h2_occupancy(pn) >= 1 ? 1 : 0;
             if (h->occ_pair[pn] >= 1) {

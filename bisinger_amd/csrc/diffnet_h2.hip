@@ -1202,12 +1202,12 @@ static int pair_occ() {
     return 0;
   return o;
 }
-int pair_h2_occupancy(int nct) { return nct == 1 ? pair_occ<1>() : pair_occ<2>(); }
+int pair_h2_occupancy(int nct) { return nct == 1 ? pair_occ<1>() : 0; }   // (pairs of 64-frame tiles: measured slower, not instantiated)
 int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct) {
   BSG_REQUIRE(p.zx && p.ix && p.pflags, "pair launch: exchange buffers missing");
   const dim3 grid(16 * cdiv(p.n_tiles, 8)), block(256);
-  if (nct == 1) hipLaunchKernelGGL(residual_pair_h2_kernel<1>, grid, block, pair_lds(1), st, p);
-  else hipLaunchKernelGGL(residual_pair_h2_kernel<2>, grid, block, pair_lds(2), st, p);
+  BSG_REQUIRE(nct == 1, "pair launch: 32-frame tiles only");
+  hipLaunchKernelGGL(residual_pair_h2_kernel<1>, grid, block, pair_lds(1), st, p);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
