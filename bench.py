@@ -20,15 +20,20 @@ The JSON line also carries
                  the batch (the reference's direct convolution) against the dense peak of the matrix pipe the
                  products run on (fp16 for the default split-fp16 form, fp32 with BSG_H2=0); `frac_executed` prices the MFMAs
                  the form actually issues (3 fp16 products per fp32 product; 5/8 of the direct FLOPs for Winograd F(4,3)), i.e.
-                 how busy the pipe is.  `traffic` = HBM-side bytes from PMC counters (profiles/traffic*.json, looked up by the
-                 launch form that ran), condition stated in `traffic_condition`;
+                 how busy the pipe is; `sustained_mhz` = shader clock over one whole timed launch of that kernel (s_memtime /
+                 s_memrealtime, tile 0) and `frac_executed_at_sustained_clock` the same share against the peak at THAT clock.
+                 `traffic` = HBM-side bytes from PMC counters (profiles/traffic*.json, looked up by the launch form that ran),
+                 condition stated in `traffic_condition`; `traffic_build_matches` says whether those passes ran on the build
+                 that was just timed;
   secondary    : (N = 1, untimed against the headline) BASELINE configs[2] — bf16 operands, B=64 — with its own roofline,
-                 configs[4] — B=1, T=1000 mel generation + HiFi-GAN vocoder, real-time factor — and f32_matrix_pipe: the headline
-                 workload with every product on the fp32 matrix pipe (the default forms fp32 products on the 16-bit pipe from
-                 exact hi + lo fp16 splits: `arithmetic`);
+                 configs[4] — B=1, T=1000 mel generation + HiFi-GAN vocoder, real-time factor —, cfg3_rank: configs[3] as ONE of
+                 its 8 ranks sees it (B_total = 64, front on 64 rows, 8 local rows, no collective) with the same 64 utterances on
+                 one GPU beside it and their ratio = the strong scaling 8 GPUs can reach at most, captured_sampler: what a
+                 stream-captured sampler loop runs and how fast, and f32_matrix_pipe: the headline workload with every product on
+                 the fp32 matrix pipe (the default forms fp32 products on the 16-bit pipe from hi + lo fp16 splits: `arithmetic`);
   cpu_baseline : the oracle (PyTorch-CPU restatement of the reference, oracle/) timed on this host with one socket's physical
-                 cores, median of 3 runs of a bounded sample (FS2 + --cpu-steps sampler steps, extrapolated to
-                 100; --cpu-steps 100 = the full pass); the same sample replayed on the GPU with the same supplied noise must
+                 cores, median of 3 runs of a bounded sample (FS2 + --cpu-steps sampler steps, default 25, extrapolated
+                 to 100; --cpu-steps 100 = the full pass); the same sample replayed on the GPU with the same supplied noise must
                  agree within 1e-3 (`parity`, asserted: a fast but wrong bench exits non-zero).
 """
 import argparse
