@@ -310,7 +310,7 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None, clock=None):
                     note='achieved = algorithmic FLOPs (direct conv, SURVEY §8d) of one layer over the batch / (launch-group duration / 20 '
                          'layers), HIP events around the launch group on its own stream; peak = dense fp16 MFMA (= bf16, MI355X_MICROARCH.md): '
                          'the pipe the products run on.  frac_executed prices the 3 fp16 products issued per fp32 product = matrix-pipe busy '
-                         'share.  Arithmetic is fp32-grade: product error <= 3 x 2^-24, fp32 accumulation (tests/test_gpu_h2.py vs float64)')
+                         'share.  Arithmetic is fp32-grade: product error a few 2^-24 (worst case 2^-21), fp32 accumulation; measured against float64 it equals the fp32-MFMA forms (tests/test_gpu_h2.py)')
     if path == 'stack_f43':
         # one launch = all 20 layers of up to 256 64-frame tiles, one workgroup per CU; the timed region is the launch group of one
         # DiffNet evaluation and n_layer counts its layers, so avg_ms is the time of one layer over all rows
@@ -699,7 +699,7 @@ def main():
         if not bf16 and model.denoise_fn.last_path().startswith('stack_h2'):
             rec['arithmetic'] = ('fp32 tensors and fp32 results; in the residual stack, the step tail and the GEMMs every fp32 product is formed on the '
                                  '16-bit matrix pipe as ah*bh + ah*bl + al*bh from EXACT hi + lo fp16 splits of both operands (fp32 accumulate; '
-                                 'product error <= 3 x 2^-24).  Error against float64 equals that of the fp32-MFMA forms (tests/test_gpu_h2.py); '
+                                 'product error a few 2^-24, worst case 2^-21).  Error against float64 equals that of the fp32-MFMA forms, also at the edges of the scheme (tests/test_gpu_h2.py); '
                                  'secondary.f32_matrix_pipe is the same workload with every product on the fp32 matrix pipe')
         if use_dist:
             rec['ranks_seen_by_rccl'] = dist.get_world_size()

@@ -1,14 +1,15 @@
-// fp32 DiffNet residual stack on the 16-bit matrix pipe: every fp32 operand split EXACTLY into two fp16 terms.
+// fp32 DiffNet residual stack on the 16-bit matrix pipe: every fp32 operand split into two fp16 terms (to one fp32 ulp; usually exactly).
 //
 // Same contract, tensors and results (to fp32 rounding) as the fp32-matrix-pipe stack launch (diffnet_f43.hip; reference semantics
 // /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130; with TAIL also net.py:126-129 and the sampler update,
 // usr/diff/shallow_diffusion_tts.py:149-201).  gfx950 multiplies fp32 operands at 256 FLOP/clk/CU (v_mfma_f32_32x32x2_f32) and fp16 operands at 4096 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  An
-// fp32 value a is hi + lo with hi = fp16(a), lo = fp16(a - hi): 11 + 11 significand bits plus the sign of lo cover the 24 of fp32, so
-// |a - hi - lo| <= 2^-24 |a| (half an fp32 ulp) as long as lo is a normal fp16.  A product of two such values is
-//     a b = ah bh + ah bl + al bh   (+ al bl, <= 2^-24 |a b|: dropped)
+// fp32 value a is hi + lo with hi = fp16(a), lo = fp16(a - hi): 11 + 11 significand bits plus the sign of lo cover 23 of fp32's 24 (the
+// residual a - hi can have 12 significant bits; rounding it to 11 loses at most the last), so |a - hi - lo| <= 2^-23 |a| (one fp32 ulp, in
+// most cases 0) as long as lo is a normal fp16.  A product of two such values is
+//     a b = ah bh + ah bl + al bh   (+ al bl, dropped: |al| <= 2^-11 |a|, so <= 2^-22 |a b| in the worst case, ~2^-24 in the mean)
 // and each of the three terms is a product of fp16 numbers — EXACT in the fp32 the matrix pipe accumulates in.  Three fp16 MFMAs of
 // K = 16 replace eight fp32 MFMAs of K = 2: 3/16 of the matrix cycles of the direct fp32 form (the F(4,3) Winograd form needs 10/16).
-// The error of a product is <= 3 x 2^-24 relative — the size of ONE fp32 rounding, and a dot product of K = 256..768 terms is
+// The error of a product is <= 2^-21 relative in the worst case and a few 2^-24 typically — the size of an fp32 rounding — and a dot product of K = 256..768 terms is
 // dominated by the roundings of its fp32 accumulation either way (measured: tests/test_gpu_h2.py compares both against float64).
 //   Range.  fp16 normals span 2^-14 .. 65504.  Weights are multiplied by a power of two per layer and GEMM (chosen at create so that
 // max |w| lands in [2^13, 2^14)) and z, which lies in (-1, 1), by 2^10; the accumulators start from (initial value) x (scale) and are

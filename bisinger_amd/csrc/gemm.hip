@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs g) {
 
 // ------------------------------------------------------------------------------------------------
 // gemm_split_kernel: the same problems on the 16-bit matrix pipe, fp32-grade.  Both operands are split EXACTLY into hi + lo fp16 terms
-// while they are staged (a = ah + al to 2^-24 |a|; see diffnet_h2.hip for the argument), and every fp32 product is formed as
+// while they are staged (a = ah + al to one fp32 ulp; see diffnet_h2.hip for the argument), and every fp32 product is formed as
 // ah bh + ah bl + al bh by three v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3/16 of the matrix cycles of the fp32 MFMA form.
 // Operands are scaled by 2^4 on the way in (products by 2^8, removed from the accumulator: exact) so that the lo terms of values down
 // to 2^-6 are normal fp16 numbers; below that they carry an absolute error <= 2^-29.  |operand| must stay below 4062 (the guard trips at 65000 / 16).

@@ -1,7 +1,7 @@
 """GPU: the split-fp16 form of the fp32 residual stack (csrc/diffnet_h2.hip) is fp32-grade arithmetic.
 
 Every fp32 operand is split exactly into hi + lo fp16 terms and every fp32 product is formed as hi*hi + hi*lo + lo*hi on the
-16-bit matrix pipe with fp32 accumulation (error of a product <= 3 x 2^-24 relative: the size of one fp32 rounding).  The claim
+16-bit matrix pipe with fp32 accumulation (error of a product: a few 2^-24 relative, the size of one fp32 rounding; 2^-21 in the worst case).  The claim
 tested here: measured against a FLOAT64 evaluation of the same network (oracle.diffnet.diffnet_forward(dtype=float64), the
 restatement of /root/reference/train_bisinger/usr/diff/net.py:107-130), the split-fp16 launch is as close as the launches that
 multiply on the fp32 matrix pipe (direct K=768 form, Winograd F(2,3), Winograd F(4,3)) — not "within the 1e-3 bar", but within

@@ -7,7 +7,7 @@ is returned (bisinger_amd/diffnet.py DiffNet.guarded).  This test runs that situ
 busy with large matrix products while this one repeats 100-step sampler passes at a stack-launch shape and a small-batch shape.
 Required: every result equals the undisturbed reference (bit for bit while no hand-off gave up, to 1e-5 — the rounding of the
 fallback kernels — after one did), nothing hangs, and the slowdown stays bounded.  Both children are started fresh; no process that
-has touched the GPU is ever re-executed.  (Promoted from tools/soak_handoffs.py)"""
+has touched the GPU is ever re-executed.  (Round 2's tools/soak_handoffs.py, promoted to a test: VERDICT r02 item 8b.)"""
 import json
 import os
 import subprocess
