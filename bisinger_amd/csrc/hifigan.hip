@@ -882,6 +882,201 @@ int launch_pair_h2(const PairArgs& a, int K, int C, int B, hipStream_t st) {
   return BSG_EINVAL;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same fused pair for 16 and 8 channels on the 16-bit matrix pipe (round 3): v_mfma_f32_16x16x32_f16, M = 16 output channels (8 used for
+// C = 8), N = 16 positions, K = 32 = TPK taps x C input channels (TPK = 2 for C = 16, 4 for C = 8; the tap count is padded to a multiple
+// of TPK with zero weights, and the padded taps read the last real tap's row so that no garbage meets a zero).  Lane l holds A[row l & 15]
+// [k = 8 (l >> 4) + j] and B[k][column l & 15] (cdna_hip_programming.md, "A/B operand lane maps"): a B fragment = 8 consecutive channels of
+// ONE position = one ds_read_b128 of the channels-last image [position][C fp16 + pad] (48-byte rows: the 16 rows of a lane group fall on
+// 16 different bank quads); C/D: column l & 15, rows 4 (l >> 4) + r.  Split-fp16 products as above (weights x 2^8 at create, activations
+// x 2^4 while staged, 3 MFMAs per product).  These stages move 96 / 48 B per position and pair against 33 / 17 kFLOP: the VALU kernels
+// they replace ran at 1.2-2 TB/s, these are bound by the memory side.
+// ------------------------------------------------------------------------------------------------
+using f32x4h = __attribute__((ext_vector_type(4))) float;
+
+// out[((ks*2 + plane)*64 + lane)*8 + j] = hi / lo of 2^8 W[co = lane & 15][ci][tap] with kb = lane >> 4,
+//   C = 16: tap = 2 ks + (kb >> 1), ci = 8 (kb & 1) + j;   C = 8: tap = 4 ks + kb, ci = j;   zero for co >= C or tap >= K
+__global__ void pack_conv_h16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int C, int K, unsigned* __restrict__ bad) {
+  const int TPK = 32 / C, KS = (K + TPK - 1) / TPK;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KS * 512) return;
+  const int j = i & 7, lane = (i >> 3) & 63, ks = i >> 9;
+  const int co = lane & 15, kb = lane >> 4;
+  const int tap = C == 16 ? 2 * ks + (kb >> 1) : 4 * ks + kb;
+  const int ci = C == 16 ? 8 * (kb & 1) + j : j;
+  float v = 0.f;
+  if (co < C && tap < K) v = w[((long long)co * C + ci) * K + tap] * HG_WSC;
+  if (!(fabsf(v) < 60000.0f)) atomicAdd(bad, 1u);
+  const _Float16 hi = (_Float16)v;
+  const long long base = ((long long)(ks * 2) * 64 + lane) * 8 + j;
+  out[base] = hi;
+  out[base + 512] = (_Float16)(v - (float)hi);
+}
+
+template <int K, int C, int NC>   // NC column tiles of 16 positions per wave
+__device__ __forceinline__ void conv_h16(f32x4h (&acc)[NC], const _Float16* __restrict__ wpk, const char* img, int rowb, int plane, int n0,
+                                         int dil, int lane) {
+  constexpr int TPK = 32 / C, KS = (K + TPK - 1) / TPK;
+  const int l15 = lane & 15, kb = lane >> 4;
+  const hf16x8* __restrict__ wp = reinterpret_cast<const hf16x8*>(wpk) + lane;
+  hf16x8 A[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {   // the whole conv's weights: KS x 2 KB
+    A[ks][0] = wp[ks * 128];
+    A[ks][1] = wp[ks * 128 + 64];
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    int tap = C == 16 ? 2 * ks + (kb >> 1) : 4 * ks + kb;
+    if (tap > K - 1) tap = K - 1;   // padded tap (zero weights): a row that exists
+    const char* bk = img + (n0 + l15 + tap * dil) * rowb + (C == 16 ? (kb & 1) * 16 : 0);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      const hf16x8 bh = *reinterpret_cast<const hf16x8*>(bk + 16 * ct * rowb);
+      const hf16x8 bl = *reinterpret_cast<const hf16x8*>(bk + 16 * ct * rowb + plane);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bh, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bl, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][1], bh, acc[ct], 0, 0, 0);
+    }
+  }
+}
+
+template <int K, int C, int NB>
+__global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
+  constexpr int PT = 128 * NB, H2 = (K - 1) / 2, POUT = PT - (K - 1), TS = PT + 16, ROWB = 48, NC = 2 * NB;
+  constexpr float ACC_SC = HG_WSC * HG_ASC, ACC_INV = 1.0f / (HG_WSC * HG_ASC);
+  static_assert(C == 16 || C == 8, "channel count");
+  extern __shared__ __attribute__((aligned(16))) char hlds[];   // lrelu(x) planes [span][ROWB], then t1 planes [TS][ROWB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int t0 = blockIdx.x * POUT, b = blockIdx.y;
+  const int h1 = H2 * a.dil, span = PT + 2 * h1;
+  const int plane = (span > TS ? span : TS) * ROWB;
+  const float* __restrict__ xb = a.x + (long long)b * C * a.L;
+  const float slope = a.slope;
+  bool bad = false;
+  auto split4 = [&](const float (&v)[4], hf16x4& hi, hf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e] * HG_ASC;
+      bad |= !(fabsf(x) < 65000.0f);
+      hi[e] = (_Float16)x;
+      lo[e] = (_Float16)(x - (float)hi[e]);
+    }
+  };
+  // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
+  for (int idx = tid; idx < (C / 4) * span; idx += 256) {
+    const int cq = idx / span, jx = idx - cq * span;
+    const int t = t0 - H2 - h1 + jx;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = (t >= 0 && t < a.L) ? xb[(long long)(4 * cq + e) * a.L + t] : 0.f;
+      v[e] = fmaxf(x, x * slope);
+    }
+    hf16x4 hi, lo;
+    split4(v, hi, lo);
+    *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
+    *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+  }
+  const int n0 = 32 * NB * wave;
+  const bool rows_ok = 4 * kb < C;   // C = 8: accumulator rows 8..15 do not exist
+  f32x4h acc[NC];
+  auto init_acc = [&](const float* bias) {
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = rows_ok ? bias[4 * kb + r] * ACC_SC : 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4h{bv[0], bv[1], bv[2], bv[3]};
+  };
+  init_acc(a.b1);
+  __syncthreads();
+  // ---- conv1 (dilation d) at t1 positions u = t0 - H2 + p: reads x row p + k d ------------------------------------------------------
+  conv_h16<K, C, NC>(acc, reinterpret_cast<const _Float16*>(a.w1), hlds, ROWB, plane, n0, a.dil, lane);
+  __syncthreads();   // every wave is done reading x
+  // ---- t1 = lrelu(conv1), zero outside [0, L) (conv2 pads its input) -> LDS planes [TS][ROWB] -----------------------------------------
+  if (rows_ok) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      const int pcol = n0 + 16 * ct + l15, u = t0 - H2 + pcol;
+      const bool in = u >= 0 && u < a.L;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = acc[ct][e] * ACC_INV;
+        v[e] = in ? fmaxf(y, y * slope) : 0.f;
+      }
+      hf16x4 hi, lo;
+      split4(v, hi, lo);
+      char* dst = hlds + pcol * ROWB + (4 * kb) * 2;
+      *reinterpret_cast<hf16x4*>(dst) = hi;
+      *reinterpret_cast<hf16x4*>(dst + plane) = lo;
+    }
+  }
+  // rows PT .. TS-1 are read by the (masked) last K-1 positions of the tile: keep them finite (both planes)
+  for (int idx = tid; idx < (TS - PT) * (ROWB / 4); idx += 256) {
+    const int row = PT + idx / (ROWB / 4), c = idx % (ROWB / 4);
+    *reinterpret_cast<unsigned*>(hlds + row * ROWB + c * 4) = 0u;
+    *reinterpret_cast<unsigned*>(hlds + plane + row * ROWB + c * 4) = 0u;
+  }
+  init_acc(a.b2);
+  __syncthreads();
+  // ---- conv2 (dilation 1) at output positions t = t0 + p: reads t1 row p + k ----------------------------------------------------------
+  conv_h16<K, C, NC>(acc, reinterpret_cast<const _Float16*>(a.w2), hlds, ROWB, plane, n0, 1, lane);
+  if (a.range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(a.range_events, 1u);
+  // ---- residual, MRF sum, store: lanes = 16 consecutive positions of 4 channels -------------------------------------------------------------
+  if (!rows_ok) return;
+  const bool has_acc = a.acc_in != nullptr, has_div = a.out_div != 1.0f;
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct) {
+    const int pcol = n0 + 16 * ct + l15, t = t0 + pcol;
+    if (pcol >= POUT || t >= a.L) continue;
+    const long long i0 = ((long long)b * C + 4 * kb) * a.L + t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[ct][r] * ACC_INV + a.x[i0 + (long long)r * a.L];
+      if (has_acc) v = a.acc_in[i0 + (long long)r * a.L] + v;
+      if (has_div) v = v / a.out_div;
+      a.y[i0 + (long long)r * a.L] = v;
+    }
+  }
+}
+
+template <int K, int C, int NB>
+int launch_pair_h16_t(const PairArgs& a, int B, hipStream_t st) {
+  constexpr int PT = 128 * NB, POUT = PT - (K - 1), ROWB = 48;
+  const int span = PT + 2 * ((K - 1) / 2 * a.dil);
+  const size_t lds = (size_t)2 * (span > PT + 16 ? span : PT + 16) * ROWB;
+  static size_t attr = 0;
+  if (lds > attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)resblock_pair_h16_kernel<K, C, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL((resblock_pair_h16_kernel<K, C, NB>), dim3(cdiv(a.L, POUT), B), dim3(256), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+template <int K, int C>
+int launch_pair_h16_kc(const PairArgs& a, int B, hipStream_t st) {
+  if ((long long)cdiv(a.L, 256 - (K - 1)) * B >= 256) return launch_pair_h16_t<K, C, 2>(a, B, st);
+  return launch_pair_h16_t<K, C, 1>(a, B, st);
+}
+int launch_pair_h16(const PairArgs& a, int K, int C, int B, hipStream_t st) {
+  if (C == 16) {
+    if (K == 3) return launch_pair_h16_kc<3, 16>(a, B, st);
+    if (K == 7) return launch_pair_h16_kc<7, 16>(a, B, st);
+    if (K == 11) return launch_pair_h16_kc<11, 16>(a, B, st);
+  } else if (C == 8) {
+    if (K == 3) return launch_pair_h16_kc<3, 8>(a, B, st);
+    if (K == 7) return launch_pair_h16_kc<7, 8>(a, B, st);
+    if (K == 11) return launch_pair_h16_kc<11, 8>(a, B, st);
+  }
+  set_error("hifigan: no 16-row split-fp16 pair kernel for K=%d, C=%d", K, C);
+  return BSG_EINVAL;
+}
+bool pair_h16_supported(int K, int C) { return (K == 3 || K == 7 || K == 11) && (C == 16 || C == 8); }
+
+
 template <int K, int C, int NB>
 int launch_pair_mfma_t(const PairArgs& a, int B, hipStream_t st) {
   constexpr int PT = 128 * NB, POUT = PT - (K - 1);
@@ -958,6 +1153,7 @@ struct ConvW {
   float* wpc = nullptr;   // ResBlock convs: [cin][k][cout] for resblock_pair_kernel
   float* wpm = nullptr;   // ResBlock convs with 32 / 64 channels: MFMA fragment order for resblock_pair_mfma_kernel
   float* wps = nullptr;   // the same as hi / lo fp16 fragments (x 2^8) for resblock_pair_h2_kernel (m floats = 2 planes of m halves)
+  float* wp16 = nullptr;  // 8 / 16 channels: hi / lo fp16 fragments of v_mfma_f32_16x16x32_f16 for resblock_pair_h16_kernel [ks][plane][64][8]
   float* wpu = nullptr;   // ConvTranspose1d with K = 2u: per-phase 2-tap weights in CO-blocks of 8 for upsample_kernel
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
@@ -1027,6 +1223,13 @@ static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st, bool pair = false
     TRY(hg_alloc(h, &c.wpc, m));
     hipLaunchKernelGGL(pack_conv_w_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, c.wpc, c.cout, c.cin, c.k, c.cout);
     BSG_LAUNCH_CHECK();
+    if (pair_h16_supported(c.k, c.cout)) {
+      const int tpk = 32 / c.cout, ks = (c.k + tpk - 1) / tpk;
+      TRY(hg_alloc(h, &c.wp16, (size_t)ks * 512));   // ks x 2 planes x 64 lanes x 8 halves = ks x 512 floats
+      hipLaunchKernelGGL(pack_conv_h16_kernel, dim3(cdiv(ks * 512, 256)), dim3(256), 0, st, (const float*)c.w, reinterpret_cast<_Float16*>(c.wp16), c.cout,
+                         c.k, h->w_range_bad);
+      BSG_LAUNCH_CHECK();
+    }
     if (pair_mfma_supported(c.k, c.cout)) {
       TRY(hg_alloc(h, &c.wpm, m));
       hipLaunchKernelGGL(pack_conv_mfma_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, (const float*)c.w, c.wpm, c.cout, c.k);
@@ -1257,7 +1460,12 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
           pa.slope = slope; pa.L = L; pa.dil = c.resblock_dilations[j][m];
           static int h2_env = -1;   // BSG_HG_SPLIT=0: the fp32-MFMA form even while the GEMMs run split-fp16
           if (h2_env < 0) { const char* e = getenv("BSG_HG_SPLIT"); h2_env = e ? atoi(e) : 1; }
-          if (use_mfma && h2_env && h->h2_ok && c1.wps && c2.wps && gemm_split_enabled()) {
+          static int h16_env = -1;  // BSG_HG_H16=0: the VALU pairs for 8 / 16 channels
+          if (h16_env < 0) { const char* e = getenv("BSG_HG_H16"); h16_env = e ? atoi(e) : 1; }
+          if (mfma_env && h16_env && h2_env && h->h2_ok && c1.wp16 && c2.wp16 && gemm_split_enabled()) {
+            pa.w1 = c1.wp16; pa.w2 = c2.wp16; pa.range_events = gemm_range_counter();
+            TRY(launch_pair_h16(pa, c1.k, c1.cout, B, st));
+          } else if (use_mfma && h2_env && h->h2_ok && c1.wps && c2.wps && gemm_split_enabled()) {
             pa.w1 = c1.wps; pa.w2 = c2.wps; pa.range_events = gemm_range_counter();
             TRY(launch_pair_h2(pa, c1.k, c1.cout, B, st));
           } else if (use_mfma) {
