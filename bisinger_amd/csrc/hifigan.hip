@@ -1066,15 +1066,14 @@ int launch_pair_h16(const PairArgs& a, int K, int C, int B, hipStream_t st) {
     if (K == 3) return launch_pair_h16_kc<3, 16>(a, B, st);
     if (K == 7) return launch_pair_h16_kc<7, 16>(a, B, st);
     if (K == 11) return launch_pair_h16_kc<11, 16>(a, B, st);
-  } else if (C == 8) {
-    if (K == 3) return launch_pair_h16_kc<3, 8>(a, B, st);
-    if (K == 7) return launch_pair_h16_kc<7, 8>(a, B, st);
-    if (K == 11) return launch_pair_h16_kc<11, 8>(a, B, st);
   }
   set_error("hifigan: no 16-row split-fp16 pair kernel for K=%d, C=%d", K, C);
   return BSG_EINVAL;
 }
-bool pair_h16_supported(int K, int C) { return (K == 3 || K == 7 || K == 11) && (C == 16 || C == 8); }
+// (the kernel is written for C = 8 too — 4 taps x 8 channels per k-step, half of the MFMA's rows unused — but measured SLOWER there than the VALU
+// pairs it would replace: 220 / 208 / 150 us against 199 / 153 / 96 us for K = 11 / 7 / 3 at B=16, T=1000; for C = 16: 180 / 161 / 118 against
+// 355 / 223 / 126 us.  Only the 16-channel form is instantiated.)
+bool pair_h16_supported(int K, int C) { return (K == 3 || K == 7 || K == 11) && C == 16; }
 
 
 template <int K, int C, int NB>
