@@ -23,6 +23,7 @@
 // the fp32 MFMA roof (157.3 TFLOP/s), not HBM.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -1076,6 +1077,9 @@ struct bsg_diffnet {
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
   int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
   bool stack_pair = false;             // ... the pair form (two workgroups per 32-frame tile, diffnet_h2.hip residual_pair_h2_kernel)
+  bool stack_quad = false;             // ... the quad form (four workgroups per 32-frame tile, residual_quad_h2_kernel); implies stack_pair
+  int occ_quad = -1;
+  unsigned short *apack1q = nullptr, *apack2q = nullptr;   // the split-fp16 weights once more as 16-row fragments (quad form)
   int occ_pair[3] = {-1, -1, -1};      // resident workgroups per CU of the pair form by tile width in column tiles (-1: not queried)
   unsigned short* pair_zx = nullptr;   // pair form: exchange slots of the z halves [tiles][2][2 planes][32][C/2] fp16
   unsigned short* pair_ix = nullptr;   //            ... of the image halves [2 parities][tiles][2][2 planes][32][C/2]
@@ -1139,6 +1143,8 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->pair_zx) (void)hipFree(h->pair_zx);
   if (h->pair_ix) (void)hipFree(h->pair_ix);
   if (h->pair_flags) (void)hipFree(h->pair_flags);
+  if (h->apack1q) (void)hipFree(h->apack1q);
+  if (h->apack2q) (void)hipFree(h->apack2q);
   delete h;
 }
 
@@ -1184,6 +1190,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   BSG_HIP(hipMalloc((void**)&h->apack2h, (size_t)L * 2 * C * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->apack1s, (size_t)L * 2 * 2 * C * 3 * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->apack2s, (size_t)L * 2 * 2 * C * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->apack1q, (size_t)L * 2 * 2 * C * 3 * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->apack2q, (size_t)L * 2 * 2 * C * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->h2_scale, (size_t)(4 * L + 2 * L) * sizeof(float)));   // table + [2L] scratch of the max reduction
   TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
   TRY(dev_alloc(&h->b_cond, (size_t)L * 2 * C));
@@ -1226,6 +1234,8 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
     if (rc == BSG_OK) rc = pack_a_frag_bf16((const float*)lw[6], h->apack2h + (size_t)l * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, st);
     if (rc == BSG_OK) rc = pack_a_frag_h2((const float*)lw[0], h->apack1s + (size_t)l * 2 * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, h->h2_scale + 4 * l, 0, st);
     if (rc == BSG_OK) rc = pack_a_frag_h2((const float*)lw[6], h->apack2s + (size_t)l * 2 * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, h->h2_scale + 4 * l, 1, st);
+    if (rc == BSG_OK) rc = pack_a_frag_q((const float*)lw[0], h->apack1q + (size_t)l * 2 * 2 * C * 3 * C, 2 * C, 3 * C, C, (long long)3 * C, 3LL, 1LL, h->h2_scale + 4 * l, 0, st);
+    if (rc == BSG_OK) rc = pack_a_frag_q((const float*)lw[6], h->apack2q + (size_t)l * 2 * 2 * C * C, 2 * C, C, C, (long long)C, 1LL, 0LL, h->h2_scale + 4 * l, 1, st);
     if (rc != BSG_OK) break;
     hipLaunchKernelGGL(pack_a16_kernel, dim3(cdiv(2 * C * C, 256)), dim3(256), 0, st, (const float*)lw[6], h->apack2w + (size_t)l * 2 * C * C,
                        2 * C, C);
@@ -1563,6 +1573,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       int nct = (long long)B * cdiv(T, 32) > h->num_cus ? 2 : 1;
       if (env_nct == 1 || env_nct == 2) nct = env_nct;
       h->stack_pair = false;
+      h->stack_quad = false;
       {
         // pair form (residual_pair_h2_kernel): two workgroups on two CUs of an XCD share a tile, each half of the channels and half of the weight
         // stream; the whole batch in one launch.  Taken while pairs of 32-frame tiles fit the chip: B * ceil(T / 32) <= CUs / 2 (B <= 4 at T = 1000;
@@ -1571,6 +1582,24 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
         // pipe is busy half of a k-step (profiles/r03_pair_form/) — not built.  BSG_H2_PAIR=0: no pair form at all
         static int env_pair = -1;
         if (env_pair < 0) { const char* e = getenv("BSG_H2_PAIR"); env_pair = e ? atoi(e) : 1; }
+        // quad form (residual_quad_h2_kernel): FOUR workgroups on four CUs of an XCD share a 32-frame tile, each a quarter of the channels and of
+        // the weight stream, 16-row matrix tiles.  Taken while quads fit the chip: B * ceil(T / 32) <= CUs / 4 (B <= 2 at T = 1000).
+        // BSG_H2_QUAD=0: pairs instead
+        static int env_quad = -1;
+        if (env_quad < 0) { const char* e = getenv("BSG_H2_QUAD"); env_quad = e ? atoi(e) : 1; }
+        if (env_pair && env_quad && env_nct == 0 && h->apack1q) {
+          const long long t32 = (long long)B * cdiv(T, 32);
+          if (4 * 8 * cdiv(t32, 8) <= h->num_cus) {
+            if (h->occ_quad < 0) h->occ_quad = quad_h2_occupancy() >= 1 ? 1 : 0;
+            if (h->occ_quad >= 1) {
+              h->stack_is_h2 = true;
+              h->stack_nct = 1;
+              h->stack_pair = true;
+              h->stack_quad = true;
+              return B;
+            }
+          }
+        }
         if (env_pair && env_nct == 0) {
           const long long t32 = (long long)B * cdiv(T, 32);
           const int pn = 2 * 8 * cdiv(t32, 8) <= h->num_cus ? 1 : 0;
@@ -1678,7 +1707,12 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
         h->pair_cap = cap;
       }
       p.zx = h->pair_zx; p.ix = h->pair_ix; p.pflags = h->pair_flags;
-      TRY(launch_residual_pair_h2(p, st, nct));
+      if (h->stack_quad) {
+        p.apack1q = h->apack1q; p.apack2q = h->apack2q;
+        TRY(launch_residual_quad_h2(p, st));
+      } else {
+        TRY(launch_residual_pair_h2(p, st, nct));
+      }
     } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
@@ -1703,7 +1737,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     }
   }
   BSG_REQUIRE(!tail || h2, "stack launch: a fused tail needs the split-fp16 form");
-  h->last_path = h2 ? (h->stack_pair ? "stack_h2_pair" : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
+  h->last_path = h2 ? (h->stack_quad ? "stack_h2_quad" : h->stack_pair ? "stack_h2_pair" : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
   return BSG_OK;
 }
 
@@ -1914,6 +1948,17 @@ static int step_from_xa(bsg_diffnet* h, int t_uniform, TailArgs& a, float* x, in
     return BSG_OK;
   }
   TRY(layers_from_xa(h, t_uniform, B, T, st));
+  if (srows && h->stack_is_h2 && h->stack_pair && strncmp(h->last_path, "stack_h2_", 9) == 0) {
+    // behind a pair / quad launch: the tail on the 16-bit matrix pipe too (step_tail_h2_kernel; BSG_H2_TAIL=0: the fp32-pipe tail)
+    const size_t off = (size_t)h->row_off * C * T;
+    a.skip = h->skip + off; a.skip_h = nullptr;
+    a.x = x; a.xa_next = h->xa + off;
+    a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
+    a.B = B; a.T = T; a.M = h->M; a.tiles_per_row = cdiv(T, 32);
+    a.ws_s = h->tail_s; a.wo_s = h->tail_s + 2 * C * C; a.wi_s = h->tail_s + 2 * C * C + 2 * 96 * C; a.tail_scale = h->tail_scale;
+    a.status = h->flags + h->flags_cap;
+    return launch_step_tail_h2(a, st);
+  }
   return launch_tail(h, a, x, B, T, st);
 }
 

@@ -720,6 +720,200 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   }
 }
 // ------------------------------------------------------------------------------------------------
+// The step tail of the pair / quad forms as its own launch on the 16-bit matrix pipe: what the TAIL branch of residual_stack_h2_kernel does on
+// chip, from the skip sum in HBM (fp32 [C][T], written by the last layer of the pair / quad launch).  One workgroup of 8 waves per 32-frame
+// tile; the three projections as split-fp16 GEMMs (the fragments and scales of h2_tail_pack), the sampler update in fp32 with the
+// reference's rounding sequence (diffnet_tail.h).  It replaces step_tail_kernel (fp32 matrix pipe: 39.8 us per step at B = 1, where the
+// 32 workgroups of a single utterance run three serial GEMMs of 128 + 128 + 40 16-pass MFMAs) behind those launches only; operands beyond
+// the fp16 range count a range event in a.status[1] like the launches in front of it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
+  constexpr int XP = h2_xp(1), ZP = h2_zp(1);
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;                  // [2 planes][48 rows][528 B]: hi / lo of s, later of the updated x (channels 0..95); rows HALO..HALO+31 used
+  char* zs = lds_raw + 2 * XP;         // [2 planes][32 rows][528 B]: hi / lo of h
+  float* nzs = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [96][32]: the step's Philox normals of the tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int T = a.T, M = a.M;
+  const int b = blockIdx.x / a.tiles_per_row;
+  const int t0 = (blockIdx.x - b * a.tiles_per_row) * 32;
+  const int col = t0 + l31;
+  const bool col_ok = col < T;
+  const int rowT = T * 4, vfrag = lane * 16;
+  const int vcol = (lh * 4 * T + (col_ok ? col : T - 1)) * 4, vst = (lh * 4 * T + col) * 4;
+  const unsigned plane = (unsigned)C * T * 4;
+  const float* tsc = a.tail_scale;   // [3][2]: scale, 1 / scale of the skip / output / input projection
+  int range_flag = 0;
+  auto range_check = [&](unsigned worst) {
+    if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
+  };
+  auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+  // ---- s (skip sum / sqrt(L), fp32 rows) -> hi / lo image rows: 32 chunks of 8 channels x 32 frames, lanes = consecutive frames ------------
+  {
+    const rsrc_t rs_s = mk_rsrc(a.skip + (long long)b * C * T, plane);
+    unsigned worst = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = it * 512 + tid;
+      const int hc = item >> 5, f = item & 31;
+      const int t = t0 + f;
+      const bool ok = t < T;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ldf(rs_s, ok ? ((8 * hc + k) * T + t) * 4 : 0, 0);
+      if (ok) worst = max(worst, max(max(max(absbits(v[0]), absbits(v[1])), max(absbits(v[2]), absbits(v[3]))),
+                                     max(max(absbits(v[4]), absbits(v[5])), max(absbits(v[6]), absbits(v[7])))));
+      const HiLo h0 = split2(v[0], v[1]), h1 = split2(v[2], v[3]), h2 = split2(v[4], v[5]), h3 = split2(v[6], v[7]);
+      u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
+      if (!ok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
+      *reinterpret_cast<u32x4*>(xs + (HALO + f) * ROWB + hc * 16) = wh;
+      *reinterpret_cast<u32x4*>(xs + XP + (HALO + f) * ROWB + hc * 16) = wl;
+    }
+    range_check(worst);
+  }
+  // ---- the step's noise, by ALL waves: the Philox quads that cover the tile's 32 frames of each mel row (element idx = quad idx >> 2, lane
+  // idx & 3: the values philox_normal1 returns; evaluated per element by the three updating waves it was 16 evaluations per lane) --------
+  const bool philox = !a.noise && a.k.sigma != 0.f && !a.plms_hist;
+  if (philox) {
+#pragma unroll 1
+    for (int item = tid; item < M * 9; item += 512) {
+      const int m = item / 9, jq = item - m * 9;
+      const unsigned long long base = a.quad_row0 + ((unsigned long long)b * M + m) * T + t0;
+      const unsigned long long qd = (base >> 2) + jq;
+      const f32x4 z = philox_normal4(a.seed, a.stream, qd);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long long cx = (long long)(4 * qd + c) - (long long)base;
+        if (cx >= 0 && cx < 32) nzs[m * 32 + (int)cx] = z[c];
+      }
+    }
+  }
+  const char* xcore = xs + (HALO + l31) * ROWB + lh * 16;
+  auto ldb_x = [&](int ks, f16x8 (&Bf)[2]) {
+    Bf[0] = *reinterpret_cast<const f16x8*>(xcore + ks * 32);
+    Bf[1] = *reinterpret_cast<const f16x8*>(xcore + ks * 32 + XP);
+  };
+  // ---- h = relu(W_skip s + b) -> zs (hi / lo)                                                                          (net.py:126-128) ----
+  {
+    const rsrc_t rs_ws = mk_rsrc(a.ws_s, 2 * C * C * 2);
+    const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
+    const float sc = tsc[0], inv = tsc[1];
+    f32x16 hc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hc[0][r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
+    __syncthreads();   // (T1) s complete
+    tail_gemm_h2<1, 16>(hc, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x);
+    unsigned worst = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) worst = max(worst, absbits(hc[0][r] * inv));
+    range_check(worst);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const HiLo s0 = split2(fmaxf(hc[0][4 * g] * inv, 0.f), fmaxf(hc[0][4 * g + 1] * inv, 0.f));
+      const HiLo s1_ = split2(fmaxf(hc[0][4 * g + 2] * inv, 0.f), fmaxf(hc[0][4 * g + 3] * inv, 0.f));
+      char* dst = zs + l31 * ROWB + (32 * wave + 8 * g + 4 * lh) * 2;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+      *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
+    }
+  }
+  __syncthreads();   // (T2) h complete; every wave is done reading s
+  // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins: waves 0..2     (net.py:129) --------------
+  if (wave < 3) {
+    const int rt = wave;
+    const rsrc_t rs_wo = mk_rsrc(a.wo_s, 2 * 96 * C * 2);
+    const rsrc_t rs_bf = mk_rsrc(a.b_fin, 96 * 4);
+    const rsrc_t rs_xx = mk_rsrc(a.x + (long long)b * M * T, (unsigned)M * T * 4);
+    const rsrc_t rs_n = mk_rsrc(a.noise ? a.noise + (long long)b * M * T : a.x, a.noise ? (unsigned)M * T * 4 : 0u);
+    const float sc = tsc[2], inv = tsc[3];
+    f32x16 e[1];
+    float xv[16], nv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // the lane's row is m0 + 4 lh; rows >= M fall outside the descriptor's range and read as 0, and are never stored
+      const int m0 = 32 * rt + acc_row0(r);
+      e[0][r] = ldf(rs_bf, lh * 16, m0 * 4) * sc;
+      xv[r] = ldf(rs_xx, vcol, m0 * rowT);
+      nv[r] = a.noise ? ldf(rs_n, vcol, m0 * rowT) : 0.f;
+    }
+    float h1v[16], h2v[16], h3v[16];
+    if (a.plms_hist) {
+      const unsigned hb = (unsigned)M * T * 4;
+      const rsrc_t rs_h1 = mk_rsrc(a.h1 + (long long)b * M * T, hb);
+      const rsrc_t rs_h2 = mk_rsrc(a.plms_hist > 1 ? a.h2 + (long long)b * M * T : a.x, a.plms_hist > 1 ? hb : 0u);
+      const rsrc_t rs_h3 = mk_rsrc(a.plms_hist > 2 ? a.h3 + (long long)b * M * T : a.x, a.plms_hist > 2 ? hb : 0u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int so = (32 * rt + acc_row0(r)) * rowT;
+        h1v[r] = ldf(rs_h1, vcol, so);
+        h2v[r] = ldf(rs_h2, vcol, so);   // zero-size descriptors read as 0
+        h3v[r] = ldf(rs_h3, vcol, so);
+      }
+    }
+    const char* zb = zs + l31 * ROWB + lh * 16;
+    auto ldb_h = [&](int ks, f16x8 (&Bf)[2]) {
+      Bf[0] = *reinterpret_cast<const f16x8*>(zb + ks * 32);
+      Bf[1] = *reinterpret_cast<const f16x8*>(zb + ks * 32 + ZP);
+    };
+    tail_gemm_h2<1, 16>(e, rs_wo, vfrag, rt * 1024, 2 * 3 * 1024, 3 * 1024, ldb_h);
+    const rsrc_t rs_en = mk_rsrc(a.plms_hist ? a.e_new + (long long)b * M * T : a.x, a.plms_hist ? (unsigned)M * T * 4 : 0u);
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * rt + acc_row(r, lh);
+      const float ev = e[0][r] * inv;
+      o[r] = 0.f;
+      if (m < M) {
+        if (a.plms_hist) {
+          o[r] = plms_update(xv[r], ev, h1v[r], h2v[r], h3v[r], a.plms_hist, a.pk, nullptr);
+          if (col_ok) stf(ev, rs_en, vst, (32 * rt + acc_row0(r)) * rowT);
+        } else {
+          const float nz = philox ? nzs[m * 32 + l31] : nv[r];
+          float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, ev));
+          x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+          const float mean = __fadd_rn(__fmul_rn(a.k.pc1, x0), __fmul_rn(a.k.pc2, xv[r]));
+          o[r] = __fadd_rn(mean, __fmul_rn(a.k.sigma, nz));
+        }
+        if (col_ok) stf(o[r], rs_xx, vst, (32 * rt + acc_row0(r)) * rowT);
+      }
+    }
+    {
+      unsigned worst = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) worst = max(worst, absbits(o[r]));
+      range_check(worst);
+    }
+    // the updated x as the input projection's B operand: channels-last rows of the image region (channels 0..95; rows >= M zero)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const HiLo s0 = split2(o[4 * g], o[4 * g + 1]), s1_ = split2(o[4 * g + 2], o[4 * g + 3]);
+      char* dst = xs + (HALO + l31) * ROWB + (32 * rt + 8 * g + 4 * lh) * 2;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+      *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
+    }
+  }
+  if (range_flag && lane == 0 && a.status) atomicAdd(a.status + 1, 1u);   // word 1: range events
+  if (!a.do_head) return;
+  // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded)                     (net.py:116-118) ----------
+  {
+    const rsrc_t rs_wi = mk_rsrc(a.wi_s, 2 * C * 96 * 2);
+    const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
+    const float sc = tsc[4], inv = tsc[5];
+    f32x16 hc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hc[0][r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
+    __syncthreads();   // (T3) the updated x tile is complete
+    tail_gemm_h2<1, 6>(hc, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x);
+    const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, plane);
+    if (col_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stf(fmaxf(hc[0][r] * inv, 0.f), rs_xa, vst, (32 * wave + acc_row0(r)) * rowT);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PAIR form for small batches (B * ceil(T / 32) <= CUs / 2; B <= 4 at T = 1000).  With one workgroup per 32-frame tile a single utterance
 // keeps 32 of the 256 CUs busy, and each of them is bound by streaming the layer's 2.1 MB of weight fragments out of L2 (the two GEMMs
 // take 18.8 us of a 25.5-us layer where their MFMAs need 10; tools/l2_fill.hip: a CU pulls at most ~64 B/clk).  Here a tile is computed by
@@ -1157,6 +1351,436 @@ __global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// QUAD form for one or two utterances (4 x B * ceil(T / 32) <= CUs; B <= 2 at T = 1000): the pair form's idea once more.  A 32-frame tile is
+// computed by FOUR workgroups of 4 waves on four CUs of one XCD, each owning a QUARTER of the channels (64): a wave owns 16 channels — 16
+// gate + 16 filter rows of GEMM1, 16 residual + 16 skip rows of GEMM2 — as 16-row matrix tiles (v_mfma_f32_16x16x32_f16: lane l holds
+// A[row l & 15][k = 8 (l >> 4) + j], B[k][column l & 15]; C/D column l & 15, rows 4 (l >> 4) + r; weights packed a second time in that
+// fragment order, pack_a_frag_q_kernel).  A CU streams a quarter of the layer's weights (0.52 MB); z and the image are all-gathered among
+// the four through L2 (8 KB per part) with the pair form's protocol; GEMM1 starts with the two 32-deep k-steps of the centre tap that
+// cover the own 64 channels.
+// ------------------------------------------------------------------------------------------------
+constexpr int QCH = C / 4;     // channels per workgroup of a quad
+constexpr int NSQ = 8;         // weight ring in k-steps of 32
+constexpr int QPLB = 32 * 1024;            // bytes per plane of a k-step slab: 32 row tiles of 16 x 1 KB
+constexpr int QKSB = 2 * QPLB;             // bytes per k-step (32 deep): hi slab, lo slab
+
+// out[(((ks*2 + plane)*(M/16) + rt)*64 + lane)*8 + j] = plane ? lo : hi of  s x W(m = 16 rt + (lane & 15), k = 32 ks + 8 (lane >> 4) + j)
+__global__ void pack_a_frag_q_kernel(const float* __restrict__ src, _Float16* __restrict__ out, int M, int K, int Kc, long long sm, long long sc,
+                                     long long st, const float* __restrict__ tab, int is_gemm2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * K) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  const long long rest = i >> 9;
+  const int RT = M / 16;
+  const int rt = (int)(rest % RT), ks = (int)(rest / RT);
+  const int m = 16 * rt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+  const float s = is_gemm2 ? tab[0] / ZSCALE : tab[0];
+  const float v = src[(long long)m * sm + (long long)(k % Kc) * sc + (long long)(k / Kc) * st] * s;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (float)hi);
+  const long long base = ((long long)(ks * 2) * RT + rt) * 512 + lane * 8 + j;
+  out[base] = hi;
+  out[base + (long long)RT * 512] = lo;
+}
+
+// i-th executed k-step (32 deep; 8 per tap) of GEMM1 for part q
+__device__ __forceinline__ int kmap_quad(int i, int q) {
+  if (i < 2) return 8 + 2 * q + i;                     // centre tap, own 64 channels
+  if (i < 8) { const int c = i - 2; return 8 + (c < 2 * q ? c : c + 2); }   // centre tap, the partners' channels
+  if (i < 16) return i - 8;                            // tap 0
+  return i;                                            // tap 2
+}
+
+#define BSG_MFMA_Q(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0)
+using f32x4q = __attribute__((ext_vector_type(4))) float;
+
+// k-step pipeline: two row tiles of 16 (c0: gate / residual, c1: filter / skip) x two column tiles of 16 frames, 12 MFMAs per k-step
+template <int ROT, typename KM, typename LDB, typename MID>
+__device__ __forceinline__ void mfma_pipe_quad(f32x4q (&c0)[2], f32x4q (&c1)[2], f16x8 (&A)[NSQ][4], rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks,
+                                               KM km, LDB ldb, MID mid) {
+  f16x8 B[2][4];
+  ldb(km(0), B[0]);
+  const int last = n_ks - 1;
+#pragma unroll 1
+  for (int ks = 0; ks < n_ks; ks += NSQ) {
+#pragma unroll
+    for (int s = 0; s < NSQ; ++s) {
+      if (ROT > 0 && s == ROT % NSQ && ks == ROT - ROT % NSQ) {   // the hand-off sits behind the first ROT k-steps
+        mid();
+        ldb(km(ks + s), B[s & 1]);
+      }
+      const int in = ks + s + 1 <= last ? ks + s + 1 : last;
+      ldb(km(in), B[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8(&Bc)[4] = B[s & 1];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        BSG_MFMA_Q(c0[ct], A[s][0], Bc[2 * ct]);
+        BSG_MFMA_Q(c1[ct], A[s][2], Bc[2 * ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        BSG_MFMA_Q(c0[ct], A[s][0], Bc[2 * ct + 1]);
+        BSG_MFMA_Q(c1[ct], A[s][2], Bc[2 * ct + 1]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        BSG_MFMA_Q(c0[ct], A[s][1], Bc[2 * ct]);
+        BSG_MFMA_Q(c1[ct], A[s][3], Bc[2 * ct]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int ir = ks + s + NSQ <= last ? ks + s + NSQ : last;
+      const int kr = km(ir);
+      A[s][0] = lda8(rs, vfrag, sa0 + kr * QKSB);
+      A[s][1] = lda8(rs, vfrag, sa0 + kr * QKSB + QPLB);
+      A[s][2] = lda8(rs, vfrag, sa1 + kr * QKSB);
+      A[s][3] = lda8(rs, vfrag, sa1 + kr * QKSB + QPLB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
+  constexpr int NT = 32, XP = h2_xp(1), ZP = h2_zp(1);
+  constexpr int NPIECE = 2 * NT * (QCH / 8);   // 16-byte pieces of one exchange slot: 2 planes x 32 frames x 8 chunks of 8 channels = 512
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;                  // [2 planes][48 frames][528 B]: hi / lo of x + d_l, ALL channels
+  char* zs = lds_raw + 2 * XP;         // [2 planes][32 frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
+  float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]
+  float* btab = dtab + C;                                              // [512]
+
+  // workgroup -> (tile, part): the four parts of a tile sit on the same XCD (workgroup i runs on XCD i mod 8)
+  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
+  const int slot = (int)blockIdx.x >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + (slot >> 2);
+  const int q = slot & 3;
+  if ((slot >> 2) >= per_xcd || tile_id >= n_tiles) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int tpr = p.tiles_per_row, L = p.L, T = p.T;
+  const int b = tile_id / tpr, j = tile_id - b * tpr;
+  const int t0 = j * NT;
+  const int tb = p.t_dev ? (int)p.t_dev[b] : p.t_uniform;
+  const bool has_left = j > 0, has_right = j + 1 < tpr;
+  const int cb = QCH * q + 16 * wave;   // first channel of this wave
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
+  const int rowT = T * 4, vfrag = lane * 16;
+  int vcol[2], vst[2];
+  bool col_ok[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = t0 + 16 * ct + l15;
+    col_ok[ct] = col < T;
+    vcol[ct] = (kb * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;   // accumulator rows 4 kb + r
+    vst[ct] = (kb * 4 * T + col) * 4;
+  }
+  const int rt_g = 4 * q + wave;                                  // gate / residual row tile (of 16); filter / skip: + 16
+  const int sa_g = rt_g * 1024, sa_f = (16 + rt_g) * 1024;
+
+  float xr[2][4], sk[2][4];
+  f32x4q yg[2], yf[2];
+  int range_flag = 0;
+  auto range_check = [&](unsigned worst) {
+    if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
+  };
+  auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+  unsigned* fx = p.pflags;                   // image flags [n_tiles][4]
+  unsigned* fz = p.pflags + 4 * n_tiles;     // z flags     [n_tiles][4]
+  auto wait_flags = [&](const unsigned* fl, unsigned want) {   // a whole wave: every lane with a flag polls its own; bounded
+    bool pend = fl != nullptr;
+    if (p.inject) {
+      if (pend) atomicAdd(p.status, 1u);
+      return;
+    }
+    unsigned spins = 0;
+    while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+      if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
+      if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+      __builtin_amdgcn_s_sleep(2);
+      ++spins;
+      const bool quit = spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+      if (quit) {
+        if (pend) atomicAdd(p.status, 1u);
+        break;
+      }
+    }
+  };
+
+  auto cond_request = [&](int l) {
+    const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int so = (cb + r) * rowT;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        yg[ct][r] = ldf(rs_ct, vcol[ct], so);
+        yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
+      }
+    }
+  };
+  auto write_core = [&]() {
+    float dv[4];
+    unsigned worst = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dv[r] = dtab[cb + 4 * kb + r];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float v0 = xr[ct][0] + dv[0], v1 = xr[ct][1] + dv[1], v2 = xr[ct][2] + dv[2], v3 = xr[ct][3] + dv[3];
+      worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
+      const HiLo s0 = split2(v0, v1);
+      const HiLo s1_ = split2(v2, v3);
+      u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
+      if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+      char* dst = xs + (HALO + 16 * ct + l15) * ROWB + (cb + 4 * kb) * 2;
+      *reinterpret_cast<u32x2*>(dst) = wh;
+      *reinterpret_cast<u32x2*>(dst + XP) = wl;
+    }
+    range_check(worst);
+  };
+  // a quarter (QCH channels) of NT LDS rows starting at row r0, both planes, to / from an exchange slot [plane][NT][QCH]
+  auto part_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot_p) {
+    const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * QCH * 2);
+#pragma unroll
+    for (int k = 0; k < NPIECE / 256; ++k) {
+      const int piece = k * 256 + tid;
+      const int pl = piece >> 8, f = (piece >> 3) & 31, c8 = piece & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (QCH * part + 8 * c8) * 2);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
+    }
+  };
+  auto parts_in = [&](char* img, int plane_bytes, int r0, auto slot_of) {   // the three partners' quarters
+    u32x4 v[3 * NPIECE / 256];
+#pragma unroll
+    for (int k = 0; k < 3 * NPIECE / 256; ++k) {
+      const int piece = k * 256 + tid;
+      const int o = piece >> 9, part = o < q ? o : o + 1;   // the o-th partner
+      const int pc = piece & 511, pl = pc >> 8, f = (pc >> 3) & 31, c8 = pc & 7;
+      const rsrc_t rs = mk_rsrc(slot_of(part), 2 * NT * QCH * 2);
+      v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
+    }
+#pragma unroll
+    for (int k = 0; k < 3 * NPIECE / 256; ++k) {
+      const int piece = k * 256 + tid;
+      const int o = piece >> 9, part = o < q ? o : o + 1;
+      const int pc = piece & 511, pl = pc >> 8, f = (pc >> 3) & 31, c8 = pc & 7;
+      *reinterpret_cast<u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (QCH * part + 8 * c8) * 2) = v[k];
+    }
+  };
+  const size_t slot_halfs = (size_t)2 * NT * QCH;   // fp16 elements of one exchange slot (8 KB)
+  auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * 4 + part) * slot_halfs; };
+  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * 4 + part) * slot_halfs; };
+
+  // ---- layer 0: x from HBM — this wave's channels into registers, the WHOLE image (all channels, halo frames included) into LDS ----------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xr[ct][r] = ldf(rs_x, vcol[ct], (cb + r) * rowT);
+      sk[ct][r] = 0.f;
+    }
+  {
+    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
+    unsigned worst = 0;
+    constexpr int ROWS = NT + 2 * HALO;
+#pragma unroll 1
+    for (int it = 0; it < 32 * ROWS / 256; ++it) {   // 32 chunks of 8 channels x 48 frames, lanes = consecutive frames
+      const int item = it * 256 + tid;
+      const int hc = item / ROWS, row = item - hc * ROWS;
+      const int th = t0 - HALO + row;
+      const bool hok = th >= 0 && th < T;
+      float hv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
+      if (hok) worst = max(worst, max(max(max(absbits(hv[0]), absbits(hv[1])), max(absbits(hv[2]), absbits(hv[3]))),
+                                      max(max(absbits(hv[4]), absbits(hv[5])), max(absbits(hv[6]), absbits(hv[7])))));
+      const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
+      u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
+      if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
+      *reinterpret_cast<u32x4*>(xs + row * ROWB + hc * 16) = wh;
+      *reinterpret_cast<u32x4*>(xs + XP + row * ROWB + hc * 16) = wl;
+    }
+    range_check(worst);
+  }
+  dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
+  btab[tid] = p.bias_out[tid];
+  btab[tid + 256] = p.bias_out[tid + 256];
+  cond_request(0);
+  f16x8 A[NSQ][4];
+  auto prefetch_a1 = [&](int l) {
+    const rsrc_t rs = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+#pragma unroll
+    for (int k = 0; k < NSQ; ++k) {
+      const int kr = kmap_quad(k, q);
+      A[k][0] = lda8(rs, vfrag, sa_g + kr * QKSB);
+      A[k][1] = lda8(rs, vfrag, sa_g + kr * QKSB + QPLB);
+      A[k][2] = lda8(rs, vfrag, sa_f + kr * QKSB);
+      A[k][3] = lda8(rs, vfrag, sa_f + kr * QKSB + QPLB);
+    }
+  };
+  prefetch_a1(0);
+  __syncthreads();   // the staged image and the tables
+
+#define QUAD_STAMP(i)                                                                                                      \
+  do {                                                                                                                    \
+    if (p.stamps && tid == 0 && q == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int dil = 1 << (l % p.cycle);
+    const rsrc_t rs_a1 = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+    const rsrc_t rs_a2 = mk_rsrc(p.apack2q + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
+    const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
+    const float dnext = l + 1 < L ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;
+    const float bnext0 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
+    const float bnext1 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tid] : 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) { yg[ct] *= s1; yf[ct] *= s1; }
+    QUAD_STAMP(0);
+    // ---- GEMM1: 24 k-steps of 32; the two of the centre tap over the own channels first, behind them the partners' quarters + the halo ----
+    {
+      const char* xb = xs + (HALO + l15) * ROWB + kb * 16;
+      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
+        const int tap = ks >> 3, kc = ks & 7;
+        const char* qp = xb + ((tap - 1) * dil) * ROWB + kc * 64;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWB);
+          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWB + XP);
+        }
+      };
+      auto mid = [&]() {
+        if (l == 0) return;   // layer 0 staged the whole image from HBM
+        if (wave == 0) {
+          // eleven flags (three partners, the four parts of each neighbouring tile), polled by eleven lanes at once
+          const unsigned want = p.fbase + (unsigned)l;
+          const unsigned* fl = nullptr;
+          if (lane < 3) fl = fx + 4 * tile_id + (lane < q ? lane : lane + 1);
+          else if (lane < 7) fl = has_left ? fx + 4 * (tile_id - 1) + (lane - 3) : nullptr;
+          else if (lane < 11) fl = has_right ? fx + 4 * (tile_id + 1) + (lane - 7) : nullptr;
+          wait_flags(fl, want);
+        }
+        __syncthreads();   // (D) the polling lanes have seen the flags
+        QUAD_STAMP(1);
+        parts_in(xs, XP, HALO, [&](int part) { return ix_slot(l & 1, tile_id, part); });   // the partners' channels of the core frames
+        {
+          // halo rows, both planes, all four parts: rows 0..7 = the left tile's last 8 frames, rows 40..47 = the right tile's first 8
+          u32x4 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int piece = k * 256 + tid;   // 2 sides x 4 parts x 2 planes x 8 frames x 8 chunks
+            const int side = piece >> 9, part = (piece >> 7) & 3, pl = (piece >> 6) & 1, f = (piece >> 3) & 7, c8 = piece & 7;
+            const bool have = side == 0 ? has_left : has_right;
+            v[k] = u32x4{0u, 0u, 0u, 0u};
+            if (have) {
+              const rsrc_t rs = mk_rsrc(ix_slot(l & 1, side == 0 ? tile_id - 1 : tile_id + 1, part), 2 * NT * QCH * 2);
+              v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + (side == 0 ? NT - 8 : 0) + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int piece = k * 256 + tid;
+            const int side = piece >> 9, part = (piece >> 7) & 3, pl = (piece >> 6) & 1, f = (piece >> 3) & 7, c8 = piece & 7;
+            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWB + (QCH * part + 8 * c8) * 2) = v[k];
+          }
+        }
+        __syncthreads();   // (A) the whole image is in place
+        QUAD_STAMP(2);
+      };
+      mfma_pipe_quad<2>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 24, [&](int i) { return kmap_quad(i, q); }, ldb, mid);
+    }
+    QUAD_STAMP(3);
+    // ---- gate -> own quarter of zs (hi / lo of 2^10 z) ----------------------------------------------------------------------------------
+    dtab[tid] = dnext;
+    const float rs2 = inv2 * 0.70710678118654752440f;
+    const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const f32x2 z01 = gate2_scaled(f32x2{yg[ct][0], yg[ct][1]}, f32x2{yf[ct][0], yf[ct][1]}, gcg, gcf, glim, ZSCALE);
+      const f32x2 z23 = gate2_scaled(f32x2{yg[ct][2], yg[ct][3]}, f32x2{yf[ct][2], yf[ct][3]}, gcg, gcf, glim, ZSCALE);
+      const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
+      char* dst = zs + (16 * ct + l15) * ROWB + (cb + 4 * kb) * 2;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+      *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float br = btab[cb + 4 * kb + r], bs = btab[C + cb + 4 * kb + r];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        yg[ct][r] = (xr[ct][r] + br) * s2;
+        yf[ct][r] = bs * s2;
+      }
+    }
+    __syncthreads();   // (Z1) the own quarter of z is complete in LDS; every wave is done reading xs and this layer's biases
+    btab[tid] = bnext0;
+    btab[tid + 256] = bnext1;
+    if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NSQ; ++k) {   // GEMM2's weights (all 8 k-steps), requested behind the drain
+      A[k][0] = lda8(rs_a2, vfrag, sa_g + k * QKSB);
+      A[k][1] = lda8(rs_a2, vfrag, sa_g + k * QKSB + QPLB);
+      A[k][2] = lda8(rs_a2, vfrag, sa_f + k * QKSB);
+      A[k][3] = lda8(rs_a2, vfrag, sa_f + k * QKSB + QPLB);
+    }
+    if (tid == 0) __hip_atomic_store(fz + 4 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) wait_flags(lane < 3 ? fz + 4 * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
+    __syncthreads();   // the partners' quarters of z are published
+    QUAD_STAMP(4);
+    parts_in(zs, ZP, 0, [&](int part) { return zx_slot(tile_id, part); });
+    __syncthreads();   // (B) zs complete
+    QUAD_STAMP(5);
+    // ---- GEMM2: 8 k-steps of 32; yg = residual rows, yf = skip rows of the own channels ---------------------------------------------------
+    {
+      const char* zb = zs + l15 * ROWB + kb * 16;
+      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(zb + 16 * ct * ROWB + ks * 64);
+          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(zb + 16 * ct * ROWB + ks * 64 + ZP);
+        }
+      };
+      mfma_pipe_quad<0>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 8, [](int i) { return i; }, ldb, [] {});
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xr[ct][r] = yg[ct][r] * rs2;
+        sk[ct][r] += yf[ct][r] * inv2;
+      }
+    QUAD_STAMP(6);
+    if (l + 1 == L) break;
+    // ---- next layer: the own quarter of the image into LDS and to the exchange slot, the flag, then the conditioner term and the weights ----
+    write_core();
+    __syncthreads();   // (C1) the own quarter of the core rows is complete
+    if (!(p.inject && (tile_id & 1))) part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (C)
+    if (tid == 0) __hip_atomic_store(fx + 4 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    QUAD_STAMP(7);
+    cond_request(l + 1);
+    prefetch_a1(l + 1);
+  }
+#undef QUAD_STAMP
+  if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);
+  // ---- the skip sum / sqrt(L) of the own channels (net.py:126), fp32 [C][T] rows: what step_tail_kernel reads ---------------------------
+  const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
+  const float rdiv = 1.0f / sqrtf((float)L);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+    if (col_ok[ct]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stf(sk[ct][r] * rdiv, rs_sk, vst[ct], (cb + r) * rowT);
+    }
+}
+#undef BSG_MFMA_Q
+
 #undef BSG_MFMA_H
 
 }  // namespace
@@ -1209,6 +1833,43 @@ int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct) {
   const dim3 grid(16 * cdiv(p.n_tiles, 8)), block(256);
   BSG_REQUIRE(nct == 1, "pair launch: 32-frame tiles only");
   hipLaunchKernelGGL(residual_pair_h2_kernel<1>, grid, block, pair_lds(1), st, p);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// the step tail behind a pair / quad launch: one workgroup per 32-frame tile (a.tiles_per_row = ceil(T / 32)); a.status: the launch's status words
+int launch_step_tail_h2(const TailArgs& a, hipStream_t st) {
+  static bool attr = false;
+  const size_t lds = (size_t)2 * h2_xp(1) + 2 * h2_zp(1) + 96 * 32 * sizeof(float);
+  if (!attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)step_tail_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  BSG_REQUIRE(a.ws_s && a.wo_s && a.wi_s && a.tail_scale && a.M <= 96, "split-fp16 step tail: fragments missing or in_dims > 96");
+  hipLaunchKernelGGL(step_tail_h2_kernel, dim3(a.B * a.tiles_per_row), dim3(512), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+int quad_h2_occupancy() {
+  int o = 0;
+  if (hipFuncSetAttribute((const void*)residual_quad_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds(1)) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_quad_h2_kernel, 256, pair_lds(1)) != hipSuccess)
+    return 0;
+  return o;
+}
+// quad form: FOUR workgroups of 4 waves per 32-frame tile; grid = 32 * ceil(n_tiles / 8) workgroups, all resident (one per CU)
+int launch_residual_quad_h2(const StackArgs& p, hipStream_t st) {
+  BSG_REQUIRE(p.zx && p.ix && p.pflags && p.apack1q && p.apack2q, "quad launch: exchange buffers / 16-row weight fragments missing");
+  hipLaunchKernelGGL(residual_quad_h2_kernel, dim3(32 * cdiv(p.n_tiles, 8)), dim3(256), pair_lds(1), st, p);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+// fp32 [M][K] weights -> hi / lo fp16 A fragments of v_mfma_f32_16x16x32_f16 (16-row tiles), scaled by the layer's table entry
+int pack_a_frag_q(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
+                  int is_gemm2, hipStream_t st) {
+  const long long total = (long long)M * K;
+  hipLaunchKernelGGL(pack_a_frag_q_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(out), M, K, Kc, sm, sc,
+                     stp, is_gemm2 ? tab + 2 : tab, is_gemm2);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

@@ -50,6 +50,8 @@ struct StackArgs {
   const unsigned short* apack1s;  // split-fp16 form (diffnet_h2.hip): hi / lo fp16 fragments of the dilated conv, layer 0; + l * 2*2C*3C
   const unsigned short* apack2s;  // split-fp16 form: output projection, layer 0; + l * 2*2C*C
   const float* h2_scale;          // split-fp16 form: [L][4] = s1, 1/s1, s2 * 2^10, 1/(s2 * 2^10)
+  const unsigned short* apack1q;  // quad form: the same weights as 16-row fragments of v_mfma_f32_16x16x32_f16, layer 0; + l * 2*2C*3C
+  const unsigned short* apack2q;  // quad form: output projection, layer 0; + l * 2*2C*C
   const float* bias_out;  // layer 0; + l * 2C
   long long ct_stride;
   float* hx;              // [2 parities][n_tiles][2 sides][C][8] edge exchange
@@ -77,6 +79,11 @@ int stack_h2_occupancy(int nct);   // nct = column tiles of 32 frames per workgr
 // 16 * ceil(n_tiles / 8) workgroups, all of which must be resident (one per CU).  No fused tail: the skip sum goes to p.skip
 int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct);   // nct: 32- or 64-frame tiles (p.n_tiles / p.tiles_per_row count those)
 int pair_h2_occupancy(int nct);
+// quad form: FOUR workgroups per 32-frame tile, each a quarter of the channels (B <= 2 at T = 1000); p.zx / p.ix slots are [tile][4 parts]
+int launch_residual_quad_h2(const StackArgs& p, hipStream_t st);
+int quad_h2_occupancy();
+int pack_a_frag_q(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
+                  int is_gemm2, hipStream_t st);
 int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* maxbits, float* tab, hipStream_t st);
 int pack_a_frag_h2(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
                    int is_gemm2, hipStream_t st);

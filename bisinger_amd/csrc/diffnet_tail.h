@@ -85,6 +85,7 @@ struct TailArgs {
   const unsigned short* wo_s;  // output projection [16][2][3][64][8]   (rows >= M zero)
   const unsigned short* wi_s;  // input projection  [6][2][8][64][8]    (K padded to 96)
   const float* tail_scale;     // [3][2]: power-of-two scale and its reciprocal of the three projections
+  unsigned* status;            // step_tail_h2_kernel: the launch status words (word 1 += range events), or null
   StepCoef k;
   unsigned long long seed, quad_row0;   // Philox: key, and the flat element index of this shard's row 0
   unsigned stream;
@@ -107,6 +108,8 @@ __device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigne
 
 // split-fp16 stack launch (diffnet_h2.hip), optionally with the step tail in the same launch
 int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct);
+// the step tail behind a pair / quad launch, on the 16-bit matrix pipe (diffnet_h2.hip step_tail_h2_kernel)
+int launch_step_tail_h2(const TailArgs& a, hipStream_t st);
 int h2_tail_pack(const float* ws, const float* wo96, const float* wi96, unsigned short* out_ws, unsigned short* out_wo, unsigned short* out_wi,
                  unsigned* maxbits, float* tab, hipStream_t st);
 

@@ -181,6 +181,6 @@ def test_split_launch_equals_regular_launch(model, data):
     a = net(x, t, cond).clone()
     b1 = net(x[3:4].contiguous(), t[3:4].contiguous(), cond[3:4].contiguous()).clone()
     # (under BSG_H2=0 — the fallback-matrix run of the whole suite, profiles/r03_fallback_suite.txt — the process has no split-fp16 launch)
-    assert net.last_path() == ('stack_h2_pair' if os.environ.get('BSG_H2', '1') != '0' else net.last_path())   # one utterance: the pair form
+    assert net.last_path() == ('stack_h2_quad' if os.environ.get('BSG_H2', '1') != '0' else net.last_path())   # one utterance: the quad form
     assert maxabs(b1[0], a[3]) <= 1e-5      # 32-frame against 64-frame tiles: the same sums, fp32 accumulation order alike
     assert maxabs(b1[0], one[0]) <= 1e-5

@@ -155,11 +155,18 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_PAIR='0'), 'stack_h2', 1e-5),   # T < one tile
     # the PAIR form of the split-fp16 launch (two workgroups on two CUs per 32-frame tile, each half of the channels; the default while the
     # 32-frame tiles fill at most half of the CUs): the same sums with GEMM1's k-steps in another order
-    (1, 1000, F23, H2, 'stack_h2_pair', 1e-5),                           # a single utterance: 32 tiles, 64 workgroups
+    (1, 1000, F23, dict(H2, BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),    # a single utterance: 32 tiles, 64 workgroups
     (4, 1000, F23, H2, 'stack_h2_pair', 1e-5),                           # 128 tiles: every CU holds one half of a tile
-    (3, 77, F23, dict(H2, BSG_H2='2'), 'stack_h2_pair', 1e-5),           # partial tile, rows of 3 tiles
-    (5, 333, F23, dict(H2, BSG_H2='2'), 'stack_h2_pair', 1e-5),
-    (2, 31, F23, dict(H2, BSG_H2='2'), 'stack_h2_pair', 1e-5),           # T < one tile: no neighbours at all
+    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),   # partial tile, rows of 3 tiles
+    (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),   # T < one tile: no neighbours at all
+    # the QUAD form (four workgroups on four CUs per 32-frame tile, each a quarter of the channels, 16-row matrix tiles; the default while
+    # the 32-frame tiles fill at most a quarter of the CUs)
+    (1, 1000, F23, H2, 'stack_h2_quad', 1e-5),                           # a single utterance: 32 tiles, 128 workgroups
+    (2, 1000, F23, H2, 'stack_h2_quad', 1e-5),                           # 64 tiles: every CU holds a quarter of a tile
+    (3, 77, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),           # partial tile, rows of 3 tiles
+    (5, 333, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),           # T < one tile: no neighbours at all
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),   # the same with 64-frame tiles
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),
 ])
