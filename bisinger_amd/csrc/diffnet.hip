@@ -1076,15 +1076,13 @@ struct bsg_diffnet {
   bool h2_off = false;                 // bsg_diffnet_set_h2(h, 0): this handle multiplies on the fp32 matrix pipe only
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
   int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
-  bool stack_pair = false;             // ... the pair form (two workgroups per 32-frame tile, diffnet_h2.hip residual_pair_h2_kernel)
-  bool stack_quad = false;             // ... the quad form (four workgroups per 32-frame tile, residual_quad_h2_kernel); implies stack_pair
-  int occ_quad = -1;
-  unsigned short *apack1q = nullptr, *apack2q = nullptr;   // the split-fp16 weights once more as 16-row fragments (quad form)
-  int occ_pair[3] = {-1, -1, -1};      // resident workgroups per CU of the pair form by tile width in column tiles (-1: not queried)
-  unsigned short* pair_zx = nullptr;   // pair form: exchange slots of the z halves [tiles][2][2 planes][32][C/2] fp16
-  unsigned short* pair_ix = nullptr;   //            ... of the image halves [2 parities][tiles][2][2 planes][32][C/2]
-  unsigned* pair_flags = nullptr;      //            [2][tiles][2] image / z flags
-  size_t pair_cap = 0;                 // 32-frame tile equivalents the pair buffers are sized for
+  int stack_parts = 0;                 // ... a part form (diffnet_h2.hip residual_part_h2_kernel): workgroups per tile (4), else 0
+  int occ_part[3] = {-1, -1, -1};      // resident workgroups per CU of the quad form by tile width in units of 32 frames (-1: not queried)
+  unsigned short *apack1q = nullptr, *apack2q = nullptr;   // the split-fp16 weights once more as 16-row fragments (part forms)
+  unsigned short* part_zx = nullptr;   // part forms: exchange slots of the z parts [tiles][P][2 planes][tile frames][C/P] fp16
+  unsigned short* part_ix = nullptr;   //             ... of the image parts [2 parities][tiles][P][2 planes][tile frames][C/P]
+  unsigned* part_flags = nullptr;      //             [2][tiles][P] image / z flags
+  size_t part_cap = 0;                 // 32-frame tile equivalents the exchange buffers are sized for
   int num_cus = 0;
   const char* last_path = "none";      // form of the last residual-layer launch (bsg_diffnet_last_path)
   // channel-split launch for small batches (residual_split_kernel)
@@ -1140,9 +1138,9 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->tail_s) (void)hipFree(h->tail_s);
   if (h->tail_scale) (void)hipFree(h->tail_scale);
   if (h->clk) (void)hipFree(h->clk);
-  if (h->pair_zx) (void)hipFree(h->pair_zx);
-  if (h->pair_ix) (void)hipFree(h->pair_ix);
-  if (h->pair_flags) (void)hipFree(h->pair_flags);
+  if (h->part_zx) (void)hipFree(h->part_zx);
+  if (h->part_ix) (void)hipFree(h->part_ix);
+  if (h->part_flags) (void)hipFree(h->part_flags);
   if (h->apack1q) (void)hipFree(h->apack1q);
   if (h->apack2q) (void)hipFree(h->apack2q);
   delete h;
@@ -1572,43 +1570,37 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       if (env_nct < 0) { const char* e = getenv("BSG_H2_NCT"); env_nct = e ? atoi(e) : 0; }
       int nct = (long long)B * cdiv(T, 32) > h->num_cus ? 2 : 1;
       if (env_nct == 1 || env_nct == 2) nct = env_nct;
-      h->stack_pair = false;
-      h->stack_quad = false;
+      h->stack_parts = 0;
       {
-        // pair form (residual_pair_h2_kernel): two workgroups on two CUs of an XCD share a tile, each half of the channels and half of the weight
-        // stream; the whole batch in one launch.  Taken while pairs of 32-frame tiles fit the chip: B * ceil(T / 32) <= CUs / 2 (B <= 4 at T = 1000;
-        // ms per 100-step pass at T = 1000, one workgroup per tile / pairs: B=1 54.5 / 44.8, B=2 52.6 / 46.1, B=4 51.5 / 47.7).  Pairs of 64-frame
-        // tiles (B = 5 .. 8) measured SLOWER than one workgroup per 32-frame tile (B=8: 77.4 against 68.1 ms): with one wave per SIMD the matrix
-        // pipe is busy half of a k-step (profiles/r03_pair_form/) — not built.  BSG_H2_PAIR=0: no pair form at all
-        static int env_pair = -1;
-        if (env_pair < 0) { const char* e = getenv("BSG_H2_PAIR"); env_pair = e ? atoi(e) : 1; }
-        // quad form (residual_quad_h2_kernel): FOUR workgroups on four CUs of an XCD share a 32-frame tile, each a quarter of the channels and of
-        // the weight stream, 16-row matrix tiles.  Taken while quads fit the chip: B * ceil(T / 32) <= CUs / 4 (B <= 2 at T = 1000).
-        // BSG_H2_QUAD=0: pairs instead
-        static int env_quad = -1;
+        // part forms (residual_part_h2_kernel): FOUR workgroups on four CUs of an XCD share a tile, each a quarter of the channels and of the
+        // weight stream; the whole batch in one launch.  Quads of 32-frame tiles while B * ceil(T / 32) <= CUs / 4 (one or two utterances at
+        // T = 1000), quads of 64-frame tiles while B * ceil(T / 64) <= CUs / 4 (B <= 4).  ms per 100-step pass at T = 1000, one workgroup per
+        // tile / part form: B=1 54.5 / 25.7, B=2 52.6 / 28.4, B=3 52.0 / 34.6, B=4 51.5 / 37.9.  BSG_H2_PART=0: none (BSG_H2_QUAD=0 /
+        // BSG_H2_QUAD64=0: not that width)
+        static int env_part = -1, env_quad = -1, env_quad64 = -1;
+        if (env_part < 0) { const char* e = getenv("BSG_H2_PART"); env_part = e ? atoi(e) : 1; }
         if (env_quad < 0) { const char* e = getenv("BSG_H2_QUAD"); env_quad = e ? atoi(e) : 1; }
-        if (env_pair && env_quad && env_nct == 0 && h->apack1q) {
-          const long long t32 = (long long)B * cdiv(T, 32);
-          if (4 * 8 * cdiv(t32, 8) <= h->num_cus) {
-            if (h->occ_quad < 0) h->occ_quad = quad_h2_occupancy() >= 1 ? 1 : 0;
-            if (h->occ_quad >= 1) {
+        if (env_quad64 < 0) { const char* e = getenv("BSG_H2_QUAD64"); env_quad64 = e ? atoi(e) : 1; }
+        auto take_quad = [&](int pn) {
+          if (h->occ_part[pn] < 0) h->occ_part[pn] = part_h2_occupancy(4, pn) >= 1 ? 1 : 0;
+          if (h->occ_part[pn] < 1) return false;
+          h->stack_is_h2 = true;
+          h->stack_nct = pn;
+          h->stack_parts = 4;
+          return true;
+        };
+        const long long t32 = (long long)B * cdiv(T, 32), t64 = (long long)B * cdiv(T, 64);
+        if (env_part && env_nct == 0 && h->apack1q) {
+          if (env_quad && 4 * 8 * cdiv(t32, 8) <= h->num_cus && take_quad(1)) return B;
+          if (env_quad64 && 4 * 8 * cdiv(t64, 8) <= h->num_cus && take_quad(2)) return B;
+          static int env_pair64 = -1;
+          if (env_pair64 < 0) { const char* e = getenv("BSG_H2_PAIR64"); env_pair64 = e ? atoi(e) : 0; }
+          if (env_pair64 && 2 * 8 * cdiv(t64, 8) <= h->num_cus) {
+            if (h->occ_part[0] < 0) h->occ_part[0] = part_h2_occupancy(2, 2) >= 1 ? 1 : 0;
+            if (h->occ_part[0] >= 1) {
               h->stack_is_h2 = true;
-              h->stack_nct = 1;
-              h->stack_pair = true;
-              h->stack_quad = true;
-              return B;
-            }
-          }
-        }
-        if (env_pair && env_nct == 0) {
-          const long long t32 = (long long)B * cdiv(T, 32);
-          const int pn = 2 * 8 * cdiv(t32, 8) <= h->num_cus ? 1 : 0;
-          if (pn) {
-            if (h->occ_pair[pn] < 0) h->occ_pair[pn] = pair_h2_occupancy(pn) >= 1 ? 1 : 0;
-            if (h->occ_pair[pn] >= 1) {
-              h->stack_is_h2 = true;
-              h->stack_nct = pn;
-              h->stack_pair = true;
+              h->stack_nct = 2;
+              h->stack_parts = 2;
               return B;
             }
           }
@@ -1657,7 +1649,7 @@ constexpr unsigned kFlagSpan = 64;
 static int next_stack_epoch(bsg_diffnet* h, hipStream_t st, unsigned* fbase) {
   if (++h->stack_epoch >= (1u << 25)) {
     BSG_HIP(hipMemsetAsync(h->flags, 0, h->flags_cap * sizeof(unsigned), st));
-    if (h->pair_flags) BSG_HIP(hipMemsetAsync(h->pair_flags, 0, 2 * h->pair_cap * 2 * sizeof(unsigned), st));
+    if (h->part_flags) BSG_HIP(hipMemsetAsync(h->part_flags, 0, 2 * h->part_cap * 4 * sizeof(unsigned), st));
     h->stack_epoch = 1;
   }
   *fbase = h->stack_epoch * kFlagSpan;
@@ -1688,31 +1680,27 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
-    if (h2 && h->stack_pair) {
-      BSG_REQUIRE(!tail && nb == B, "pair launch: whole batch, no fused tail");
+    if (h2 && h->stack_parts) {
+      BSG_REQUIRE(!tail && nb == B, "part launch: whole batch, no fused tail");
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       const size_t need32 = (size_t)p.n_tiles * nct;   // slots scale with the tile width: size the buffers in 32-frame tile equivalents
-      if (need32 > h->pair_cap) {
+      if (need32 > h->part_cap) {
         BSG_HIP(hipStreamSynchronize(st));
-        if (h->pair_zx) (void)hipFree(h->pair_zx);
-        if (h->pair_ix) (void)hipFree(h->pair_ix);
-        if (h->pair_flags) (void)hipFree(h->pair_flags);
-        h->pair_zx = nullptr; h->pair_ix = nullptr; h->pair_flags = nullptr; h->pair_cap = 0;
+        if (h->part_zx) (void)hipFree(h->part_zx);
+        if (h->part_ix) (void)hipFree(h->part_ix);
+        if (h->part_flags) (void)hipFree(h->part_flags);
+        h->part_zx = nullptr; h->part_ix = nullptr; h->part_flags = nullptr; h->part_cap = 0;
         const size_t cap = (size_t)h->num_cus > need32 ? (size_t)h->num_cus : need32;
-        const size_t slot = (size_t)2 * 32 * (C / 2) * sizeof(unsigned short);   // one half of a 32-frame tile: 2 planes x 32 frames x C/2 fp16 = 16 KB
-        BSG_HIP(hipMalloc((void**)&h->pair_zx, cap * 2 * slot));
-        BSG_HIP(hipMalloc((void**)&h->pair_ix, 2 * cap * 2 * slot));
-        BSG_HIP(hipMalloc((void**)&h->pair_flags, 2 * cap * 2 * sizeof(unsigned)));
-        BSG_HIP(hipMemsetAsync(h->pair_flags, 0, 2 * cap * 2 * sizeof(unsigned), st));   // flag values are launch epoch x 64 + layer: monotonic
-        h->pair_cap = cap;
+        const size_t tile_bytes = (size_t)2 * 32 * C * sizeof(unsigned short);   // all parts of a 32-frame tile: 2 planes x 32 frames x C fp16 = 32 KB
+        BSG_HIP(hipMalloc((void**)&h->part_zx, cap * tile_bytes));
+        BSG_HIP(hipMalloc((void**)&h->part_ix, 2 * cap * tile_bytes));
+        BSG_HIP(hipMalloc((void**)&h->part_flags, 2 * cap * 4 * sizeof(unsigned)));
+        BSG_HIP(hipMemsetAsync(h->part_flags, 0, 2 * cap * 4 * sizeof(unsigned), st));   // flag values are launch epoch x 64 + layer: monotonic
+        h->part_cap = cap;
       }
-      p.zx = h->pair_zx; p.ix = h->pair_ix; p.pflags = h->pair_flags;
-      if (h->stack_quad) {
-        p.apack1q = h->apack1q; p.apack2q = h->apack2q;
-        TRY(launch_residual_quad_h2(p, st));
-      } else {
-        TRY(launch_residual_pair_h2(p, st, nct));
-      }
+      p.zx = h->part_zx; p.ix = h->part_ix; p.pflags = h->part_flags;
+      p.apack1q = h->apack1q; p.apack2q = h->apack2q;
+      TRY(launch_residual_part_h2(p, st, h->stack_parts, nct));
     } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
@@ -1737,7 +1725,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     }
   }
   BSG_REQUIRE(!tail || h2, "stack launch: a fused tail needs the split-fp16 form");
-  h->last_path = h2 ? (h->stack_quad ? "stack_h2_quad" : h->stack_pair ? "stack_h2_pair" : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
+  h->last_path = h2 ? (h->stack_parts == 2 ? "stack_h2_pair64" : h->stack_parts ? (h->stack_nct == 2 ? "stack_h2_quad64" : "stack_h2_quad") : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
   return BSG_OK;
 }
 
@@ -1931,7 +1919,7 @@ static int step_from_xa(bsg_diffnet* h, int t_uniform, TailArgs& a, float* x, in
   static int env = -1;
   if (env < 0) { const char* e = getenv("BSG_H2_TAIL"); env = e ? atoi(e) : 1; }
   const int srows = (h->no_split || h->compute != BSG_COMPUTE_F32 || !env || !h->tail_s || h->M > 96) ? 0 : stack_rows(h, B, T, st);
-  if (srows && h->stack_is_h2 && !h->stack_pair) {
+  if (srows && h->stack_is_h2 && !h->stack_parts) {
     const size_t off = (size_t)h->row_off * C * T;
     a.x = x; a.xa_next = h->xa + off;
     a.b_skip = h->b_skip; a.b_fin = h->b_fin96; a.b_in = h->b_in;
@@ -1948,8 +1936,8 @@ static int step_from_xa(bsg_diffnet* h, int t_uniform, TailArgs& a, float* x, in
     return BSG_OK;
   }
   TRY(layers_from_xa(h, t_uniform, B, T, st));
-  if (srows && h->stack_is_h2 && h->stack_pair && strncmp(h->last_path, "stack_h2_", 9) == 0) {
-    // behind a pair / quad launch: the tail on the 16-bit matrix pipe too (step_tail_h2_kernel; BSG_H2_TAIL=0: the fp32-pipe tail)
+  if (srows && h->stack_is_h2 && h->stack_parts && strncmp(h->last_path, "stack_h2_", 9) == 0) {
+    // behind a part launch: the tail on the 16-bit matrix pipe too (step_tail_h2_kernel; BSG_H2_TAIL=0: the fp32-pipe tail)
     const size_t off = (size_t)h->row_off * C * T;
     a.skip = h->skip + off; a.skip_h = nullptr;
     a.x = x; a.xa_next = h->xa + off;

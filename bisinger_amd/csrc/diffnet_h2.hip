@@ -720,8 +720,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   }
 }
 // ------------------------------------------------------------------------------------------------
-// The step tail of the pair / quad forms as its own launch on the 16-bit matrix pipe: what the TAIL branch of residual_stack_h2_kernel does on
-// chip, from the skip sum in HBM (fp32 [C][T], written by the last layer of the pair / quad launch).  One workgroup of 8 waves per 32-frame
+// The step tail of the part forms as its own launch on the 16-bit matrix pipe: what the TAIL branch of residual_stack_h2_kernel does on
+// chip, from the skip sum in HBM (fp32 [C][T], written by the last layer of the part launch).  One workgroup of 8 waves per 32-frame
 // tile; the three projections as split-fp16 GEMMs (the fragments and scales of h2_tail_pack), the sampler update in fp32 with the
 // reference's rounding sequence (diffnet_tail.h).  It replaces step_tail_kernel (fp32 matrix pipe: 39.8 us per step at B = 1, where the
 // 32 workgroups of a single utterance run three serial GEMMs of 128 + 128 + 40 16-pass MFMAs) behind those launches only; operands beyond
@@ -914,454 +914,29 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// PAIR form for small batches (B * ceil(T / 32) <= CUs / 2; B <= 4 at T = 1000).  With one workgroup per 32-frame tile a single utterance
-// keeps 32 of the 256 CUs busy, and each of them is bound by streaming the layer's 2.1 MB of weight fragments out of L2 (the two GEMMs
-// take 18.8 us of a 25.5-us layer where their MFMAs need 10; tools/l2_fill.hip: a CU pulls at most ~64 B/clk).  Here a tile is computed by
-// TWO workgroups of 4 waves on two CUs of one XCD, each owning HALF of the channels — its gate / filter rows of GEMM1, its residual / skip
-// rows of GEMM2, its 128 channels of x and of the skip sum in registers — so every CU streams half of the weights.  What a workgroup
-// lacks it gets from its partner through L2, twice per layer, with the hand-off protocol of the launch above (write-through stores,
-// drain, barrier, flag = launch epoch + layer, bounded poll, sc1 loads):
-//   * after the gate: the partner's half of z (16 KB, both planes) — GEMM2 contracts over all 256 channels;
-//   * after GEMM2: the partner's half of the next image (16 KB) and, from the two neighbouring tiles' workgroups, the 8-frame edges of
-//     both halves — GEMM1 contracts over all 256 channels of 48 frames.  GEMM1 starts with the centre tap of its OWN channels (8 k-steps),
-//     the only part of the image a workgroup has without waiting.
-// The step tail is not fused (its skip projection contracts over both halves): the skip sum goes to HBM and step_tail_kernel follows.
+// PART forms for small batches (residual_part_h2_kernel<P, W, NC>).  With one workgroup per tile a single utterance keeps 32 of the 256
+// CUs busy, each of them bound by streaming the layer's 2.1 MB of weight fragments out of L2 (tools/l2_fill.hip: a CU pulls at most
+// ~64 B/clk).  Here a tile is computed by P workgroups of W waves on P CUs of one XCD, each owning C / P channels — its gate / filter rows
+// of GEMM1, its residual / skip rows of GEMM2, its channels of x and of the skip sum in registers — so every CU streams 1 / P of the
+// weights.  A wave owns 16 channels as 16-row matrix tiles over NC column tiles of 16 frames (v_mfma_f32_16x16x32_f16: lane l holds
+// A[row l & 15][k = 8 (l >> 4) + j], B[k][column l & 15]; C/D column l & 15, rows 4 (l >> 4) + r; the weights are packed a second time in that
+// fragment order, pack_a_frag_q_kernel).  What a workgroup lacks it gets from its partners through L2, twice per layer, with the hand-off
+// protocol of the launch above (write-through stores, drain, barrier, flag = launch epoch + layer, bounded poll by one lane per flag, sc1
+// loads):
+//   * after the gate: the partners' parts of z — GEMM2 contracts over all 256 channels;
+//   * after GEMM2: the partners' parts of the next image and, from the two neighbouring tiles' workgroups, the 8-frame edges of all parts —
+//     GEMM1 contracts over all 256 channels of NT + 16 frames.  GEMM1 starts with the 32-deep k-steps of the centre tap over its OWN
+//     channels, the only part of the image a workgroup has without waiting.
+// The step tail is not fused (its skip projection contracts over all parts): the skip sum goes to HBM and step_tail_h2_kernel follows.
+// Instantiated:
+//   <4, 4, 2>  QUAD of a 32-frame tile: 4 x B * ceil(T / 32) <= CUs (one or two utterances at T = 1000)
+//   <4, 4, 4>  QUAD of a 64-frame tile: 4 x B * ceil(T / 64) <= CUs (B <= 4 at T = 1000)
+// Measured and not kept (profiles/r03_part_forms/): pairs of 32-frame tiles on 32-row matrix tiles (the first form of this idea: B=1 44.4 ms
+// per 100-step pass against 25.7 for the quad, B=4 47.3 against 37.9 for the quad of 64-frame tiles), pairs of 64-frame tiles with 4 or 8
+// waves (B=8: 77.4 / 74.9 ms against 68.8 for one workgroup per 32-frame tile: with every CU busy the conditioner burst and the exchange
+// phases grow faster than the GEMMs shrink), octets of 2 waves (B=1: 27.8 against 25.7 ms: the exchange among eight costs more than the
+// halved weight stream saves).
 // ------------------------------------------------------------------------------------------------
-constexpr int PCH = C / 2;   // channels per workgroup of a pair
-
-// i-th executed k-step of GEMM1 -> k-step index (tap-major, 16 channel groups per tap) for part q
-__device__ __forceinline__ int kmap_pair(int i, int q) {
-  if (i < 8) return 16 + 8 * q + i;                  // centre tap, own channels
-  if (i < 16) return 16 + 8 * (1 - q) + (i - 8);     // centre tap, the partner's channels
-  if (i < 32) return i - 16;                         // tap 0
-  return i;                                          // tap 2
-}
-
-// weight ring of the pair form in k-steps: one wave per SIMD has the registers, and with half as many waves per CU the bytes in flight —
-// not the L2 — bound the weight stream (phase stamps at B=1 with a ring of 4: 0.22 us per k-step where the MFMAs need 0.08)
-constexpr int NSP = 8;   // (measured at B=1, us per layer: ring 4 18.6, ring 8 17.5, ring 16 18.9; three accumulators per row tile instead of one, or an
-                         // L2 prefetch of the next layer's weights, change nothing: profiles/r03_pair_form/)
-// the k-step pipeline of mfma_pipe_h2 with the k-step order given by `km` (NCT column tiles of 32 frames)
-template <int ROT, int NCT, typename KM, typename LDB, typename MID>
-__device__ __forceinline__ void mfma_pipe_pair(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT], f16x8 (&A)[NSP][4], rsrc_t rs, int vfrag, int sa0, int sa1,
-                                               int n_ks, KM km, LDB ldb, MID mid) {
-  f16x8 B[2][2 * NCT];
-  ldb(km(0), B[0]);
-  const int last = n_ks - 1;
-#pragma unroll 1
-  for (int ks = 0; ks < n_ks; ks += NSP) {
-#pragma unroll
-    for (int s = 0; s < NSP; ++s) {
-      if (ROT > 0 && s == ROT % NSP && ks == ROT - ROT % NSP) {   // the hand-off sits behind the first ROT k-steps
-        mid();
-        ldb(km(ks + s), B[s & 1]);
-      }
-      const int in = ks + s + 1 <= last ? ks + s + 1 : last;
-      // (never across the hand-off: the k-step behind it is read again above)
-      ldb(km(in), B[(s + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      const f16x8(&Bc)[2 * NCT] = B[s & 1];
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {   // hi hi
-        BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct]);
-        BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct]);
-      }
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {   // hi lo
-        BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct + 1]);
-        BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct + 1]);
-      }
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {   // lo hi
-        BSG_MFMA_H(c0[ct], A[s][1], Bc[2 * ct]);
-        BSG_MFMA_H(c1[ct], A[s][3], Bc[2 * ct]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const int ir = ks + s + NSP <= last ? ks + s + NSP : last;
-      const int kr = km(ir);
-      A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
-      A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
-      A[s][2] = lda8(rs, vfrag, sa1 + kr * KSB2);
-      A[s][3] = lda8(rs, vfrag, sa1 + kr * KSB2 + PLB);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-// NCT = column tiles of 32 frames per tile: 1 (32-frame tiles: while those fill at most half of the CUs, B <= 4 at T = 1000) or 2 (64-frame
-// tiles: B = 5 .. 8 at T = 1000, where one workgroup per 32-frame tile had every CU stream the whole layer for half the matrix work)
-template <int NCT>
-__global__ __launch_bounds__(256, 1) void residual_pair_h2_kernel(StackArgs p) {
-  constexpr int NT = 32 * NCT, XP = h2_xp(NCT), ZP = h2_zp(NCT);
-  constexpr int NPIECE = 2 * NT * 16;   // 16-byte pieces of one exchange slot: 2 planes x NT frames x 16 chunks of 8 channels
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  char* xs = lds_raw;                  // [2 planes][NT + 16 frames][528 B]: hi / lo of x + d_l, ALL channels, frames t0-8 .. t0+NT+7
-  char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
-  float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]
-  float* btab = dtab + C;                                              // [512]
-
-  // workgroup -> (tile, part): the two parts of a tile sit on the same XCD (workgroup i runs on XCD i mod 8)
-  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
-  const int slot = (int)blockIdx.x >> 3;
-  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + (slot >> 1);
-  const int q = slot & 1;
-  if ((slot >> 1) >= per_xcd || tile_id >= n_tiles) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int tpr = p.tiles_per_row, L = p.L, T = p.T;
-  const int b = tile_id / tpr, j = tile_id - b * tpr;
-  const int t0 = j * NT;
-  const int tb = p.t_dev ? (int)p.t_dev[b] : p.t_uniform;
-  const bool has_left = j > 0, has_right = j + 1 < tpr;
-  const int cb = PCH * q + 32 * wave;   // first channel of this wave
-
-  const unsigned plane = (unsigned)C * T * 4;
-  const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
-  const int rowT = T * 4, vfrag = lane * 16;
-  int vcol[NCT], vst[NCT];
-  bool col_ok[NCT];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const int col = t0 + 32 * ct + l31;
-    col_ok[ct] = col < T;
-    vcol[ct] = (lh * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
-    vst[ct] = (lh * 4 * T + col) * 4;
-  }
-  const int sa_g = (4 * q + wave) * 1024, sa_f = (8 + 4 * q + wave) * 1024;   // gate / filter (= residual / skip) row tile inside a plane of a k-step slab
-
-  float xr[NCT][16], sk[NCT][16];
-  f32x16 yg[NCT], yf[NCT];
-  int range_flag = 0;
-  auto range_check = [&](unsigned worst) {
-    if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
-  };
-  auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
-  unsigned* fx = p.pflags;                   // image flags [n_tiles][2]
-  unsigned* fz = p.pflags + 2 * n_tiles;     // z flags     [n_tiles][2]
-  // a whole wave: every lane with a flag polls its own (all in flight together); bounded like the polls of residual_stack_h2_kernel
-  auto wait_flags = [&](const unsigned* fl, unsigned want) {
-    bool pend = fl != nullptr;
-    if (p.inject) {
-      if (pend) atomicAdd(p.status, 1u);
-      return;
-    }
-    unsigned spins = 0;
-    while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
-      if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
-      if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
-      __builtin_amdgcn_s_sleep(2);
-      ++spins;
-      const bool quit = spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
-      if (quit) {
-        if (pend) atomicAdd(p.status, 1u);
-        break;
-      }
-    }
-  };
-  auto wait_flag = [&](const unsigned* fl, unsigned want) {   // one lane
-    if (p.inject) { atomicAdd(p.status, 1u); return; }
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-        atomicAdd(p.status, 1u);
-        break;
-      }
-    }
-  };
-
-  auto cond_request = [&](int l) {
-    const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int so = (cb + acc_row0(r)) * rowT;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        yg[ct][r] = ldf(rs_ct, vcol[ct], so);
-        yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
-      }
-    }
-  };
-  auto write_core = [&]() {
-    float dv[16];
-    unsigned worst = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dv[r] = dtab[cb + acc_row(r, lh)];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float v0 = xr[ct][4 * g] + dv[4 * g], v1 = xr[ct][4 * g + 1] + dv[4 * g + 1];
-        const float v2 = xr[ct][4 * g + 2] + dv[4 * g + 2], v3 = xr[ct][4 * g + 3] + dv[4 * g + 3];
-        worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
-        const HiLo s0 = split2(v0, v1);
-        const HiLo s1_ = split2(v2, v3);
-        u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
-        if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
-        char* dst = xs + (HALO + 32 * ct + l31) * ROWB + (cb + 8 * g + 4 * lh) * 2;
-        *reinterpret_cast<u32x2*>(dst) = wh;
-        *reinterpret_cast<u32x2*>(dst + XP) = wl;
-      }
-    range_check(worst);
-  };
-  // a half (PCH channels) of NT LDS rows starting at row r0, both planes, to / from an exchange slot [plane][NT][PCH]: 16-byte pieces,
-  // write-through stores / sc1 loads (the hand-off form that needs no acquire)
-  auto half_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot_p) {
-    const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * PCH * 2);
-#pragma unroll
-    for (int k = 0; k < NPIECE / 256; ++k) {
-      const int piece = k * 256 + tid;
-      const int pl = piece / (NT * 16), f = (piece >> 4) % NT, c16 = piece & 15;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (PCH * part + 8 * c16) * 2);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
-    }
-  };
-  auto half_in = [&](char* img, int plane_bytes, int r0, int part, const unsigned short* slot_p) {
-    const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * PCH * 2);
-    u32x4 v[NPIECE / 256];
-#pragma unroll
-    for (int k = 0; k < NPIECE / 256; ++k) {
-      const int piece = k * 256 + tid;
-      const int pl = piece / (NT * 16), f = (piece >> 4) % NT, c16 = piece & 15;
-      v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
-    }
-#pragma unroll
-    for (int k = 0; k < NPIECE / 256; ++k) {
-      const int piece = k * 256 + tid;
-      const int pl = piece / (NT * 16), f = (piece >> 4) % NT, c16 = piece & 15;
-      *reinterpret_cast<u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (PCH * part + 8 * c16) * 2) = v[k];
-    }
-  };
-  const size_t slot_halfs = (size_t)2 * NT * PCH;   // fp16 elements of one exchange slot
-  auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * 2 + part) * slot_halfs; };
-  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * 2 + part) * slot_halfs; };
-
-  // ---- layer 0: x from HBM — this wave's channels into registers, the WHOLE image (all channels, halo frames included) into LDS ----------
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      xr[ct][r] = ldf(rs_x, vcol[ct], (cb + acc_row0(r)) * rowT);
-      sk[ct][r] = 0.f;
-    }
-  {
-    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
-    unsigned worst = 0;
-    constexpr int ROWS = NT + 2 * HALO;
-#pragma unroll 1
-    for (int it = 0; it < 32 * ROWS / 256; ++it) {   // 32 chunks of 8 channels x ROWS frames, lanes = consecutive frames
-      const int item = it * 256 + tid;
-      const int hc = item / ROWS, row = item - hc * ROWS;
-      const int th = t0 - HALO + row;
-      const bool hok = th >= 0 && th < T;
-      float hv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
-      if (hok) worst = max(worst, max(max(max(absbits(hv[0]), absbits(hv[1])), max(absbits(hv[2]), absbits(hv[3]))),
-                                      max(max(absbits(hv[4]), absbits(hv[5])), max(absbits(hv[6]), absbits(hv[7])))));
-      const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
-      u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
-      if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
-      *reinterpret_cast<u32x4*>(xs + row * ROWB + hc * 16) = wh;
-      *reinterpret_cast<u32x4*>(xs + XP + row * ROWB + hc * 16) = wl;
-    }
-    range_check(worst);
-  }
-  dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
-  btab[tid] = p.bias_out[tid];
-  btab[tid + 256] = p.bias_out[tid + 256];
-  cond_request(0);
-  f16x8 A[NSP][4];
-  auto prefetch_a1 = [&](int l) {
-    const rsrc_t rs = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
-#pragma unroll
-    for (int k = 0; k < NSP; ++k) {
-      const int kr = kmap_pair(k, q);
-      A[k][0] = lda8(rs, vfrag, sa_g + kr * KSB2);
-      A[k][1] = lda8(rs, vfrag, sa_g + kr * KSB2 + PLB);
-      A[k][2] = lda8(rs, vfrag, sa_f + kr * KSB2);
-      A[k][3] = lda8(rs, vfrag, sa_f + kr * KSB2 + PLB);
-    }
-  };
-  prefetch_a1(0);
-  __syncthreads();   // the staged image and the tables
-
-#define PAIR_STAMP(i)                                                                                                      \
-  do {                                                                                                                    \
-    if (p.stamps && tid == 0 && q == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#pragma unroll 1
-  for (int l = 0; l < L; ++l) {
-    const int dil = 1 << (l % p.cycle);
-    const rsrc_t rs_a1 = mk_rsrc(p.apack1s + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
-    const rsrc_t rs_a2 = mk_rsrc(p.apack2s + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
-    const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
-    const float dnext = l + 1 < L ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;
-    const float bnext0 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
-    const float bnext1 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tid] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) { yg[ct][r] *= s1; yf[ct][r] *= s1; }
-    PAIR_STAMP(0);
-    // ---- GEMM1: the centre tap of the own channels first (8 k-steps); behind it the partner's half of the image and the neighbours' edges
-    {
-      const char* xb = xs + (HALO + l31) * ROWB + lh * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[2 * NCT]) {
-        const int tap = ks >> 4, kc = ks & 15;
-        const char* qp = xb + ((tap - 1) * dil) * ROWB + kc * 32;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(qp + 32 * ct * ROWB);
-          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(qp + 32 * ct * ROWB + XP);
-        }
-      };
-      auto mid = [&]() {
-        if (l == 0) return;   // layer 0 staged the whole image from HBM
-        if (wave == 0) {
-          // five flags (the partner's and the two neighbouring tiles' halves), polled by five lanes AT ONCE: one L2 round trip, not five
-          const unsigned want = p.fbase + (unsigned)l;
-          const unsigned* fl = lane == 0 ? fx + 2 * tile_id + (1 - q)
-                               : (lane <= 2 ? (has_left ? fx + 2 * (tile_id - 1) + (lane - 1) : nullptr)
-                                            : (lane <= 4 ? (has_right ? fx + 2 * (tile_id + 1) + (lane - 3) : nullptr) : nullptr));
-          wait_flags(fl, want);
-        }
-        __syncthreads();   // (D) the polling lanes have seen the flags
-        PAIR_STAMP(1);
-        half_in(xs, XP, HALO, 1 - q, ix_slot(l & 1, tile_id, 1 - q));   // the partner's channels of the core frames
-        {
-          // halo rows, both planes, both halves: rows 0..7 = the left tile's last 8 frames, rows NT+8..NT+15 = the right tile's first 8
-          u32x4 v[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int piece = k * 256 + tid;   // 2 sides x 2 parts x 2 planes x 8 frames x 16 chunks
-            const int side = piece >> 9, part = (piece >> 8) & 1, pl = (piece >> 7) & 1, f = (piece >> 4) & 7, c16 = piece & 15;
-            const bool have = side == 0 ? has_left : has_right;
-            v[k] = u32x4{0u, 0u, 0u, 0u};
-            if (have) {
-              const rsrc_t rs = mk_rsrc(ix_slot(l & 1, side == 0 ? tile_id - 1 : tile_id + 1, part), 2 * NT * PCH * 2);
-              v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + (side == 0 ? NT - 8 : 0) + f) * PCH + 8 * c16) * 2, 0, 16);   // sc1
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int piece = k * 256 + tid;
-            const int side = piece >> 9, part = (piece >> 8) & 1, pl = (piece >> 7) & 1, f = (piece >> 4) & 7, c16 = piece & 15;
-            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWB + (PCH * part + 8 * c16) * 2) = v[k];
-          }
-        }
-        __syncthreads();   // (A) the whole image is in place
-        PAIR_STAMP(2);
-      };
-      mfma_pipe_pair<8, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, [&](int i) { return kmap_pair(i, q); }, ldb, mid);
-    }
-    PAIR_STAMP(3);
-    // ---- gate -> own half of zs (hi / lo of 2^10 z) ---------------------------------------------------------------------------------
-    dtab[tid] = dnext;   // read by write_core() behind the barriers below
-    const float rs2 = inv2 * 0.70710678118654752440f;
-    const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x2 z01 = gate2_scaled(f32x2{yg[ct][4 * g], yg[ct][4 * g + 1]}, f32x2{yf[ct][4 * g], yf[ct][4 * g + 1]}, gcg, gcf, glim, ZSCALE);
-        const f32x2 z23 = gate2_scaled(f32x2{yg[ct][4 * g + 2], yg[ct][4 * g + 3]}, f32x2{yf[ct][4 * g + 2], yf[ct][4 * g + 3]}, gcg, gcf, glim, ZSCALE);
-        const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
-        char* dst = zs + (32 * ct + l31) * ROWB + (cb + 8 * g + 4 * lh) * 2;
-        *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
-        *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
-      }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float br = btab[cb + acc_row(r, lh)], bs = btab[C + cb + acc_row(r, lh)];
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        yg[ct][r] = (xr[ct][r] + br) * s2;
-        yf[ct][r] = bs * s2;
-      }
-    }
-    __syncthreads();   // (Z1) the own half of z is complete in LDS; every wave is done reading xs and this layer's biases
-    btab[tid] = bnext0;
-    btab[tid + 256] = bnext1;
-    if (!(p.inject && (tile_id & 1))) half_out(zs, ZP, 0, q, zx_slot(tile_id, q));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
-    __syncthreads();
-    // GEMM2's first weights are requested only now: in front of the drain they would delay the flag by their own latency (vmcnt counts in
-    // order), here they land while the partner's half of z is on its way
-#pragma unroll
-    for (int k = 0; k < NSP; ++k) {
-      A[k][0] = lda8(rs_a2, vfrag, sa_g + k * KSB2);
-      A[k][1] = lda8(rs_a2, vfrag, sa_g + k * KSB2 + PLB);
-      A[k][2] = lda8(rs_a2, vfrag, sa_f + k * KSB2);
-      A[k][3] = lda8(rs_a2, vfrag, sa_f + k * KSB2 + PLB);
-    }
-    if (tid == 0) {
-      __hip_atomic_store(fz + 2 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      wait_flag(fz + 2 * tile_id + (1 - q), p.fbase + (unsigned)(l + 1));
-    }
-    __syncthreads();   // the partner's half of z is published
-    PAIR_STAMP(4);
-    half_in(zs, ZP, 0, 1 - q, zx_slot(tile_id, 1 - q));
-    __syncthreads();   // (B) zs complete
-    PAIR_STAMP(5);
-    // ---- GEMM2: 16 k-steps; yg = residual rows, yf = skip rows of the own channels ----------------------------------------------------
-    {
-      const char* zb = zs + l31 * ROWB + lh * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[2 * NCT]) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(zb + 32 * ct * ROWB + ks * 32);
-          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(zb + 32 * ct * ROWB + ks * 32 + ZP);
-        }
-      };
-      mfma_pipe_pair<0, NCT>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 16, [](int i) { return i; }, ldb, [] {});
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        xr[ct][r] = yg[ct][r] * rs2;
-        sk[ct][r] += yf[ct][r] * inv2;
-      }
-    PAIR_STAMP(6);
-    if (l + 1 == L) break;
-    // ---- next layer: the own half of the image into LDS and to the exchange slot, the flag — and only then the conditioner term into the
-    // free accumulators: its HBM latency overlaps the wait for the partner's half instead of delaying the own flag (vmcnt counts in order)
-    write_core();
-    __syncthreads();   // (C1) the own half of the core rows is complete
-    if (!(p.inject && (tile_id & 1))) half_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // (C)
-    if (tid == 0) __hip_atomic_store(fx + 2 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    PAIR_STAMP(7);
-    cond_request(l + 1);
-    prefetch_a1(l + 1);   // (behind the drain, like the conditioner term)
-  }
-#undef PAIR_STAMP
-  if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);
-  // ---- the skip sum / sqrt(L) of the own channels (net.py:126), fp32 [C][T] rows: what step_tail_kernel reads ---------------------------
-  const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
-  const float rdiv = 1.0f / sqrtf((float)L);
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
-    if (col_ok[ct]) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) stf(sk[ct][r] * rdiv, rs_sk, vst[ct], (cb + acc_row0(r)) * rowT);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// QUAD form for one or two utterances (4 x B * ceil(T / 32) <= CUs; B <= 2 at T = 1000): the pair form's idea once more.  A 32-frame tile is
-// computed by FOUR workgroups of 4 waves on four CUs of one XCD, each owning a QUARTER of the channels (64): a wave owns 16 channels — 16
-// gate + 16 filter rows of GEMM1, 16 residual + 16 skip rows of GEMM2 — as 16-row matrix tiles (v_mfma_f32_16x16x32_f16: lane l holds
-// A[row l & 15][k = 8 (l >> 4) + j], B[k][column l & 15]; C/D column l & 15, rows 4 (l >> 4) + r; weights packed a second time in that
-// fragment order, pack_a_frag_q_kernel).  A CU streams a quarter of the layer's weights (0.52 MB); z and the image are all-gathered among
-// the four through L2 (8 KB per part) with the pair form's protocol; GEMM1 starts with the two 32-deep k-steps of the centre tap that
-// cover the own 64 channels.
-// ------------------------------------------------------------------------------------------------
-constexpr int QCH = C / 4;     // channels per workgroup of a quad
-constexpr int NSQ = 8;         // weight ring in k-steps of 32
 constexpr int QPLB = 32 * 1024;            // bytes per plane of a k-step slab: 32 row tiles of 16 x 1 KB
 constexpr int QKSB = 2 * QPLB;             // bytes per k-step (32 deep): hi slab, lo slab
 
@@ -1384,78 +959,142 @@ __global__ void pack_a_frag_q_kernel(const float* __restrict__ src, _Float16* __
   out[base + (long long)RT * 512] = lo;
 }
 
-// i-th executed k-step (32 deep; 8 per tap) of GEMM1 for part q
-__device__ __forceinline__ int kmap_quad(int i, int q) {
-  if (i < 2) return 8 + 2 * q + i;                     // centre tap, own 64 channels
-  if (i < 8) { const int c = i - 2; return 8 + (c < 2 * q ? c : c + 2); }   // centre tap, the partners' channels
-  if (i < 16) return i - 8;                            // tap 0
-  return i;                                            // tap 2
-}
-
+// LDS rows of the part forms: 256 fp16 + 32 B pad = 544 B.  A B fragment of v_mfma_f32_16x16x32_f16 is read as 16 bytes per lane at row
+// (lane & 15), byte 16 (lane >> 4): with the 528-byte rows of the 32-row forms the 16-lane groups of ds_read_b128 meet 2-way bank conflicts
+// (rows 4 dwords apart); with rows 8 dwords apart mod 64 every group covers the 64 banks once.
+constexpr int ROWQ = 2 * C + 32;
+constexpr int part_xp(int nc) { return (16 * nc + 2 * HALO) * ROWQ; }   // bytes per plane of the image
+constexpr int part_zp(int nc) { return 16 * nc * ROWQ; }                // bytes per plane of z
+constexpr size_t part_lds(int nc) { return (size_t)2 * part_xp(nc) + 2 * part_zp(nc) + 3 * C * sizeof(float); }
+static_assert(part_lds(4) <= 160 * 1024 && part_lds(2) > 80 * 1024, "the 64-frame forms fill the LDS; the 32-frame ones take more than half of it, so that a CU holds ONE workgroup");
 #define BSG_MFMA_Q(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0)
 using f32x4q = __attribute__((ext_vector_type(4))) float;
 
-// k-step pipeline: two row tiles of 16 (c0: gate / residual, c1: filter / skip) x two column tiles of 16 frames, 12 MFMAs per k-step
-template <int ROT, typename KM, typename LDB, typename MID>
-__device__ __forceinline__ void mfma_pipe_quad(f32x4q (&c0)[2], f32x4q (&c1)[2], f16x8 (&A)[NSQ][4], rsrc_t rs, int vfrag, int sa0, int sa1, int n_ks,
-                                               KM km, LDB ldb, MID mid) {
-  f16x8 B[2][4];
-  ldb(km(0), B[0]);
-  const int last = n_ks - 1;
+// Order of GEMM1's k-steps (32 deep; 8 per tap) for a part whose own channels start at k-step `base` of a tap: the centre tap first, cyclically
+// from the own channels (the only part of the image a workgroup has without waiting), then tap 0, then tap 2.  The i-th executed k-step is
+// kb0 + ((rot + (i & 7)) & 7) with (kb0, rot) constant over the 8 steps of a tap — a pass of the weight ring never straddles two taps, so
+// the scalar index arithmetic of a k-step is two adds and a mask (with a general map it outweighed the k-step's MFMA issue time).
+struct KPass {
+  int kb0;    // first k-step of the tap in the packed weights / the image's tap order (tap 0: 0, centre: 8, tap 2: 16)
+  int rot;    // cyclic start inside the tap
+  int boff;   // LDS byte offset of the tap's rows relative to the centre tap: (tap - 1) x dilation x ROWQ
+};
+template <bool GEMM1>
+__device__ __forceinline__ KPass k_pass(int i0, int base, int dilrow) {
+  if (!GEMM1) return KPass{i0 & ~7, 0, 0};
+  const int t = i0 >> 3;   // 0: centre tap, 1: tap 0, 2: tap 2
+  return KPass{t == 0 ? 8 : (t == 1 ? 0 : 16), t == 0 ? base : 0, t == 0 ? 0 : (t == 1 ? -dilrow : dilrow)};
+}
+__device__ __forceinline__ int k_of(const KPass& d, int i) { return d.kb0 + ((d.rot + i) & 7); }   // i: any index congruent to the step's mod 8
+
+// k-step pipeline: two row tiles of 16 (c0: gate / residual, c1: filter / skip) x NC column tiles of 16 frames, 6 NC MFMAs per k-step;
+// weight ring of NSQ k-steps (NSQ divides 8).  B fragments: 16-byte reads at bptr + tap offset + 64 x (k-step inside the tap) + 16 ct rows,
+// the lo plane `bplane` bytes behind.  The hand-off `mid` sits behind the first ROT k-steps.  The ring runs THROUGH the GEMMs: the reloads of
+// the last pass fetch the first NSQ k-steps of the GEMM that follows (`rs_next`; NEXT1: it is a GEMM1, in its order) — requested after this
+// GEMM instead, the first slot's way from L2 stood in front of every GEMM (1.2 us per layer).
+template <bool GEMM1, bool NEXT1, int ROT, int NC, int NSQ, typename MID>
+__device__ __forceinline__ void mfma_pipe_part(f32x4q (&c0)[NC], f32x4q (&c1)[NC], f16x8 (&A)[NSQ][4], rsrc_t rs, rsrc_t rs_next, int vfrag, int sa0,
+                                               int sa1, int n_ks, int base, int dilrow, const char* bptr, int bplane, MID mid) {
+  static_assert(8 % NSQ == 0, "a ring pass stays inside a tap");
+  f16x8 B[2][2 * NC];
+  auto ldb = [&](const KPass& d, int i, f16x8 (&Bf)[2 * NC]) {
+    const char* qp = bptr + d.boff + ((d.rot + i) & 7) * 64;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      Bf[2 * ct] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWQ);
+      Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWQ + bplane);
+    }
+  };
+  ldb(k_pass<GEMM1>(0, base, dilrow), 0, B[0]);
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += NSQ) {
+    const KPass dc = k_pass<GEMM1>(ks, base, dilrow);
+    const bool fin = ks + NSQ >= n_ks;   // the last pass: its reloads belong to the next GEMM
+    const KPass dn = fin ? k_pass<NEXT1>(0, base, 0) : k_pass<GEMM1>(ks + NSQ, base, dilrow);
+    const rsrc_t rsn = fin ? rs_next : rs;
+    const int o = ks & 7;
 #pragma unroll
     for (int s = 0; s < NSQ; ++s) {
-      if (ROT > 0 && s == ROT % NSQ && ks == ROT - ROT % NSQ) {   // the hand-off sits behind the first ROT k-steps
+      if (ROT > 0 && s == ROT % NSQ && ks == ROT - ROT % NSQ) {
         mid();
-        ldb(km(ks + s), B[s & 1]);
+        ldb(dc, o + s, B[s & 1]);
       }
-      const int in = ks + s + 1 <= last ? ks + s + 1 : last;
-      ldb(km(in), B[(s + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      const f16x8(&Bc)[4] = B[s & 1];
+      // One k-step.  An MFMA of this shape occupies the pipe for 16 cycles and holds the vector issue for 8 of them: everything else of the
+      // k-step (the next step's B fragments from LDS, the ring's reloads) is issued INSIDE those gaps — one LDS read behind each MFMA of the
+      // first group (lo weights x hi operand: their registers are free for the reload right behind it), one reload behind every NC / 2 MFMAs of
+      // the second; the hi weights' reload follows one k-step later, inside the next step's second group.  (With the loads outside the MFMA
+      // sequence a k-step took 300 cycles for 192 cycles of matrix work.)
+      ldb(s + 1 < NSQ ? dc : dn, o + s + 1, B[(s + 1) & 1]);
+      const f16x8(&Bc)[2 * NC] = B[s & 1];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < NC; ++ct) {
+        BSG_MFMA_Q(c0[ct], A[s][1], Bc[2 * ct]);
+        BSG_MFMA_Q(c1[ct], A[s][3], Bc[2 * ct]);
+      }
+      {
+        const int kr = k_of(dn, o + s + NSQ) * QKSB;
+        A[s][1] = lda8(rsn, vfrag, sa0 + kr + QPLB);
+        A[s][3] = lda8(rsn, vfrag, sa1 + kr + QPLB);
+        const int sp = (s + NSQ - 1) % NSQ;       // the previous k-step's slot: its hi weights (a constant in the unrolled loop)
+        const int kp = k_of(s > 0 ? dn : dc, o + s - 1 + NSQ) * QKSB;
+        A[sp][0] = lda8(s > 0 ? rsn : rs, vfrag, sa0 + kp);
+        A[sp][2] = lda8(s > 0 ? rsn : rs, vfrag, sa1 + kp);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) {
         BSG_MFMA_Q(c0[ct], A[s][0], Bc[2 * ct]);
         BSG_MFMA_Q(c1[ct], A[s][2], Bc[2 * ct]);
       }
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < NC; ++ct) {
         BSG_MFMA_Q(c0[ct], A[s][0], Bc[2 * ct + 1]);
         BSG_MFMA_Q(c1[ct], A[s][2], Bc[2 * ct + 1]);
       }
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        BSG_MFMA_Q(c0[ct], A[s][1], Bc[2 * ct]);
-        BSG_MFMA_Q(c1[ct], A[s][3], Bc[2 * ct]);
+      for (int i = 0; i < 2 * NC; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const int ir = ks + s + NSQ <= last ? ks + s + NSQ : last;
-      const int kr = km(ir);
-      A[s][0] = lda8(rs, vfrag, sa0 + kr * QKSB);
-      A[s][1] = lda8(rs, vfrag, sa0 + kr * QKSB + QPLB);
-      A[s][2] = lda8(rs, vfrag, sa1 + kr * QKSB);
-      A[s][3] = lda8(rs, vfrag, sa1 + kr * QKSB + QPLB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NC / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NC, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  {   // the last k-step's hi weights: slot NSQ - 1 of the next GEMM
+    const int kp = k_of(k_pass<NEXT1>(0, base, 0), NSQ - 1) * QKSB;
+    A[NSQ - 1][0] = lda8(rs_next, vfrag, sa0 + kp);
+    A[NSQ - 1][2] = lda8(rs_next, vfrag, sa1 + kp);
+  }
 }
 
-__global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
-  constexpr int NT = 32, XP = h2_xp(1), ZP = h2_zp(1);
-  constexpr int NPIECE = 2 * NT * (QCH / 8);   // 16-byte pieces of one exchange slot: 2 planes x 32 frames x 8 chunks of 8 channels = 512
+template <int P, int W, int NC>
+__global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p) {
+  static_assert(P * W * 16 == C && (NC == 2 || NC == 4), "a wave owns 16 channels; 32- or 64-frame tiles");
+  constexpr int NT = 16 * NC, XP = part_xp(NC), ZP = part_zp(NC);
+  constexpr int NTH = 64 * W;                  // threads
+  constexpr int TPT = NTH >= C ? 1 : C / NTH;  // table entries per thread
+  constexpr int QCH = C / P;                   // channels per workgroup
+  constexpr int CH8 = QCH / 8;                 // 16-byte chunks of 8 channels per frame of a slot
+  constexpr int NSQ = W == 8 ? 4 : 8;          // weight ring in k-steps of 32 (one wave per SIMD: 512 registers)
+  constexpr int OWN = 8 / P;                   // k-steps of a tap over the own channels
+  constexpr int NPIECE = 2 * NT * CH8;         // 16-byte pieces of one exchange slot: 2 planes x NT frames x CH8 chunks
+  static_assert(NPIECE % NTH == 0 && 1024 % NTH == 0 && (32 * (NT + 2 * HALO)) % NTH == 0, "copy loops");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  char* xs = lds_raw;                  // [2 planes][48 frames][528 B]: hi / lo of x + d_l, ALL channels
-  char* zs = lds_raw + 2 * XP;         // [2 planes][32 frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
+  char* xs = lds_raw;                  // [2 planes][NT + 16 frames][528 B]: hi / lo of x + d_l, ALL channels
+  char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation, ALL channels
   float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]
   float* btab = dtab + C;                                              // [512]
 
-  // workgroup -> (tile, part): the four parts of a tile sit on the same XCD (workgroup i runs on XCD i mod 8)
+  // workgroup -> (tile, part): the P parts of a tile sit on the same XCD (workgroup i runs on XCD i mod 8)
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int slot = (int)blockIdx.x >> 3;
-  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + (slot >> 2);
-  const int q = slot & 3;
-  if ((slot >> 2) >= per_xcd || tile_id >= n_tiles) return;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + slot / P;
+  const int q = slot % P;
+  if (slot / P >= per_xcd || tile_id >= n_tiles) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kb = lane >> 4;
@@ -1469,27 +1108,29 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
   const unsigned plane = (unsigned)C * T * 4;
   const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
   const int rowT = T * 4, vfrag = lane * 16;
-  int vcol[2], vst[2];
-  bool col_ok[2];
+  int vcol[NC], vst[NC];
+  bool col_ok[NC];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < NC; ++ct) {
     const int col = t0 + 16 * ct + l15;
     col_ok[ct] = col < T;
     vcol[ct] = (kb * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;   // accumulator rows 4 kb + r
     vst[ct] = (kb * 4 * T + col) * 4;
   }
-  const int rt_g = 4 * q + wave;                                  // gate / residual row tile (of 16); filter / skip: + 16
+  const int rt_g = W * q + wave;                                  // gate / residual row tile (of 16); filter / skip: + 16
   const int sa_g = rt_g * 1024, sa_f = (16 + rt_g) * 1024;
 
-  float xr[2][4], sk[2][4];
-  f32x4q yg[2], yf[2];
+  float xr[NC][4], sk[NC][4];
+  f32x4q yg[NC], yf[NC];
+  constexpr bool COND_LATE = W == 4;   // one wave per SIMD (512 registers): the conditioner term in registers of its own, added behind GEMM1
+  f32x4q cg[COND_LATE ? NC : 1], cf[COND_LATE ? NC : 1];
   int range_flag = 0;
   auto range_check = [&](unsigned worst) {
     if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
   };
   auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
-  unsigned* fx = p.pflags;                   // image flags [n_tiles][4]
-  unsigned* fz = p.pflags + 4 * n_tiles;     // z flags     [n_tiles][4]
+  unsigned* fx = p.pflags;                   // image flags [n_tiles][P]
+  unsigned* fz = p.pflags + P * n_tiles;     // z flags     [n_tiles][P]
   auto wait_flags = [&](const unsigned* fl, unsigned want) {   // a whole wave: every lane with a flag polls its own; bounded
     bool pend = fl != nullptr;
     if (p.inject) {
@@ -1516,9 +1157,14 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     for (int r = 0; r < 4; ++r) {
       const int so = (cb + r) * rowT;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        yg[ct][r] = ldf(rs_ct, vcol[ct], so);
-        yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
+      for (int ct = 0; ct < NC; ++ct) {
+        if constexpr (COND_LATE) {
+          cg[ct][r] = ldf(rs_ct, vcol[ct], so);
+          cf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
+        } else {
+          yg[ct][r] = ldf(rs_ct, vcol[ct], so);
+          yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
+        }
       }
     }
   };
@@ -1528,14 +1174,14 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) dv[r] = dtab[cb + 4 * kb + r];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < NC; ++ct) {
       const float v0 = xr[ct][0] + dv[0], v1 = xr[ct][1] + dv[1], v2 = xr[ct][2] + dv[2], v3 = xr[ct][3] + dv[3];
       worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
       const HiLo s0 = split2(v0, v1);
       const HiLo s1_ = split2(v2, v3);
       u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
       if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
-      char* dst = xs + (HALO + 16 * ct + l15) * ROWB + (cb + 4 * kb) * 2;
+      char* dst = xs + (HALO + 16 * ct + l15) * ROWQ + (cb + 4 * kb) * 2;
       *reinterpret_cast<u32x2*>(dst) = wh;
       *reinterpret_cast<u32x2*>(dst + XP) = wl;
     }
@@ -1545,38 +1191,38 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
   auto part_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot_p) {
     const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * QCH * 2);
 #pragma unroll
-    for (int k = 0; k < NPIECE / 256; ++k) {
-      const int piece = k * 256 + tid;
-      const int pl = piece >> 8, f = (piece >> 3) & 31, c8 = piece & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (QCH * part + 8 * c8) * 2);
+    for (int k = 0; k < NPIECE / NTH; ++k) {
+      const int piece = k * NTH + tid;
+      const int pl = piece / (NT * CH8), f = (piece / CH8) % NT, c8 = piece % CH8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWQ + (QCH * part + 8 * c8) * 2);
       __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
     }
   };
-  auto parts_in = [&](char* img, int plane_bytes, int r0, auto slot_of) {   // the three partners' quarters
-    u32x4 v[3 * NPIECE / 256];
+  auto parts_in = [&](char* img, int plane_bytes, int r0, auto slot_of) {   // the P - 1 partners' parts
+    u32x4 v[(P - 1) * NPIECE / NTH];
 #pragma unroll
-    for (int k = 0; k < 3 * NPIECE / 256; ++k) {
-      const int piece = k * 256 + tid;
-      const int o = piece >> 9, part = o < q ? o : o + 1;   // the o-th partner
-      const int pc = piece & 511, pl = pc >> 8, f = (pc >> 3) & 31, c8 = pc & 7;
+    for (int k = 0; k < (P - 1) * NPIECE / NTH; ++k) {
+      const int piece = k * NTH + tid;
+      const int o = piece / NPIECE, part = o < q ? o : o + 1;   // the o-th partner
+      const int pc = piece % NPIECE, pl = pc / (NT * CH8), f = (pc / CH8) % NT, c8 = pc % CH8;
       const rsrc_t rs = mk_rsrc(slot_of(part), 2 * NT * QCH * 2);
       v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
     }
 #pragma unroll
-    for (int k = 0; k < 3 * NPIECE / 256; ++k) {
-      const int piece = k * 256 + tid;
-      const int o = piece >> 9, part = o < q ? o : o + 1;
-      const int pc = piece & 511, pl = pc >> 8, f = (pc >> 3) & 31, c8 = pc & 7;
-      *reinterpret_cast<u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWB + (QCH * part + 8 * c8) * 2) = v[k];
+    for (int k = 0; k < (P - 1) * NPIECE / NTH; ++k) {
+      const int piece = k * NTH + tid;
+      const int o = piece / NPIECE, part = o < q ? o : o + 1;
+      const int pc = piece % NPIECE, pl = pc / (NT * CH8), f = (pc / CH8) % NT, c8 = pc % CH8;
+      *reinterpret_cast<u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWQ + (QCH * part + 8 * c8) * 2) = v[k];
     }
   };
-  const size_t slot_halfs = (size_t)2 * NT * QCH;   // fp16 elements of one exchange slot (8 KB)
-  auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * 4 + part) * slot_halfs; };
-  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * 4 + part) * slot_halfs; };
+  const size_t slot_halfs = (size_t)2 * NT * QCH;   // fp16 elements of one exchange slot
+  auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * P + part) * slot_halfs; };
+  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * P + part) * slot_halfs; };
 
   // ---- layer 0: x from HBM — this wave's channels into registers, the WHOLE image (all channels, halo frames included) into LDS ----------
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       xr[ct][r] = ldf(rs_x, vcol[ct], (cb + r) * rowT);
@@ -1587,8 +1233,8 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     unsigned worst = 0;
     constexpr int ROWS = NT + 2 * HALO;
 #pragma unroll 1
-    for (int it = 0; it < 32 * ROWS / 256; ++it) {   // 32 chunks of 8 channels x 48 frames, lanes = consecutive frames
-      const int item = it * 256 + tid;
+    for (int it = 0; it < 32 * ROWS / NTH; ++it) {   // 32 chunks of 8 channels x ROWS frames, lanes = consecutive frames
+      const int item = it * NTH + tid;
       const int hc = item / ROWS, row = item - hc * ROWS;
       const int th = t0 - HALO + row;
       const bool hok = th >= 0 && th < T;
@@ -1600,21 +1246,20 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
       const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
       u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
       if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
-      *reinterpret_cast<u32x4*>(xs + row * ROWB + hc * 16) = wh;
-      *reinterpret_cast<u32x4*>(xs + XP + row * ROWB + hc * 16) = wl;
+      *reinterpret_cast<u32x4*>(xs + row * ROWQ + hc * 16) = wh;
+      *reinterpret_cast<u32x4*>(xs + XP + row * ROWQ + hc * 16) = wl;
     }
     range_check(worst);
   }
-  dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
-  btab[tid] = p.bias_out[tid];
-  btab[tid + 256] = p.bias_out[tid + 256];
+  for (int i = tid; i < C; i += NTH) dtab[i] = p.dproj[((long long)tb * L + 0) * C + i];
+  for (int i = tid; i < 2 * C; i += NTH) btab[i] = p.bias_out[i];
   cond_request(0);
   f16x8 A[NSQ][4];
   auto prefetch_a1 = [&](int l) {
     const rsrc_t rs = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
 #pragma unroll
     for (int k = 0; k < NSQ; ++k) {
-      const int kr = kmap_quad(k, q);
+      const int kr = k_of(k_pass<true>(0, OWN * q, 0), k);
       A[k][0] = lda8(rs, vfrag, sa_g + kr * QKSB);
       A[k][1] = lda8(rs, vfrag, sa_g + kr * QKSB + QPLB);
       A[k][2] = lda8(rs, vfrag, sa_f + kr * QKSB);
@@ -1622,6 +1267,7 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     }
   };
   prefetch_a1(0);
+  if (p.clk && tile_id == 0 && q == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
   __syncthreads();   // the staged image and the tables
 
 #define QUAD_STAMP(i)                                                                                                      \
@@ -1633,46 +1279,49 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     const int dil = 1 << (l % p.cycle);
     const rsrc_t rs_a1 = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
     const rsrc_t rs_a2 = mk_rsrc(p.apack2q + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
+    const rsrc_t rs_a1n = mk_rsrc(p.apack1q + (long long)(l + 1 < L ? l + 1 : 0) * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);   // the next layer's GEMM1
     const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
-    const float dnext = l + 1 < L ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;
-    const float bnext0 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
-    const float bnext1 = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tid] : 0.f;
+    float dnext[TPT], bnext0[TPT], bnext1[TPT];   // the next layer's tables: entries tid + k NTH (W = 8: threads 256.. repeat the first half's)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) { yg[ct] *= s1; yf[ct] *= s1; }
+    for (int k = 0; k < TPT; ++k) {
+      const int tc = (tid + k * NTH) & (C - 1);
+      dnext[k] = l + 1 < L ? p.dproj[((long long)tb * L + l + 1) * C + tc] : 0.f;
+      bnext0[k] = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tc] : 0.f;
+      bnext1[k] = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tc] : 0.f;
+    }
+    // GEMM1 accumulates from zero; the conditioner term — requested behind the hand-off inside GEMM1, so that its way from HBM is covered by
+    // the outer taps instead of standing in front of the layer (vmcnt counts in order: requested in front of the weight ring it would be
+    // waited for with the ring's first slot) — is added behind it
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      if constexpr (COND_LATE) { yg[ct] = f32x4q{0.f, 0.f, 0.f, 0.f}; yf[ct] = f32x4q{0.f, 0.f, 0.f, 0.f}; }
+      else { yg[ct] *= s1; yf[ct] *= s1; }   // (two waves per SIMD: no registers to spare — the term was requested behind the image flag)
+    }
     QUAD_STAMP(0);
-    // ---- GEMM1: 24 k-steps of 32; the two of the centre tap over the own channels first, behind them the partners' quarters + the halo ----
+    // ---- GEMM1: 24 k-steps of 32; those of the centre tap over the own channels first, behind them the partners' parts + the halo ----
     {
-      const char* xb = xs + (HALO + l15) * ROWB + kb * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
-        const int tap = ks >> 3, kc = ks & 7;
-        const char* qp = xb + ((tap - 1) * dil) * ROWB + kc * 64;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWB);
-          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWB + XP);
-        }
-      };
+      const char* xb = xs + (HALO + l15) * ROWQ + kb * 16;
       auto mid = [&]() {
         if (l == 0) return;   // layer 0 staged the whole image from HBM
         if (wave == 0) {
-          // eleven flags (three partners, the four parts of each neighbouring tile), polled by eleven lanes at once
+          // 3 P - 1 flags (the partners, the P parts of each neighbouring tile), polled by as many lanes at once
           const unsigned want = p.fbase + (unsigned)l;
           const unsigned* fl = nullptr;
-          if (lane < 3) fl = fx + 4 * tile_id + (lane < q ? lane : lane + 1);
-          else if (lane < 7) fl = has_left ? fx + 4 * (tile_id - 1) + (lane - 3) : nullptr;
-          else if (lane < 11) fl = has_right ? fx + 4 * (tile_id + 1) + (lane - 7) : nullptr;
+          if (lane < P - 1) fl = fx + P * tile_id + (lane < q ? lane : lane + 1);
+          else if (lane < 2 * P - 1) fl = has_left ? fx + P * (tile_id - 1) + (lane - (P - 1)) : nullptr;
+          else if (lane < 3 * P - 1) fl = has_right ? fx + P * (tile_id + 1) + (lane - (2 * P - 1)) : nullptr;
           wait_flags(fl, want);
         }
         __syncthreads();   // (D) the polling lanes have seen the flags
         QUAD_STAMP(1);
         parts_in(xs, XP, HALO, [&](int part) { return ix_slot(l & 1, tile_id, part); });   // the partners' channels of the core frames
         {
-          // halo rows, both planes, all four parts: rows 0..7 = the left tile's last 8 frames, rows 40..47 = the right tile's first 8
-          u32x4 v[4];
+          // halo rows, both planes, all P parts: rows 0..7 = the left tile's last 8 frames, rows NT+8..NT+15 = the right tile's first 8
+          u32x4 v[1024 / NTH];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int piece = k * 256 + tid;   // 2 sides x 4 parts x 2 planes x 8 frames x 8 chunks
-            const int side = piece >> 9, part = (piece >> 7) & 3, pl = (piece >> 6) & 1, f = (piece >> 3) & 7, c8 = piece & 7;
+          for (int k = 0; k < 1024 / NTH; ++k) {
+            const int piece = k * NTH + tid;   // 2 sides x P parts x 2 planes x 8 frames x CH8 chunks = 1024
+            const int side = piece >> 9, part = (piece & 511) / (16 * CH8), pl = (piece / (8 * CH8)) & 1, f = (piece / CH8) & 7, c8 = piece % CH8;
             const bool have = side == 0 ? has_left : has_right;
             v[k] = u32x4{0u, 0u, 0u, 0u};
             if (have) {
@@ -1681,28 +1330,40 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
             }
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int piece = k * 256 + tid;
-            const int side = piece >> 9, part = (piece >> 7) & 3, pl = (piece >> 6) & 1, f = (piece >> 3) & 7, c8 = piece & 7;
-            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWB + (QCH * part + 8 * c8) * 2) = v[k];
+          for (int k = 0; k < 1024 / NTH; ++k) {
+            const int piece = k * NTH + tid;
+            const int side = piece >> 9, part = (piece & 511) / (16 * CH8), pl = (piece / (8 * CH8)) & 1, f = (piece / CH8) & 7, c8 = piece % CH8;
+            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWQ + (QCH * part + 8 * c8) * 2) = v[k];
           }
         }
         __syncthreads();   // (A) the whole image is in place
         QUAD_STAMP(2);
+        if constexpr (COND_LATE) cond_request(l);
       };
-      mfma_pipe_quad<2>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 24, [&](int i) { return kmap_quad(i, q); }, ldb, mid);
+      mfma_pipe_part<true, false, OWN, NC, NSQ>(yg, yf, A, rs_a1, rs_a2, vfrag, sa_g, sa_f, 24, OWN * q, dil * ROWQ, xb, XP, mid);
+    }
+    if constexpr (COND_LATE) {
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          yg[ct][r] = fmaf(cg[ct][r], s1, yg[ct][r]);
+          yf[ct][r] = fmaf(cf[ct][r], s1, yf[ct][r]);
+        }
     }
     QUAD_STAMP(3);
     // ---- gate -> own quarter of zs (hi / lo of 2^10 z) ----------------------------------------------------------------------------------
-    dtab[tid] = dnext;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k)
+      if (tid + k * NTH < C) dtab[tid + k * NTH] = dnext[k];
     const float rs2 = inv2 * 0.70710678118654752440f;
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < NC; ++ct) {
       const f32x2 z01 = gate2_scaled(f32x2{yg[ct][0], yg[ct][1]}, f32x2{yf[ct][0], yf[ct][1]}, gcg, gcf, glim, ZSCALE);
       const f32x2 z23 = gate2_scaled(f32x2{yg[ct][2], yg[ct][3]}, f32x2{yf[ct][2], yf[ct][3]}, gcg, gcf, glim, ZSCALE);
       const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
-      char* dst = zs + (16 * ct + l15) * ROWB + (cb + 4 * kb) * 2;
+      char* dst = zs + (16 * ct + l15) * ROWQ + (cb + 4 * kb) * 2;
       *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
       *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
     }
@@ -1710,26 +1371,23 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     for (int r = 0; r < 4; ++r) {
       const float br = btab[cb + 4 * kb + r], bs = btab[C + cb + 4 * kb + r];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < NC; ++ct) {
         yg[ct][r] = (xr[ct][r] + br) * s2;
         yf[ct][r] = bs * s2;
       }
     }
     __syncthreads();   // (Z1) the own quarter of z is complete in LDS; every wave is done reading xs and this layer's biases
-    btab[tid] = bnext0;
-    btab[tid + 256] = bnext1;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k)
+      if (tid + k * NTH < C) {
+        btab[tid + k * NTH] = bnext0[k];
+        btab[tid + k * NTH + 256] = bnext1[k];
+      }
     if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NSQ; ++k) {   // GEMM2's weights (all 8 k-steps), requested behind the drain
-      A[k][0] = lda8(rs_a2, vfrag, sa_g + k * QKSB);
-      A[k][1] = lda8(rs_a2, vfrag, sa_g + k * QKSB + QPLB);
-      A[k][2] = lda8(rs_a2, vfrag, sa_f + k * QKSB);
-      A[k][3] = lda8(rs_a2, vfrag, sa_f + k * QKSB + QPLB);
-    }
-    if (tid == 0) __hip_atomic_store(fz + 4 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave == 0) wait_flags(lane < 3 ? fz + 4 * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
+    if (tid == 0) __hip_atomic_store(fz + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
     __syncthreads();   // the partners' quarters of z are published
     QUAD_STAMP(4);
     parts_in(zs, ZP, 0, [&](int part) { return zx_slot(tile_id, part); });
@@ -1737,18 +1395,11 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     QUAD_STAMP(5);
     // ---- GEMM2: 8 k-steps of 32; yg = residual rows, yf = skip rows of the own channels ---------------------------------------------------
     {
-      const char* zb = zs + l15 * ROWB + kb * 16;
-      auto ldb = [&](int ks, f16x8 (&Bf)[4]) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          Bf[2 * ct] = *reinterpret_cast<const f16x8*>(zb + 16 * ct * ROWB + ks * 64);
-          Bf[2 * ct + 1] = *reinterpret_cast<const f16x8*>(zb + 16 * ct * ROWB + ks * 64 + ZP);
-        }
-      };
-      mfma_pipe_quad<0>(yg, yf, A, rs_a2, vfrag, sa_g, sa_f, 8, [](int i) { return i; }, ldb, [] {});
+      const char* zb = zs + l15 * ROWQ + kb * 16;
+      mfma_pipe_part<false, true, 0, NC, NSQ>(yg, yf, A, rs_a2, rs_a1n, vfrag, sa_g, sa_f, 8, OWN * q, 0, zb, ZP, [] {});
     }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         xr[ct][r] = yg[ct][r] * rs2;
@@ -1762,18 +1413,18 @@ __global__ __launch_bounds__(256, 1) void residual_quad_h2_kernel(StackArgs p) {
     if (!(p.inject && (tile_id & 1))) part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // (C)
-    if (tid == 0) __hip_atomic_store(fx + 4 * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(fx + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     QUAD_STAMP(7);
-    cond_request(l + 1);
-    prefetch_a1(l + 1);
+    if constexpr (!COND_LATE) cond_request(l + 1);
   }
 #undef QUAD_STAMP
+  if (p.clk && tile_id == 0 && q == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);
   // ---- the skip sum / sqrt(L) of the own channels (net.py:126), fp32 [C][T] rows: what step_tail_kernel reads ---------------------------
   const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
   const float rdiv = 1.0f / sqrtf((float)L);
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < NC; ++ct)
     if (col_ok[ct]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) stf(sk[ct][r] * rdiv, rs_sk, vst[ct], (cb + r) * rowT);
@@ -1817,27 +1468,7 @@ int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream
   return nct == 1 ? h2_launch<1>(p, tail, st) : h2_launch<2>(p, tail, st);
 }
 
-// LDS of the pair form: the image and z of the whole tile (both channel halves), and more than half of the CU's LDS so that a CU holds one workgroup
-constexpr size_t pair_lds(int nct) { return h2_lds(nct) > 84 * 1024 ? h2_lds(nct) : 84 * 1024; }
-template <int NCT>
-static int pair_occ() {
-  int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_pair_h2_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds(NCT)) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_pair_h2_kernel<NCT>, 256, pair_lds(NCT)) != hipSuccess)
-    return 0;
-  return o;
-}
-int pair_h2_occupancy(int nct) { return nct == 1 ? pair_occ<1>() : 0; }   // (pairs of 64-frame tiles: measured slower, not instantiated)
-int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct) {
-  BSG_REQUIRE(p.zx && p.ix && p.pflags, "pair launch: exchange buffers missing");
-  const dim3 grid(16 * cdiv(p.n_tiles, 8)), block(256);
-  BSG_REQUIRE(nct == 1, "pair launch: 32-frame tiles only");
-  hipLaunchKernelGGL(residual_pair_h2_kernel<1>, grid, block, pair_lds(1), st, p);
-  BSG_LAUNCH_CHECK();
-  return BSG_OK;
-}
-
-// the step tail behind a pair / quad launch: one workgroup per 32-frame tile (a.tiles_per_row = ceil(T / 32)); a.status: the launch's status words
+// the step tail behind a part launch: one workgroup per 32-frame tile (a.tiles_per_row = ceil(T / 32)); a.status: the launch's status words
 int launch_step_tail_h2(const TailArgs& a, hipStream_t st) {
   static bool attr = false;
   const size_t lds = (size_t)2 * h2_xp(1) + 2 * h2_zp(1) + 96 * 32 * sizeof(float);
@@ -1850,17 +1481,31 @@ int launch_step_tail_h2(const TailArgs& a, hipStream_t st) {
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
-int quad_h2_occupancy() {
+
+template <int P, int W, int NC>
+static int part_occ() {
   int o = 0;
-  if (hipFuncSetAttribute((const void*)residual_quad_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds(1)) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_quad_h2_kernel, 256, pair_lds(1)) != hipSuccess)
+  const size_t lds = part_lds(NC);
+  if (hipFuncSetAttribute((const void*)residual_part_h2_kernel<P, W, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_part_h2_kernel<P, W, NC>, 64 * W, lds) != hipSuccess)
     return 0;
   return o;
 }
-// quad form: FOUR workgroups of 4 waves per 32-frame tile; grid = 32 * ceil(n_tiles / 8) workgroups, all resident (one per CU)
-int launch_residual_quad_h2(const StackArgs& p, hipStream_t st) {
-  BSG_REQUIRE(p.zx && p.ix && p.pflags && p.apack1q && p.apack2q, "quad launch: exchange buffers / 16-row weight fragments missing");
-  hipLaunchKernelGGL(residual_quad_h2_kernel, dim3(32 * cdiv(p.n_tiles, 8)), dim3(256), pair_lds(1), st, p);
+// resident workgroups per CU of the part form (parts per tile, tile width in units of 32 frames): (4, 1) quad of 32 frames, (4, 2) quad of 64
+int part_h2_occupancy(int parts, int nct) {
+  if (parts == 4 && nct == 1) return part_occ<4, 4, 2>();
+  if (parts == 4 && nct == 2) return part_occ<4, 4, 4>();
+  if (parts == 2 && nct == 2) return part_occ<2, 8, 4>();
+  return 0;
+}
+// part forms: `parts` workgroups per tile of 32 nct frames; grid = 8 parts ceil(n_tiles / 8) workgroups, all resident (one per CU)
+int launch_residual_part_h2(const StackArgs& p, hipStream_t st, int parts, int nct) {
+  BSG_REQUIRE(p.zx && p.ix && p.pflags && p.apack1q && p.apack2q, "part launch: exchange buffers / 16-row weight fragments missing");
+  const dim3 grid(8 * parts * cdiv(p.n_tiles, 8));
+  if (parts == 4 && nct == 1) hipLaunchKernelGGL((residual_part_h2_kernel<4, 4, 2>), grid, dim3(256), part_lds(2), st, p);
+  else if (parts == 4 && nct == 2) hipLaunchKernelGGL((residual_part_h2_kernel<4, 4, 4>), grid, dim3(256), part_lds(4), st, p);
+  else if (parts == 2 && nct == 2) hipLaunchKernelGGL((residual_part_h2_kernel<2, 8, 4>), grid, dim3(512), part_lds(4), st, p);
+  else BSG_REQUIRE(false, "part launch: no form for %d parts of %d-frame tiles", parts, 32 * nct);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }

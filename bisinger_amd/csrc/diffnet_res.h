@@ -60,10 +60,10 @@ struct StackArgs {
   int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
   unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
   int inject;             // fault injection: consumers do not wait
-  // pair form of the split-fp16 launch (residual_pair_h2_kernel, small batches): exchange of the two channel halves of a 32-frame tile
-  unsigned short* zx;     // [n_tiles][2 parts][2 planes][tile frames][C/2] fp16: gated activation halves
-  unsigned short* ix;     // [2 parities][n_tiles][2 parts][2 planes][tile frames][C/2] fp16: image halves (core frames; neighbours read the edges)
-  unsigned* pflags;       // [2][n_tiles][2 parts]: [0] image flags (layers prepared), [1] z flags
+  // part forms of the split-fp16 launch (residual_part_h2_kernel, small batches): exchange of the P channel parts of a tile
+  unsigned short* zx;     // [n_tiles][P parts][2 planes][tile frames][C/P] fp16: gated activation parts
+  unsigned short* ix;     // [2 parities][n_tiles][P parts][2 planes][tile frames][C/P] fp16: image parts (core frames; neighbours read the edges)
+  unsigned* pflags;       // [2][n_tiles][P parts]: [0] image flags (layers prepared), [1] z flags
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
   unsigned long long* clk;      // null, or [4]: tile 0 stores s_memtime / s_memrealtime at its start and end (sustained shader clock, bench.py)
 };
@@ -75,13 +75,10 @@ int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf
 // fp32 stack launch on the 16-bit matrix pipe: operands split exactly into hi + lo fp16 terms (diffnet_h2.hip); 64-frame tiles, one
 // workgroup per CU; grid = p.n_tiles rounded up to 8
 int stack_h2_occupancy(int nct);   // nct = column tiles of 32 frames per workgroup (1 or 2)
-// pair form: TWO workgroups of 4 waves (on two CUs of one XCD) per 32-frame tile, each one half of the channels; p.n_tiles tiles -> grid of
-// 16 * ceil(n_tiles / 8) workgroups, all of which must be resident (one per CU).  No fused tail: the skip sum goes to p.skip
-int launch_residual_pair_h2(const StackArgs& p, hipStream_t st, int nct);   // nct: 32- or 64-frame tiles (p.n_tiles / p.tiles_per_row count those)
-int pair_h2_occupancy(int nct);
-// quad form: FOUR workgroups per 32-frame tile, each a quarter of the channels (B <= 2 at T = 1000); p.zx / p.ix slots are [tile][4 parts]
-int launch_residual_quad_h2(const StackArgs& p, hipStream_t st);
-int quad_h2_occupancy();
+// part forms on 16-row matrix tiles: `parts` workgroups (on as many CUs of one XCD) per tile of 32 nct frames, each C / parts channels:
+// (4, 1) quad of a 32-frame tile, (4, 2) quad of a 64-frame tile; p.n_tiles tiles -> grid of 8 parts ceil(n_tiles / 8) workgroups, all resident
+int launch_residual_part_h2(const StackArgs& p, hipStream_t st, int parts, int nct);
+int part_h2_occupancy(int parts, int nct);
 int pack_a_frag_q(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,
                   int is_gemm2, hipStream_t st);
 int h2_scales(const float* const* w1, const float* const* w2, int L, unsigned* maxbits, float* tab, hipStream_t st);

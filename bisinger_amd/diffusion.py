@@ -194,10 +194,11 @@ class GaussianDiffusion(nn.Module):
         """Extensions over the reference signature: ``noise`` (supplied draws, parity mode), ``seed`` (Philox
         key, default hparams['seed']) and ``rows`` (slice of the batch this process generates; outputs then
         have len(rows) rows and reproduce the same rows of the unsharded call — SURVEY.md §8e).
-        How closely: the launch form of the sampler is chosen by the LOCAL batch size (pair form for B*ceil(T/32) <= CUs/2, 32-frame
-        tiles up to one launch group, 64-frame tiles beyond).  The 32- and 64-frame forms sum in the same order (sharded rows were
-        bit-identical to the unsharded run at every shape tested, e.g. 8 of 64 rows at T=1000); the pair form orders GEMM1's k-steps
-        differently (1e-6 on the mel).  ``BSG_H2_PAIR=0`` makes the arithmetic of a row independent of the batch around it."""
+        How closely: the launch form of the sampler is chosen by the LOCAL batch size (part forms — four workgroups per tile — while
+        4 * B * ceil(T/64) <= CUs, 32-frame tiles up to one launch group, 64-frame tiles beyond).  The 32- and 64-frame forms sum in the
+        same order (sharded rows were bit-identical to the unsharded run at every shape tested, e.g. 8 of 64 rows at T=1000); the part
+        forms order GEMM1's k-steps differently and add the conditioner term last (1e-6 on the mel).  ``BSG_H2_PART=0`` makes the
+        arithmetic of a row independent of the batch around it."""
         if not infer:
             raise NotImplementedError('training (p_losses) is outside the accelerated hot path (SURVEY.md §8)')
         # one range guard around the whole call (FS2, the conditioner projections, the sampler): an operand beyond the fp16 range of the

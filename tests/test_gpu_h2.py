@@ -53,9 +53,8 @@ print(json.dumps({'path': net.last_path(), 'timeouts': net.handoff_timeouts()}))
 '''
 
 FORMS = {
-    'split_fp16': ({'BSG_H2': '2'}, 'stack_h2'),                                  # at these sizes: the quad / pair form (four / two workgroups per tile)
-    'split_fp16_pair': ({'BSG_H2': '2', 'BSG_H2_QUAD': '0'}, 'stack_h2_pair'),    # two workgroups per tile
-    'split_fp16_1wg': ({'BSG_H2': '2', 'BSG_H2_PAIR': '0'}, 'stack_h2'),          # one workgroup per tile
+    'split_fp16': ({'BSG_H2': '2'}, 'stack_h2'),                                  # at these sizes: a part form (four workgroups per tile)
+    'split_fp16_1wg': ({'BSG_H2': '2', 'BSG_H2_PART': '0'}, 'stack_h2'),          # one workgroup per tile
     'fp32_direct': ({'BSG_H2': '0', 'BSG_WINO': '0', 'BSG_SPLIT': '0'}, 'layer'),
     'fp32_wino23': ({'BSG_H2': '0', 'BSG_WINO': '1', 'BSG_SPLIT': '0'}, 'layer'),
     'fp32_wino43': ({'BSG_H2': '0', 'BSG_WINO': '2', 'BSG_STACK43': '2'}, 'stack_f43'),
@@ -88,15 +87,16 @@ def test_split_fp16_is_fp32_grade(B, T, wscale, stress, tmp_path):
         ref32 = odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.').double().numpy()
     err = {'cpu_fp32': (float(np.abs(ref32 - ref64).max()), float(np.sqrt(((ref32 - ref64) ** 2).mean())))}
     code = CHILD % (ROOT, B, T, wscale, stress)
-    forms = FORMS if not stress else {k: FORMS[k] for k in ('split_fp16', 'split_fp16_pair', 'split_fp16_1wg', 'fp32_direct', 'fp32_wino23')}
+    forms = FORMS if not stress else {k: FORMS[k] for k in ('split_fp16', 'split_fp16_1wg', 'fp32_direct', 'fp32_wino23')}
     for name, (env, path) in forms.items():
         f = str(tmp_path / f'{name}.npy')
         out = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         info = json.loads(out.stdout.strip().splitlines()[-1])
-        if name == 'split_fp16':     # quads while four workgroups per 32-frame tile fit the chip (256 CUs), else pairs
-            t32 = B * -(-T // 32)
-            path += '_quad' if 4 * 8 * -(-t32 // 8) <= 256 else '_pair'
+        if name == 'split_fp16':     # quads of 32-frame tiles while four workgroups per tile fit the chip (256 CUs), else of 64-frame tiles
+            t32, t64 = B * -(-T // 32), B * -(-T // 64)
+            assert 4 * 8 * -(-t64 // 8) <= 256
+            path += '_quad' if 4 * 8 * -(-t32 // 8) <= 256 else '_quad64'
         assert info['path'] == path, (name, info)
         assert info['timeouts'] == 0
         e = np.load(f).astype(np.float64) - ref64
@@ -109,8 +109,7 @@ def test_split_fp16_is_fp32_grade(B, T, wscale, stress, tmp_path):
     assert err['split_fp16'][0] <= max(2e-5 * max(1.0, rms_eps), max(e[0] for e in fp32_forms) if stress else 0.0)
     assert err['split_fp16'][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9
     assert err['split_fp16'][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9
-    for k in ('split_fp16_1wg', 'split_fp16_pair'):
-        assert err[k][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9 and err[k][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9, k
+    assert err['split_fp16_1wg'][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9 and err['split_fp16_1wg'][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9
 
 
 GEMM_CHILD = r'''

@@ -150,23 +150,21 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     (32, 997, F23, H2, 'stack_h2', 1e-5),
     (8, 1000, F23, H2, 'stack_h2', 1e-5),                                # 32-frame tiles (the 64-frame ones would fill half of the CUs)
     (16, 1000, F23, dict(H2, BSG_H2_NCT='1'), 'stack_h2', 1e-5),         # forced 32-frame tiles: two launch groups of 8 rows
-    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_PAIR='0'), 'stack_h2', 1e-5),   # forced for a few tiles (32-frame), partial tile
-    (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_PAIR='0'), 'stack_h2', 1e-5),
-    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_PAIR='0'), 'stack_h2', 1e-5),   # T < one tile
-    # the PAIR form of the split-fp16 launch (two workgroups on two CUs per 32-frame tile, each half of the channels; the default while the
-    # 32-frame tiles fill at most half of the CUs): the same sums with GEMM1's k-steps in another order
-    (1, 1000, F23, dict(H2, BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),    # a single utterance: 32 tiles, 64 workgroups
-    (4, 1000, F23, H2, 'stack_h2_pair', 1e-5),                           # 128 tiles: every CU holds one half of a tile
-    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),   # partial tile, rows of 3 tiles
-    (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),
-    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_pair', 1e-5),   # T < one tile: no neighbours at all
-    # the QUAD form (four workgroups on four CUs per 32-frame tile, each a quarter of the channels, 16-row matrix tiles; the default while
-    # the 32-frame tiles fill at most a quarter of the CUs)
+    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2', 1e-5),   # forced for a few tiles (32-frame), partial tile
+    (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2', 1e-5),   # T < one tile
+    # the PART forms of the split-fp16 launch (four workgroups on four CUs per tile, each a quarter of the channels, 16-row matrix tiles; the
+    # default while four workgroups per tile fit the chip): the same sums with GEMM1's k-steps in another order.  Quads of 32-frame tiles:
     (1, 1000, F23, H2, 'stack_h2_quad', 1e-5),                           # a single utterance: 32 tiles, 128 workgroups
     (2, 1000, F23, H2, 'stack_h2_quad', 1e-5),                           # 64 tiles: every CU holds a quarter of a tile
     (3, 77, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),           # partial tile, rows of 3 tiles
     (5, 333, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),
     (2, 31, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),           # T < one tile: no neighbours at all
+    # quads of 64-frame tiles (B = 3, 4 at T = 1000)
+    (4, 1000, F23, H2, 'stack_h2_quad64', 1e-5),                         # 64 tiles: every CU holds a quarter of a tile
+    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),   # partial tiles, rows of 2 tiles
+    (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),   # T < one tile
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),   # the same with 64-frame tiles
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),
 ])

@@ -29,10 +29,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 F43 = net.last_path() == 'stack_f43'
 H2 = net.last_path() == 'stack_h2'   # split-fp16 form: same stamp slots as the bf16 stack launch
-PAIR = net.last_path() in ('stack_h2_pair', 'stack_h2_quad')   # two workgroups per 32-frame tile (stamps of part 0)
+PAIR = net.last_path() in ('stack_h2_quad', 'stack_h2_quad64')   # part forms: four workgroups per tile (stamps of part 0)
 NTILE = 64 if DT == 'bf16' or F43 or H2 else 32
 if PAIR:
-    NTILE = 32
+    NTILE = 64 if net.last_path().endswith('64') else 32
 if H2:   # the split-fp16 launch picks 32-frame tiles when the 64-frame ones would fill at most half of the CUs (stack_rows, diffnet.hip)
     nct = int(os.environ.get('BSG_H2_NCT', '0')) or (2 if B * ((T + 63) // 64) * 2 > 256 else 1)
     NTILE = 32 * nct
@@ -53,9 +53,9 @@ if F43:   # 0 start, 1 GEMM1 done (wave 0), 2 barrier B passed, 3 residual rows 
     names = ['GEMM1, wave 0 (0->1)', 'gate + x recovery + barrier B (1->2)', 'GEMM2 residual rows (2->3)', 'image + barrier + publish + drain + flag (3->4)',
              'GEMM2 skip rows + skip RMW (4->5)', 'd tables + flag wait + barrier D (5->6)', 'halo copy (6->7)', 'barrier A (7->0 next)']
 if PAIR:   # 0 conditioner term arrived (loop top), 1 flags seen, 2 image complete, 3 GEMM1 done, 4 partner's z published, 5 z complete, 6 GEMM2 + x update, 7 image flag stored
-    names = ['own centre tap + wait for the image flags (0->1)', "partner's half + halo copy (1->2)", 'rest of GEMM1 (2->3)',
-             "gate + z out + wait for the partner's z (3->4)", 'z in + barrier (4->5)', 'GEMM2 + x/skip update (5->6)',
-             'image + out + drain + flag (6->7)', 'conditioner request + its arrival (7->0 next)']
+    names = ['own centre tap + wait for the image flags (0->1)', "partners' parts + halo copy (1->2)", 'rest of GEMM1 + conditioner term (2->3)',
+             "gate + z out + wait for the partners' z (3->4)", 'z in + barrier (4->5)', 'GEMM2 + x/skip update (5->6)',
+             'image + out + drain + flag (6->7)', 'loop top (7->0 next)']
 if F43 or H2:
     raw = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64)
     cyc = raw[:, L - 1, 7] - raw[:, L - 1, 6]
