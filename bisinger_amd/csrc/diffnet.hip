@@ -1076,8 +1076,8 @@ struct bsg_diffnet {
   bool h2_off = false;                 // bsg_diffnet_set_h2(h, 0): this handle multiplies on the fp32 matrix pipe only
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
   int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
-  int stack_parts = 0;                 // ... a part form (diffnet_h2.hip residual_part_h2_kernel): workgroups per tile (4), else 0
-  int occ_part[3] = {-1, -1, -1};      // resident workgroups per CU of the quad form by tile width in units of 32 frames (-1: not queried)
+  int stack_parts = 0;                 // ... a part form (diffnet_h2.hip residual_part_h2_kernel): workgroups per tile (4 / 2), else 0
+  int occ_part[3] = {-1, -1, -1};      // resident workgroups per CU: [1] / [2] quad of 32- / 64-frame tiles, [0] pair of 64-frame tiles (-1: not queried)
   unsigned short *apack1q = nullptr, *apack2q = nullptr;   // the split-fp16 weights once more as 16-row fragments (part forms)
   unsigned short* part_zx = nullptr;   // part forms: exchange slots of the z parts [tiles][P][2 planes][tile frames][C/P] fp16
   unsigned short* part_ix = nullptr;   //             ... of the image parts [2 parities][tiles][P][2 planes][tile frames][C/P]
@@ -1572,11 +1572,12 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       if (env_nct == 1 || env_nct == 2) nct = env_nct;
       h->stack_parts = 0;
       {
-        // part forms (residual_part_h2_kernel): FOUR workgroups on four CUs of an XCD share a tile, each a quarter of the channels and of the
-        // weight stream; the whole batch in one launch.  Quads of 32-frame tiles while B * ceil(T / 32) <= CUs / 4 (one or two utterances at
-        // T = 1000), quads of 64-frame tiles while B * ceil(T / 64) <= CUs / 4 (B <= 4).  ms per 100-step pass at T = 1000, one workgroup per
-        // tile / part form: B=1 54.5 / 25.7, B=2 52.6 / 28.4, B=3 52.0 / 34.6, B=4 51.5 / 37.9.  BSG_H2_PART=0: none (BSG_H2_QUAD=0 /
-        // BSG_H2_QUAD64=0: not that width)
+        // part forms (residual_part_h2_kernel): several workgroups on as many CUs of an XCD share a tile, each a part of the channels and of
+        // the weight stream; the whole batch in one launch.  Quads of 32-frame tiles while B * ceil(T / 32) <= CUs / 4 (one or two utterances
+        // at T = 1000), quads of 64-frame tiles while B * ceil(T / 64) <= CUs / 4 (B <= 4), pairs of 64-frame tiles (8 waves each) while
+        // B * ceil(T / 64) <= CUs / 2 (B <= 8).  ms per 100-step pass at T = 1000, one workgroup per tile / part form: B=1 54.5 / 25.7,
+        // B=2 52.6 / 28.4, B=3 52.0 / 34.6, B=4 51.5 / 37.9, B=5 54.8 / 52.6, B=6 57.1 / 55.0, B=8 69.1 / 65.2.  BSG_H2_PART=0: none
+        // (BSG_H2_QUAD=0 / BSG_H2_QUAD64=0 / BSG_H2_PAIR64=0: not that form)
         static int env_part = -1, env_quad = -1, env_quad64 = -1;
         if (env_part < 0) { const char* e = getenv("BSG_H2_PART"); env_part = e ? atoi(e) : 1; }
         if (env_quad < 0) { const char* e = getenv("BSG_H2_QUAD"); env_quad = e ? atoi(e) : 1; }
@@ -1594,7 +1595,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
           if (env_quad && 4 * 8 * cdiv(t32, 8) <= h->num_cus && take_quad(1)) return B;
           if (env_quad64 && 4 * 8 * cdiv(t64, 8) <= h->num_cus && take_quad(2)) return B;
           static int env_pair64 = -1;
-          if (env_pair64 < 0) { const char* e = getenv("BSG_H2_PAIR64"); env_pair64 = e ? atoi(e) : 0; }
+          if (env_pair64 < 0) { const char* e = getenv("BSG_H2_PAIR64"); env_pair64 = e ? atoi(e) : 1; }
           if (env_pair64 && 2 * 8 * cdiv(t64, 8) <= h->num_cus) {
             if (h->occ_part[0] < 0) h->occ_part[0] = part_h2_occupancy(2, 2) >= 1 ? 1 : 0;
             if (h->occ_part[0] >= 1) {

@@ -76,7 +76,7 @@ int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf
 // workgroup per CU; grid = p.n_tiles rounded up to 8
 int stack_h2_occupancy(int nct);   // nct = column tiles of 32 frames per workgroup (1 or 2)
 // part forms on 16-row matrix tiles: `parts` workgroups (on as many CUs of one XCD) per tile of 32 nct frames, each C / parts channels:
-// (4, 1) quad of a 32-frame tile, (4, 2) quad of a 64-frame tile; p.n_tiles tiles -> grid of 8 parts ceil(n_tiles / 8) workgroups, all resident
+// (4, 1) quad of a 32-frame tile, (4, 2) quad of a 64-frame tile, (2, 2) pair of a 64-frame tile (8 waves); p.n_tiles tiles -> grid of 8 parts ceil(n_tiles / 8) workgroups, all resident
 int launch_residual_part_h2(const StackArgs& p, hipStream_t st, int parts, int nct);
 int part_h2_occupancy(int parts, int nct);
 int pack_a_frag_q(const float* src, unsigned short* out, int M, int K, int Kc, long long sm, long long sc, long long stp, const float* tab,

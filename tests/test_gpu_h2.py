@@ -209,7 +209,7 @@ print(json.dumps(out))
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
     print(out)
-    assert out['small_path'] == 'stack_h2' and out['small_warn'] == 0            # the shape does run the split-fp16 launch, quietly
+    assert out['small_path'].startswith('stack_h2') and out['small_warn'] == 0   # the shape does run a split-fp16 launch, quietly
     assert out['finite'] and not out['ref_path'].startswith('stack')
     assert out['warn_stack'] if mode == 'stack' else (out['warn_gemm'] and out['retries'] >= 1)
     assert out['dev'] <= 1e-5 * max(1.0, out['scale'])

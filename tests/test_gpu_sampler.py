@@ -148,7 +148,7 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     # every fp32 operand as hi + lo fp16 terms on the 16-bit matrix pipe — a third rounding of the same sums
     (16, 1000, F23, H2, 'stack_h2', 1e-5),                               # 64-frame tiles: 256 workgroups
     (32, 997, F23, H2, 'stack_h2', 1e-5),
-    (8, 1000, F23, H2, 'stack_h2', 1e-5),                                # 32-frame tiles (the 64-frame ones would fill half of the CUs)
+    (8, 1000, F23, dict(H2, BSG_H2_PAIR64='0'), 'stack_h2', 1e-5),       # 32-frame tiles (the 64-frame ones would fill half of the CUs)
     (16, 1000, F23, dict(H2, BSG_H2_NCT='1'), 'stack_h2', 1e-5),         # forced 32-frame tiles: two launch groups of 8 rows
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2', 1e-5),   # forced for a few tiles (32-frame), partial tile
     (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2', 1e-5),
@@ -165,6 +165,11 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),   # partial tiles, rows of 2 tiles
     (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),   # T < one tile
+    # pairs of 64-frame tiles, 8 waves per workgroup (B = 5 .. 8 at T = 1000)
+    (8, 1000, F23, H2, 'stack_h2_pair64', 1e-5),                         # 128 tiles: every CU holds a half of a tile
+    (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0', BSG_H2_QUAD64='0'), 'stack_h2_pair64', 1e-5),
+    (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0', BSG_H2_QUAD64='0'), 'stack_h2_pair64', 1e-5),
+    (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0', BSG_H2_QUAD64='0'), 'stack_h2_pair64', 1e-5),
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),   # the same with 64-frame tiles
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),
 ])

@@ -29,7 +29,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 F43 = net.last_path() == 'stack_f43'
 H2 = net.last_path() == 'stack_h2'   # split-fp16 form: same stamp slots as the bf16 stack launch
-PAIR = net.last_path() in ('stack_h2_quad', 'stack_h2_quad64')   # part forms: four workgroups per tile (stamps of part 0)
+PAIR = net.last_path() in ('stack_h2_quad', 'stack_h2_quad64', 'stack_h2_pair64')   # part forms: four workgroups per tile (stamps of part 0)
 NTILE = 64 if DT == 'bf16' or F43 or H2 else 32
 if PAIR:
     NTILE = 64 if net.last_path().endswith('64') else 32
