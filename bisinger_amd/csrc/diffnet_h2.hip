@@ -30,6 +30,7 @@
 // count after every change (tests/test_build_resources.py; ~10-17 spilled registers outside the matrix loops are the good state).
 #include "diffnet_res.h"
 #include "diffnet_tail.h"
+#include <type_traits>
 
 namespace bsg {
 
@@ -1133,6 +1134,8 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
   auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
   unsigned* fx = p.pflags;                   // image flags [n_tiles][P]
   unsigned* fz = p.pflags + P * n_tiles;     // z flags     [n_tiles][P]
+  unsigned* xcc_tab = p.pflags + 2 * P * n_tiles;   // [n_tiles][P]: launch epoch + the XCC id the part runs on
+  const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
   auto wait_flags = [&](const unsigned* fl, unsigned want) {   // a whole wave: every lane with a flag polls its own; bounded
     bool pend = fl != nullptr;
     if (p.inject) {
@@ -1190,14 +1193,15 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     range_check(worst);
   };
   // a quarter (QCH channels) of NT LDS rows starting at row r0, both planes, to / from an exchange slot [plane][NT][QCH]
-  auto part_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot_p) {
+  auto part_out = [&](const char* img, int plane_bytes, int r0, int part, unsigned short* slot_p, auto aux_c) {
+    constexpr int AUX = decltype(aux_c)::value;
     const rsrc_t rs = mk_rsrc(slot_p, 2 * NT * QCH * 2);
 #pragma unroll
     for (int k = 0; k < NPIECE / NTH; ++k) {
       const int piece = k * NTH + tid;
       const int pl = piece / (NT * CH8), f = (piece / CH8) % NT, c8 = piece % CH8;
       const u32x4 v = *reinterpret_cast<const u32x4*>(img + pl * plane_bytes + (r0 + f) * ROWQ + (QCH * part + 8 * c8) * 2);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((pl * NT + f) * QCH + 8 * c8) * 2, 0, AUX);   // 16: sc1
     }
   };
   auto parts_in = [&](char* img, int plane_bytes, int r0, auto slot_of) {   // the P - 1 partners' parts
@@ -1269,6 +1273,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     }
   };
   prefetch_a1(0);
+  if (tid == 0) __hip_atomic_store(xcc_tab + P * tile_id + q, p.fbase + my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (p.clk && tile_id == 0 && q == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
   __syncthreads();   // the staged image and the tables
 
@@ -1385,12 +1390,24 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
         btab[tid + k * NTH] = bnext0[k];
         btab[tid + k * NTH + 256] = bnext1[k];
       }
-    if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
+    // z is read by the partners only, and they sit on THIS XCD (checked below): plain stores, which keep the lines in the XCD's L2 — the
+    // partners' L1-bypassing loads are served there at the same-XCD rate; write-through stores would drop them from L2
+    // (MI355X_MICROARCH.md, stores of each flavour)
+    if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q), std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached L2
     __syncthreads();
     if (tid == 0) __hip_atomic_store(fz + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave == 0) wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
-    __syncthreads();   // the partners' quarters of z are published
+    if (wave == 0) {
+      wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
+      if (l == 0 && lane < P - 1) {
+        // once per launch: do the partners really run on this XCD?  (Each part stored its XCC id in front of its first flag.)  If not —
+        // another dispatch order than workgroup i -> XCD i mod 8 — their plain stores are not visible here: count a give-up, the host
+        // repeats the evaluation without hand-offs and keeps them off
+        const unsigned theirs = __hip_atomic_load(xcc_tab + P * tile_id + (lane < q ? lane : lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (theirs != p.fbase + my_xcc) atomicAdd(p.status, 1u);
+      }
+    }
+    __syncthreads();   // the partners' parts of z are published
     QUAD_STAMP(4);
     parts_in(zs, ZP, 0, [&](int part) { return zx_slot(tile_id, part); });
     __syncthreads();   // (B) zs complete
@@ -1412,7 +1429,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     // ---- next layer: the own quarter of the image into LDS and to the exchange slot, the flag, then the conditioner term and the weights ----
     write_core();
     __syncthreads();   // (C1) the own quarter of the core rows is complete
-    if (!(p.inject && (tile_id & 1))) part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q));
+    if (!(p.inject && (tile_id & 1))) part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q), std::integral_constant<int, 16>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // (C)
     if (tid == 0) __hip_atomic_store(fx + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
