@@ -995,10 +995,88 @@ __device__ __forceinline__ int k_of(const KPass& d, int i) { return d.kb0 + ((d.
 // the lo plane `bplane` bytes behind.  The hand-off `mid` sits behind the first ROT k-steps.  The ring runs THROUGH the GEMMs: the reloads of
 // the last pass fetch the first NSQ k-steps of the GEMM that follows (`rs_next`; NEXT1: it is a GEMM1, in its order) — requested after this
 // GEMM instead, the first slot's way from L2 stood in front of every GEMM (1.2 us per layer).
-template <bool GEMM1, bool NEXT1, int ROT, int NC, int NSQ, typename MID>
+template <bool GEMM1, bool NEXT1, int ROT, int NC, int NSQ, bool BS1, typename MID>
 __device__ __forceinline__ void mfma_pipe_part(f32x4q (&c0)[NC], f32x4q (&c1)[NC], f16x8 (&A)[NSQ][4], rsrc_t rs, rsrc_t rs_next, int vfrag, int sa0,
                                                int sa1, int n_ks, int base, int dilrow, const char* bptr, int bplane, MID mid) {
   static_assert(8 % NSQ == 0, "a ring pass stays inside a tap");
+  if constexpr (BS1) {
+    // Two waves per SIMD (256 registers each): ONE set of B fragments instead of two.  The hi plane's registers are free behind the second
+    // MFMA group of a k-step and are refilled during the third (lo weights first: hi x hi is the second group); the lo plane's are free behind
+    // the third and are refilled during the next step's first.  The LDS latency of either is a group of 2 NC MFMAs — and the other wave's.
+    f16x8 Bh[NC], Bl[NC];
+    auto ldh = [&](const KPass& d, int i) {
+      const char* qp = bptr + d.boff + ((d.rot + i) & 7) * 64;
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) Bh[ct] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWQ);
+    };
+    auto ldl = [&](const KPass& d, int i) {
+      const char* qp = bptr + d.boff + ((d.rot + i) & 7) * 64 + bplane;
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) Bl[ct] = *reinterpret_cast<const f16x8*>(qp + 16 * ct * ROWQ);
+    };
+    ldh(k_pass<GEMM1>(0, base, dilrow), 0);
+#pragma unroll 1
+    for (int ks = 0; ks < n_ks; ks += NSQ) {
+      const KPass dc = k_pass<GEMM1>(ks, base, dilrow);
+      const bool fin = ks + NSQ >= n_ks;
+      const KPass dn = fin ? k_pass<NEXT1>(0, base, 0) : k_pass<GEMM1>(ks + NSQ, base, dilrow);
+      const rsrc_t rsn = fin ? rs_next : rs;
+      const int o = ks & 7;
+#pragma unroll
+      for (int s = 0; s < NSQ; ++s) {
+        if (ROT > 0 && s == ROT % NSQ && ks == ROT - ROT % NSQ) {
+          mid();
+          ldh(dc, o + s);
+        }
+        ldl(dc, o + s);
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+          BSG_MFMA_Q(c0[ct], A[s][1], Bh[ct]);
+          BSG_MFMA_Q(c1[ct], A[s][3], Bh[ct]);
+        }
+        {
+          const int kr = k_of(dn, o + s + NSQ) * QKSB;
+          A[s][1] = lda8(rsn, vfrag, sa0 + kr + QPLB);
+          A[s][3] = lda8(rsn, vfrag, sa1 + kr + QPLB);
+          const int sp = (s + NSQ - 1) % NSQ;
+          const int kp = k_of(s > 0 ? dn : dc, o + s - 1 + NSQ) * QKSB;
+          A[sp][0] = lda8(s > 0 ? rsn : rs, vfrag, sa0 + kp);
+          A[sp][2] = lda8(s > 0 ? rsn : rs, vfrag, sa1 + kp);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+          BSG_MFMA_Q(c0[ct], A[s][0], Bh[ct]);
+          BSG_MFMA_Q(c1[ct], A[s][2], Bh[ct]);
+        }
+        ldh(s + 1 < NSQ ? dc : dn, o + s + 1);
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+          BSG_MFMA_Q(c0[ct], A[s][0], Bl[ct]);
+          BSG_MFMA_Q(c1[ct], A[s][2], Bl[ct]);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (lo plane of this step)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NC / 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (hi plane of the next step)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int kpe = k_of(k_pass<NEXT1>(0, base, 0), NSQ - 1) * QKSB;
+    A[NSQ - 1][0] = lda8(rs_next, vfrag, sa0 + kpe);
+    A[NSQ - 1][2] = lda8(rs_next, vfrag, sa1 + kpe);
+    return;
+  }
   f16x8 B[2][2 * NC];
   auto ldb = [&](const KPass& d, int i, f16x8 (&Bf)[2 * NC]) {
     const char* qp = bptr + d.boff + ((d.rot + i) & 7) * 64;
@@ -1347,7 +1425,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
         QUAD_STAMP(2);
         if constexpr (COND_LATE) cond_request(l);
       };
-      mfma_pipe_part<true, false, OWN, NC, NSQ>(yg, yf, A, rs_a1, rs_a2, vfrag, sa_g, sa_f, 24, OWN * q, dil * ROWQ, xb, XP, mid);
+      mfma_pipe_part<true, false, OWN, NC, NSQ, W == 8>(yg, yf, A, rs_a1, rs_a2, vfrag, sa_g, sa_f, 24, OWN * q, dil * ROWQ, xb, XP, mid);
     }
     if constexpr (COND_LATE) {
 #pragma unroll
@@ -1415,7 +1493,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     // ---- GEMM2: 8 k-steps of 32; yg = residual rows, yf = skip rows of the own channels ---------------------------------------------------
     {
       const char* zb = zs + l15 * ROWQ + kb * 16;
-      mfma_pipe_part<false, true, 0, NC, NSQ>(yg, yf, A, rs_a2, rs_a1n, vfrag, sa_g, sa_f, 8, OWN * q, 0, zb, ZP, [] {});
+      mfma_pipe_part<false, true, 0, NC, NSQ, W == 8>(yg, yf, A, rs_a2, rs_a1n, vfrag, sa_g, sa_f, 8, OWN * q, 0, zb, ZP, [] {});
     }
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct)
