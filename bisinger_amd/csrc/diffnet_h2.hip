@@ -1301,6 +1301,19 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     }
   };
   const size_t slot_halfs = (size_t)2 * NT * QCH;   // fp16 elements of one exchange slot
+  // the 8-frame edges of the image for the neighbouring tiles: [parity][tile][2 sides: first / last 8 core frames][2 planes][8][C] fp16 in
+  // the edge-exchange array of the one-workgroup launches (p.hx: the same 16 KB per tile and parity)
+  constexpr int EDGE_HALFS = 2 * 2 * 8 * C;
+  auto edge_slot = [&](int par, int tile) { return reinterpret_cast<unsigned short*>(p.hx) + ((size_t)par * n_tiles + tile) * EDGE_HALFS; };
+  auto edges_out = [&](int par) {   // the own channels of the first and the last 8 core frames, both planes: write-through
+    const rsrc_t rs = mk_rsrc(edge_slot(par, tile_id), EDGE_HALFS * 2);
+    static_assert(32 * CH8 <= NTH, "one 16-byte piece per thread");
+    if (tid < 32 * CH8) {
+      const int side = tid / (16 * CH8), pl = (tid / (8 * CH8)) & 1, f = (tid / CH8) & 7, c8 = tid % CH8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + pl * XP + (HALO + (side ? NT - 8 : 0) + f) * ROWQ + (QCH * q + 8 * c8) * 2);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (((side * 2 + pl) * 8 + f) * C + QCH * q + 8 * c8) * 2, 0, 16);   // sc1
+    }
+  };
   auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * P + part) * slot_halfs; };
   auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * P + part) * slot_halfs; };
 
@@ -1401,24 +1414,25 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
         QUAD_STAMP(1);
         parts_in(xs, XP, HALO, [&](int part) { return ix_slot(l & 1, tile_id, part); });   // the partners' channels of the core frames
         {
-          // halo rows, both planes, all P parts: rows 0..7 = the left tile's last 8 frames, rows NT+8..NT+15 = the right tile's first 8
+          // halo rows, both planes, all channels: rows 0..7 = the left tile's last 8 frames (its edge slot 1), rows NT+8..NT+15 = the right
+          // tile's first 8 (its edge slot 0); a neighbour may sit on another XCD: write-through stores there, L1-bypassing loads here
           u32x4 v[1024 / NTH];
 #pragma unroll
           for (int k = 0; k < 1024 / NTH; ++k) {
-            const int piece = k * NTH + tid;   // 2 sides x P parts x 2 planes x 8 frames x CH8 chunks = 1024
-            const int side = piece >> 9, part = (piece & 511) / (16 * CH8), pl = (piece / (8 * CH8)) & 1, f = (piece / CH8) & 7, c8 = piece % CH8;
+            const int piece = k * NTH + tid;   // 2 sides x 2 planes x 8 frames x 32 chunks of 8 channels = 1024
+            const int side = piece >> 9, pl = (piece >> 8) & 1, f = (piece >> 5) & 7, c8 = piece & 31;
             const bool have = side == 0 ? has_left : has_right;
             v[k] = u32x4{0u, 0u, 0u, 0u};
             if (have) {
-              const rsrc_t rs = mk_rsrc(ix_slot(l & 1, side == 0 ? tile_id - 1 : tile_id + 1, part), 2 * NT * QCH * 2);
-              v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((pl * NT + (side == 0 ? NT - 8 : 0) + f) * QCH + 8 * c8) * 2, 0, 16);   // sc1
+              const rsrc_t rs = mk_rsrc(edge_slot(l & 1, side == 0 ? tile_id - 1 : tile_id + 1), EDGE_HALFS * 2);
+              v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((((1 - side) * 2 + pl) * 8 + f) * C + 8 * c8) * 2, 0, 16);   // sc1
             }
           }
 #pragma unroll
           for (int k = 0; k < 1024 / NTH; ++k) {
             const int piece = k * NTH + tid;
-            const int side = piece >> 9, part = (piece & 511) / (16 * CH8), pl = (piece / (8 * CH8)) & 1, f = (piece / CH8) & 7, c8 = piece % CH8;
-            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWQ + (QCH * part + 8 * c8) * 2) = v[k];
+            const int side = piece >> 9, pl = (piece >> 8) & 1, f = (piece >> 5) & 7, c8 = piece & 31;
+            *reinterpret_cast<u32x4*>(xs + pl * XP + ((side ? HALO + NT : 0) + f) * ROWQ + 8 * c8 * 2) = v[k];
           }
         }
         __syncthreads();   // (A) the whole image is in place
@@ -1507,7 +1521,11 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     // ---- next layer: the own quarter of the image into LDS and to the exchange slot, the flag, then the conditioner term and the weights ----
     write_core();
     __syncthreads();   // (C1) the own quarter of the core rows is complete
-    if (!(p.inject && (tile_id & 1))) part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q), std::integral_constant<int, 16>{});
+    // the own part of the image: plain stores for the partners (this XCD, like z), the edges once more write-through for the neighbours
+    if (!(p.inject && (tile_id & 1))) {
+      part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q), std::integral_constant<int, 0>{});
+      edges_out((l + 1) & 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // (C)
     if (tid == 0) __hip_atomic_store(fx + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1598,7 +1616,7 @@ int part_h2_occupancy(int parts, int nct) {
 }
 // part forms: `parts` workgroups per tile of 32 nct frames; grid = 8 parts ceil(n_tiles / 8) workgroups, all resident (one per CU)
 int launch_residual_part_h2(const StackArgs& p, hipStream_t st, int parts, int nct) {
-  BSG_REQUIRE(p.zx && p.ix && p.pflags && p.apack1q && p.apack2q, "part launch: exchange buffers / 16-row weight fragments missing");
+  BSG_REQUIRE(p.zx && p.ix && p.hx && p.pflags && p.apack1q && p.apack2q, "part launch: exchange buffers / 16-row weight fragments missing");
   const dim3 grid(8 * parts * cdiv(p.n_tiles, 8));
   if (parts == 4 && nct == 1) hipLaunchKernelGGL((residual_part_h2_kernel<4, 4, 2>), grid, dim3(256), part_lds(2), st, p);
   else if (parts == 4 && nct == 2) hipLaunchKernelGGL((residual_part_h2_kernel<4, 4, 4>), grid, dim3(256), part_lds(4), st, p);
