@@ -1488,7 +1488,10 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q), std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached L2
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(fz + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {   // the z flag is polled by the partners only (this XCD): a plain store too — it stays in L2, where their polls are served
+      const rsrc_t rs_f = mk_rsrc(fz + P * tile_id, P * 4);
+      __builtin_amdgcn_raw_buffer_store_b32(p.fbase + (unsigned)(l + 1), rs_f, q * 4, 0, 0);
+    }
     if (wave == 0) {
       wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
       if (l == 0 && lane < P - 1) {
