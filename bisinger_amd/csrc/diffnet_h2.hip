@@ -617,6 +617,27 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
         }
     }
     __syncthreads();   // (T2) h complete; every wave is done reading s
+    // ---- the step's noise, by ALL waves: the Philox quads that cover the tile's frames of each mel row (element idx = quad idx >> 2, lane
+    // idx & 3: the values philox_normal1 returns).  Evaluated per element by the 3 NCT updating waves it was 16 Philox rounds + Box-Muller
+    // per lane.  Where: the dead s image, bytes 192.. of the hi plane's core rows (channels 96.. — the updated x below uses 0..95): 80 floats
+    // per frame, so for in_dims <= 80 only (else per element as before) ------------------------------------------------------------------
+    const bool lds_noise = !a.noise && a.k.sigma != 0.f && !a.plms_hist && M <= 80;
+    if (lds_noise) {
+      constexpr int QPR = NT / 4 + 1;
+#pragma unroll 1
+      for (int item = tid; item < M * QPR; item += 512) {
+        const int m = item / QPR, jq = item - m * QPR;
+        const unsigned long long base = a.quad_row0 + ((unsigned long long)b * M + m) * T + t0;
+        const unsigned long long qd = (base >> 2) + jq;
+        const f32x4 z = philox_normal4(a.seed, a.stream, qd);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const long long cx = (long long)(4 * qd + c) - (long long)base;
+          if (cx >= 0 && cx < NT) *reinterpret_cast<float*>(xs + (HALO + (int)cx) * ROWB + 192 + 4 * m) = z[c];
+        }
+      }
+      __syncthreads();   // (T2b)
+    }
     // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins x 2 column tiles: waves 0..5 ----
     if (wave < 3 * NCT) {
       const int rt = wave % 3, ct2 = wave / 3;
@@ -671,7 +692,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
             if (cok) stf(ev, rs_en, vs, (32 * rt + acc_row0(r)) * rowT);
           } else {
             float nz = nv[r];
-            if (!a.noise && a.k.sigma != 0.f)
+            if (lds_noise) nz = *reinterpret_cast<const float*>(xs + (HALO + 32 * ct2 + l31) * ROWB + 192 + 4 * m);
+            else if (!a.noise && a.k.sigma != 0.f)
               nz = philox_normal1(a.seed, a.stream, a.quad_row0 + ((unsigned long long)b * M + m) * T + (cok ? col : T - 1));
             float x0 = __fsub_rn(__fmul_rn(a.k.recip, xv[r]), __fmul_rn(a.k.recipm1, ev));
             x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
