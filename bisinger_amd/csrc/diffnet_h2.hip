@@ -773,28 +773,18 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
     if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
   };
   auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
-  // ---- s (skip sum / sqrt(L), fp32 rows) -> hi / lo image rows: 32 chunks of 8 channels x 32 frames, lanes = consecutive frames ------------
+  // ---- s (skip sum / sqrt(L), fp32 rows) -> hi / lo image rows: 32 chunks of 8 channels x 32 frames, lanes = consecutive frames.  The
+  // loads are requested first; the noise below is generated while they are on their way from HBM ------------------------------------
+  float sv[2][8];
   {
     const rsrc_t rs_s = mk_rsrc(a.skip + (long long)b * C * T, plane);
-    unsigned worst = 0;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int item = it * 512 + tid;
-      const int hc = item >> 5, f = item & 31;
-      const int t = t0 + f;
-      const bool ok = t < T;
-      float v[8];
+      const int hc = item >> 5, t = t0 + (item & 31);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = ldf(rs_s, ok ? ((8 * hc + k) * T + t) * 4 : 0, 0);
-      if (ok) worst = max(worst, max(max(max(absbits(v[0]), absbits(v[1])), max(absbits(v[2]), absbits(v[3]))),
-                                     max(max(absbits(v[4]), absbits(v[5])), max(absbits(v[6]), absbits(v[7])))));
-      const HiLo h0 = split2(v[0], v[1]), h1 = split2(v[2], v[3]), h2 = split2(v[4], v[5]), h3 = split2(v[6], v[7]);
-      u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
-      if (!ok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
-      *reinterpret_cast<u32x4*>(xs + (HALO + f) * ROWB + hc * 16) = wh;
-      *reinterpret_cast<u32x4*>(xs + XP + (HALO + f) * ROWB + hc * 16) = wl;
+      for (int k = 0; k < 8; ++k) sv[it][k] = ldf(rs_s, t < T ? ((8 * hc + k) * T + t) * 4 : 0, 0);
     }
-    range_check(worst);
   }
   // ---- the step's noise, by ALL waves: the Philox quads that cover the tile's 32 frames of each mel row (element idx = quad idx >> 2, lane
   // idx & 3: the values philox_normal1 returns; evaluated per element by the three updating waves it was 16 evaluations per lane) --------
@@ -812,6 +802,24 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
         if (cx >= 0 && cx < 32) nzs[m * 32 + (int)cx] = z[c];
       }
     }
+  }
+  {
+    unsigned worst = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = it * 512 + tid;
+      const int hc = item >> 5, f = item & 31;
+      const bool ok = t0 + f < T;
+      const float(&v)[8] = sv[it];
+      if (ok) worst = max(worst, max(max(max(absbits(v[0]), absbits(v[1])), max(absbits(v[2]), absbits(v[3]))),
+                                     max(max(absbits(v[4]), absbits(v[5])), max(absbits(v[6]), absbits(v[7])))));
+      const HiLo h0 = split2(v[0], v[1]), h1 = split2(v[2], v[3]), h2 = split2(v[4], v[5]), h3 = split2(v[6], v[7]);
+      u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
+      if (!ok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
+      *reinterpret_cast<u32x4*>(xs + (HALO + f) * ROWB + hc * 16) = wh;
+      *reinterpret_cast<u32x4*>(xs + XP + (HALO + f) * ROWB + hc * 16) = wl;
+    }
+    range_check(worst);
   }
   const char* xcore = xs + (HALO + l31) * ROWB + lh * 16;
   auto ldb_x = [&](int ks, f16x8 (&Bf)[2]) {
