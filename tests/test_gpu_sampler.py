@@ -165,6 +165,12 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),   # partial tiles, rows of 2 tiles
     (5, 333, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),   # T < one tile
+    # odd corners of the part forms: a single frame, fewer frames than a column tile, one frame more than a tile, a long single utterance
+    (1, 1, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),
+    (2, 17, F23, dict(H2, BSG_H2='2'), 'stack_h2_quad', 1e-5),
+    (3, 65, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0'), 'stack_h2_quad64', 1e-5),
+    (7, 129, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0', BSG_H2_QUAD64='0'), 'stack_h2_pair64', 1e-5),
+    (1, 2500, F23, H2, 'stack_h2_quad64', 1e-5),                         # 79 tiles of 32 frames do not fit as quads: 40 tiles of 64 do
     # pairs of 64-frame tiles, 8 waves per workgroup (B = 5 .. 8 at T = 1000)
     (8, 1000, F23, H2, 'stack_h2_pair64', 1e-5),                         # 128 tiles: every CU holds a half of a tile
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0', BSG_H2_QUAD64='0'), 'stack_h2_pair64', 1e-5),
