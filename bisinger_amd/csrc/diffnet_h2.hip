@@ -962,8 +962,7 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
 // Instantiated:
 //   <4, 4, 2>  QUAD of a 32-frame tile: 4 x B * ceil(T / 32) <= CUs (one or two utterances at T = 1000)
 //   <4, 4, 4>  QUAD of a 64-frame tile: 4 x B * ceil(T / 64) <= CUs (B <= 4 at T = 1000)
-//   <2, 8, 4>  PAIR of a 64-frame tile, 8 waves each (two per SIMD, 256 registers: the conditioner term lands in the accumulators as in the
-//              one-workgroup launch): 2 x B * ceil(T / 64) <= CUs (B <= 8 at T = 1000; 65.2 ms per pass at B = 8 against 69.1 for one
+//   <2, 8, 4>  PAIR of a 64-frame tile, 8 waves each (two per SIMD, 256 registers: one set of B fragments): 2 x B * ceil(T / 64) <= CUs (B <= 8 at T = 1000; 65.2 ms per pass at B = 8 against 69.1 for one
 //              workgroup per 32-frame tile — with every CU busy the conditioner burst and the exchange phases grow while the GEMMs shrink)
 // Measured and not kept (profiles/r03_part_forms/): pairs of 32-frame tiles on 32-row matrix tiles (the first form of this idea: B=1 44.4 ms
 // per 100-step pass against 25.7 for the quad, B=4 47.3 against 37.9 for the quad of 64-frame tiles), pairs of 64-frame tiles with 4 waves
@@ -1233,8 +1232,6 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
 
   float xr[NC][4], sk[NC][4];
   f32x4q yg[NC], yf[NC];
-  constexpr bool COND_LATE = W == 4;   // one wave per SIMD (512 registers): the conditioner term in registers of its own, added behind GEMM1
-  f32x4q cg[COND_LATE ? NC : 1], cf[COND_LATE ? NC : 1];
   int range_flag = 0;
   auto range_check = [&](unsigned worst) {
     if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
@@ -1271,13 +1268,8 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
       const int so = (cb + r) * rowT;
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
-        if constexpr (COND_LATE) {
-          cg[ct][r] = ldf(rs_ct, vcol[ct], so);
-          cf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
-        } else {
-          yg[ct][r] = ldf(rs_ct, vcol[ct], so);
-          yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
-        }
+        yg[ct][r] = ldf(rs_ct, vcol[ct], so);
+        yf[ct][r] = ldf(rs_ct, vcol[ct], so + C * rowT);
       }
     }
   };
@@ -1417,14 +1409,11 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
       bnext0[k] = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tc] : 0.f;
       bnext1[k] = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + 256 + tc] : 0.f;
     }
-    // GEMM1 accumulates from zero; the conditioner term — requested behind the hand-off inside GEMM1, so that its way from HBM is covered by
-    // the outer taps instead of standing in front of the layer (vmcnt counts in order: requested in front of the weight ring it would be
-    // waited for with the ring's first slot) — is added behind it
+    // the conditioner term landed in the accumulators (requested behind the previous layer's image flag).  (Requested inside GEMM1 and added
+    // behind it — tried for the forms with one wave per SIMD — it blocks the weight ring: vmcnt counts in order, so every ring load issued
+    // behind the HBM request completes behind it.  Quad of 64-frame tiles: 16.1 -> 13.8 us per layer without it)
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
-      if constexpr (COND_LATE) { yg[ct] = f32x4q{0.f, 0.f, 0.f, 0.f}; yf[ct] = f32x4q{0.f, 0.f, 0.f, 0.f}; }
-      else { yg[ct] *= s1; yf[ct] *= s1; }   // (two waves per SIMD: no registers to spare — the term was requested behind the image flag)
-    }
+    for (int ct = 0; ct < NC; ++ct) { yg[ct] *= s1; yf[ct] *= s1; }
     QUAD_STAMP(0);
     // ---- GEMM1: 24 k-steps of 32; those of the centre tap over the own channels first, behind them the partners' parts + the halo ----
     {
@@ -1467,18 +1456,8 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
         }
         __syncthreads();   // (A) the whole image is in place
         QUAD_STAMP(2);
-        if constexpr (COND_LATE) cond_request(l);
       };
       mfma_pipe_part<true, false, OWN, NC, NSQ, W == 8>(yg, yf, A, rs_a1, rs_a2, vfrag, sa_g, sa_f, 24, OWN * q, dil * ROWQ, xb, XP, mid);
-    }
-    if constexpr (COND_LATE) {
-#pragma unroll
-      for (int ct = 0; ct < NC; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          yg[ct][r] = fmaf(cg[ct][r], s1, yg[ct][r]);
-          yf[ct][r] = fmaf(cf[ct][r], s1, yf[ct][r]);
-        }
     }
     QUAD_STAMP(3);
     // ---- gate -> own quarter of zs (hi / lo of 2^10 z) ----------------------------------------------------------------------------------
@@ -1563,7 +1542,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     __syncthreads();   // (C)
     if (tid == 0) __hip_atomic_store(fx + P * tile_id + q, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     QUAD_STAMP(7);
-    if constexpr (!COND_LATE) cond_request(l + 1);
+    cond_request(l + 1);   // (behind the flag: in front of the drain its way from HBM would delay the flag — vmcnt counts in order)
   }
 #undef QUAD_STAMP
   if (p.clk && tile_id == 0 && q == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }

@@ -14,7 +14,7 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 
 template <int DEPTH>
 __global__ __launch_bounds__(512, 2) void stream_kernel(const unsigned* __restrict__ buf, unsigned bytes, int passes, unsigned* out,
-                                                        unsigned long long* clk) {
+                                                        unsigned long long* clk, int skew) {
   extern __shared__ char lds[];
   const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(buf), 0, bytes, 0x00020000);
   const int tid = threadIdx.x;
@@ -22,9 +22,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(const unsigned* __restri
   u32x4 acc = {0, 0, 0, 0};
   const int voff = tid * 16;                    // 512 lanes x 16 B = 8 KB per "k-step"
   const int steps = bytes / 8192;
+  // skew: every workgroup starts at another place of the buffer (the CUs of an XCD then ask for DIFFERENT lines at any moment, like tiles that
+  // drift apart), instead of all of them streaming the same lines together
+  const int start = skew ? (int)(((long long)blockIdx.x * steps / gridDim.x) / DEPTH * DEPTH) : 0;
   for (int p = 0; p < passes; ++p) {
 #pragma unroll 1
-    for (int s = 0; s < steps; s += DEPTH) {
+    for (int s0 = 0; s0 < steps; s0 += DEPTH) {
+      const int s = (s0 + start) % steps;
       u32x4 v[DEPTH];
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) v[d] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (s + d) * 8192, 0);
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(const unsigned* __restri
 }
 
 template <int DEPTH>
-static void run(const unsigned* buf, unsigned bytes, int wgs, int passes, unsigned* out, unsigned long long* clk) {
+static void run(const unsigned* buf, unsigned bytes, int wgs, int passes, unsigned* out, unsigned long long* clk, int skew = 0) {
   const size_t lds = 150 * 1024;   // one workgroup per CU, like the stack launches
   hipFuncSetAttribute((const void*)stream_kernel<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
@@ -46,7 +50,7 @@ static void run(const unsigned* buf, unsigned bytes, int wgs, int passes, unsign
   float ms = 0;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(stream_kernel<DEPTH>, dim3(wgs), dim3(512), lds, 0, buf, bytes, passes, out, clk);
+    hipLaunchKernelGGL(stream_kernel<DEPTH>, dim3(wgs), dim3(512), lds, 0, buf, bytes, passes, out, clk, skew);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -55,8 +59,8 @@ static void run(const unsigned* buf, unsigned bytes, int wgs, int passes, unsign
   hipMemcpy(c, clk, sizeof(c), hipMemcpyDeviceToHost);
   const double us = (double)(c[3] - c[1]) / 100.0, mhz = (double)(c[2] - c[0]) / us;
   const double per_cu = (double)bytes * passes;   // bytes one workgroup pulled in
-  printf("buffer %5.2f MB  workgroups %3d  loads in flight/lane %2d: %8.1f us  shader %4.0f MHz  %6.1f GB/s per CU = %5.1f B/clk/CU  chip %5.2f TB/s\n",
-         bytes / 1048576.0, wgs, DEPTH, ms * 1e3, mhz, per_cu / (ms * 1e-3) / 1e9, per_cu / (ms * 1e-3) / (mhz * 1e6), per_cu * wgs / (ms * 1e-3) / 1e12);
+  printf("%sbuffer %5.2f MB  workgroups %3d  loads in flight/lane %2d: %8.1f us  shader %4.0f MHz  %6.1f GB/s per CU = %5.1f B/clk/CU  chip %5.2f TB/s\n",
+         skew ? "skewed starts  " : "", bytes / 1048576.0, wgs, DEPTH, ms * 1e3, mhz, per_cu / (ms * 1e-3) / 1e9, per_cu / (ms * 1e-3) / (mhz * 1e6), per_cu * wgs / (ms * 1e-3) / 1e12);
 }
 
 int main() {
@@ -70,5 +74,9 @@ int main() {
       run<8>(buf, mb << 20, wgs, 64, out, clk);
       run<16>(buf, mb << 20, wgs, 64, out, clk);
     }
+  for (int wgs : {128, 256}) {                               // the same with every workgroup at another place of a 2-MB buffer
+    run<8>(buf, 2u << 20, wgs, 64, out, clk, 1);
+    run<16>(buf, 2u << 20, wgs, 64, out, clk, 1);
+  }
   return 0;
 }
