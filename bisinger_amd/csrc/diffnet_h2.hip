@@ -120,7 +120,7 @@ __device__ __forceinline__ int kmap(int i) {
   return i < ROT ? i + ROT : (i < 2 * ROT ? i - ROT : i);
 }
 
-// k-step pipeline over two row tiles x two column tiles, 12 MFMAs per k-step (hi hi, hi lo, lo hi for each of the 4 accumulators; an
+// k-step pipeline over two row tiles x two column tiles, 12 MFMAs per k-step (lo hi, hi hi, hi lo for each of the 4 accumulators; an
 // accumulator is revisited every 4th MFMA).  A[s] = {row tile 0 hi, row tile 0 lo, row tile 1 hi, row tile 1 lo} of ring slot s,
 // refilled right after use (NSH k-steps = 48 MFMAs ahead); the B fragments of the next k-step (LDS: column tile 0 hi, lo, column tile
 // 1 hi, lo) are read before the MFMAs of the current one.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0:
@@ -146,10 +146,28 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT
     }
 #pragma unroll
     for (int s = 0; s < NSH; ++s) {
+      // One k-step: the next step's B fragments and the ring's reloads are issued INSIDE the MFMA sequence (sched_group_barrier), not around it:
+      // lo weights x hi operand first — their registers are reloaded right behind that group — and the hi weights' reload one k-step later,
+      // inside the next step's second group (residual_part_h2_kernel's pipe, where it matters more: one wave per SIMD).  +0.65 % at B = 16
       const int in = ks + s + 1 <= last ? ks + s + 1 : last;
       ldb(kmap<ROT>(in), B[(s + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
       const f16x8(&Bc)[2 * NCT] = B[s & 1];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {   // lo hi
+        BSG_MFMA_H(c0[ct], A[s][1], Bc[2 * ct]);
+        BSG_MFMA_H(c1[ct], A[s][3], Bc[2 * ct]);
+      }
+      {
+        const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
+        const int kr = kmap<ROT>(ir);
+        A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
+        A[s][3] = lda8(rs, vfrag, sa1 + kr * KSB2 + PLB);
+        const int sp = (s + NSH - 1) % NSH;
+        const int ip = ks + s - 1 + NSH <= last ? ks + s - 1 + NSH : last;
+        const int kp = kmap<ROT>(ip);
+        A[sp][0] = lda8(rs, vfrag, sa0 + kp * KSB2);
+        A[sp][2] = lda8(rs, vfrag, sa1 + kp * KSB2);
+      }
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {   // hi hi
         BSG_MFMA_H(c0[ct], A[s][0], Bc[2 * ct]);
@@ -161,17 +179,16 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT
         BSG_MFMA_H(c1[ct], A[s][2], Bc[2 * ct + 1]);
       }
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {   // lo hi
-        BSG_MFMA_H(c0[ct], A[s][1], Bc[2 * ct]);
-        BSG_MFMA_H(c1[ct], A[s][3], Bc[2 * ct]);
+      for (int i = 0; i < 2 * NCT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const int ir = ks + s + NSH <= last ? ks + s + NSH : last;
-      const int kr = kmap<ROT>(ir);
-      A[s][0] = lda8(rs, vfrag, sa0 + kr * KSB2);
-      A[s][1] = lda8(rs, vfrag, sa0 + kr * KSB2 + PLB);
-      A[s][2] = lda8(rs, vfrag, sa1 + kr * KSB2);
-      A[s][3] = lda8(rs, vfrag, sa1 + kr * KSB2 + PLB);
+#pragma unroll
+      for (int i = 0; i < 2 * NCT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 4 / (2 * NCT), 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCT, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
