@@ -370,16 +370,27 @@ __device__ __forceinline__ void mfma_pipe_bf8(f32x16& c00, f32x16& c10, f32x16& 
       // never read across the hand-off: the k-step after the centre tap is re-read above
       B0[(s + 1) & 1] = ldb(kmap<ROT>(in, n_ks), 0);
       B1[(s + 1) & 1] = ldb(kmap<ROT>(in, n_ks), 1);
-      __builtin_amdgcn_sched_barrier(0);
+      // the LDS reads and the ring's reloads inside the MFMA sequence (row tile 0 first: its fragment is reloaded right behind its two MFMAs,
+      // row tile 1's one k-step later), as in diffnet_h2.hip
       BSG_MFMA_BF(c00, A0[s], B0[s & 1]);
-      BSG_MFMA_BF(c10, A1[s], B0[s & 1]);
       BSG_MFMA_BF(c01, A0[s], B1[s & 1]);
+      {
+        const int ir = ks + s + NSS <= last ? ks + s + NSS : last;
+        A0[s] = lda8(rs, vfrag, sa0 + kmap<ROT>(ir, n_ks) * KSB);
+        const int sp = (s + NSS - 1) % NSS;
+        const int ip = ks + s - 1 + NSS <= last ? ks + s - 1 + NSS : last;
+        A1[sp] = lda8(rs, vfrag, sa1 + kmap<ROT>(ip, n_ks) * KSB);
+      }
+      BSG_MFMA_BF(c10, A1[s], B0[s & 1]);
       BSG_MFMA_BF(c11, A1[s], B1[s & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      const int ir = ks + s + NSS <= last ? ks + s + NSS : last;
-      const int kr = kmap<ROT>(ir, n_ks);
-      A0[s] = lda8(rs, vfrag, sa0 + kr * KSB);
-      A1[s] = lda8(rs, vfrag, sa1 + kr * KSB);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
