@@ -1581,8 +1581,8 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
         // part forms (residual_part_h2_kernel): several workgroups on as many CUs of an XCD share a tile, each a part of the channels and of
         // the weight stream; the whole batch in one launch.  Quads of 32-frame tiles while B * ceil(T / 32) <= CUs / 4 (one or two utterances
         // at T = 1000), quads of 64-frame tiles while B * ceil(T / 64) <= CUs / 4 (B <= 4), pairs of 64-frame tiles (8 waves each) while
-        // B * ceil(T / 64) <= CUs / 2 (B <= 8).  ms per 100-step pass at T = 1000, one workgroup per tile / part form: B=1 54.5 / 25.7,
-        // B=2 52.6 / 28.4, B=3 52.0 / 34.6, B=4 51.5 / 37.9, B=5 54.8 / 52.6, B=6 57.1 / 55.0, B=8 69.1 / 65.2.  BSG_H2_PART=0: none
+        // B * ceil(T / 64) <= CUs / 2 (B <= 8).  ms per 100-step pass at T = 1000, one workgroup per tile / part form: B=1 54.5 / 24.1,
+        // B=2 52.6 / 25.4, B=3 52.0 / 32.0, B=4 51.5 / 35.0, B=5 54.8 / 46.0, B=6 57.1 / 49.6, B=8 69.1 / 59.4.  BSG_H2_PART=0: none
         // (BSG_H2_QUAD=0 / BSG_H2_QUAD64=0 / BSG_H2_PAIR64=0: not that form)
         static int env_part = -1, env_quad = -1, env_quad64 = -1;
         if (env_part < 0) { const char* e = getenv("BSG_H2_PART"); env_part = e ? atoi(e) : 1; }

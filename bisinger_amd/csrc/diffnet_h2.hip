@@ -979,11 +979,11 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
 // Instantiated:
 //   <4, 4, 2>  QUAD of a 32-frame tile: 4 x B * ceil(T / 32) <= CUs (one or two utterances at T = 1000)
 //   <4, 4, 4>  QUAD of a 64-frame tile: 4 x B * ceil(T / 64) <= CUs (B <= 4 at T = 1000)
-//   <2, 8, 4>  PAIR of a 64-frame tile, 8 waves each (two per SIMD, 256 registers: one set of B fragments): 2 x B * ceil(T / 64) <= CUs (B <= 8 at T = 1000; 65.2 ms per pass at B = 8 against 69.1 for one
+//   <2, 8, 4>  PAIR of a 64-frame tile, 8 waves each (two per SIMD, 256 registers: one set of B fragments): 2 x B * ceil(T / 64) <= CUs (B <= 8 at T = 1000; 59.4 ms per pass at B = 8 against 69.1 for one
 //              workgroup per 32-frame tile — with every CU busy the conditioner burst and the exchange phases grow while the GEMMs shrink)
 // Measured and not kept (profiles/r03_part_forms/): pairs of 32-frame tiles on 32-row matrix tiles (the first form of this idea: B=1 44.4 ms
-// per 100-step pass against 25.7 for the quad, B=4 47.3 against 37.9 for the quad of 64-frame tiles), pairs of 64-frame tiles with 4 waves
-// of 32-row tiles (B=8: 77.4 ms), octets of 2 waves (B=1: 27.8 against 25.7 ms: the exchange among eight costs more than the halved
+// per 100-step pass against 24.1 for the quad, B=4 47.3 against 35.0 for the quad of 64-frame tiles), pairs of 64-frame tiles with 4 waves
+// of 32-row tiles (B=8: 77.4 ms), octets of 2 waves (B=1: 27.8 against 25.7 ms at the time: the exchange among eight costs more than the halved
 // weight stream saves).
 // ------------------------------------------------------------------------------------------------
 constexpr int QPLB = 32 * 1024;            // bytes per plane of a k-step slab: 32 row tiles of 16 x 1 KB
