@@ -105,6 +105,8 @@ _SIGS = {
     'bsg_gemm_set_split': (c_int32, [c_int32]),
     'bsg_diffnet_set_h2': (c_int32, [c_void_p, c_int32]),
     'bsg_gemm_range_events': (c_int32, [POINTER(c_int32), c_int32, c_void_p]),
+    'bsg_gemm_presplit_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                        c_int32, c_void_p]),
 }
 
 _lib = None
@@ -136,36 +138,62 @@ _range_strikes = 0     # range events seen by this process; from RANGE_STRIKES_M
 RANGE_STRIKES_MAX = 3
 
 
-def gemm_range_take():
-    """Wait for the current stream; number of split-fp16 GEMM waves that staged an out-of-range operand since the last take (reset)."""
+def on_device(device):
+    """Context: `device` (a torch.device, a tensor, a module, or None = leave the ambient device) current.  The guard counters live
+    per device and are read on the current stream OF that device: a model on cuda:1 while cuda:0 is current must not wait on, read
+    or reset cuda:0's state."""
+    import contextlib
+    import torch
+    if device is None:
+        return contextlib.nullcontext()
+    if isinstance(device, torch.nn.Module):
+        device = next((p.device for p in device.parameters()), None)
+        if device is None:
+            return contextlib.nullcontext()
+    elif isinstance(device, torch.Tensor):
+        device = device.device
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return contextlib.nullcontext()
+    return torch.cuda.device(device)
+
+
+def gemm_range_take(device=None):
+    """Wait for the current stream of `device`; number of split-fp16 GEMM waves that staged an out-of-range operand there since the
+    last take (reset)."""
     n = c_int32()
-    check(load().bsg_gemm_range_events(ctypes.byref(n), 1, stream_ptr()), 'bsg_gemm_range_events')
+    with on_device(device):
+        check(load().bsg_gemm_range_events(ctypes.byref(n), 1, stream_ptr()), 'bsg_gemm_range_events')
     return n.value
 
 
-def gemm_range_peek():
+def gemm_range_peek(device=None):
     """The same count without resetting it (a nested guard looks at it and leaves the take to the outermost one)."""
     n = c_int32()
-    check(load().bsg_gemm_range_events(ctypes.byref(n), 0, stream_ptr()), 'bsg_gemm_range_events')
+    with on_device(device):
+        check(load().bsg_gemm_range_events(ctypes.byref(n), 0, stream_ptr()), 'bsg_gemm_range_events')
     return n.value
 
 
-def range_guarded(run, what, on_retry=None):
+def range_guarded(run, what, on_retry=None, device=None):
     """Every public entry that may enqueue split-fp16 products outside the residual stack (FS2 linears and fused attention, the
     conditioner / input projections, HiFi-GAN's ResBlock pairs, PitchExtractor, the FFT denoiser) goes through here, so that an operand
     beyond the fp16 range of the split (|v| >= 4062 after scaling: counted by the kernels, never clipped) cannot leave the call as a
     silent NaN: the OUTERMOST guarded call waits for its stream once, and on an event moves every GEMM to the fp32 matrix pipe
     (bsg_gemm_set_split(0)), warns and runs `run()` again (`on_retry()` first restores what run() consumed).  The split form comes
     back for the next call — the event was a property of this input — until RANGE_STRIKES_MAX events have been seen in the process.
-    Inside a stream capture nothing can wait: the counter is left for the next guarded call (which then repeats its own work)."""
+    Inside a stream capture nothing can wait: the counter is left for the next guarded call (which then repeats its own work).
+    `device`: where the guarded work runs (device, tensor or module): the counter of THAT device is read on ITS current stream."""
     global _range_depth, range_retries, _range_strikes
     import torch
-    if _range_depth > 0 or torch.cuda.is_current_stream_capturing():
+    with on_device(device):
+        capturing = torch.cuda.is_current_stream_capturing()
+    if _range_depth > 0 or capturing:
         return run()
     _range_depth += 1
     try:
         out = run()
-        if gemm_range_take():
+        if gemm_range_take(device):
             import warnings
             warnings.warn(f'bisinger_amd: {what}: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4062); the call is '
                           f'repeated with every GEMM on the fp32 matrix pipe')
@@ -175,7 +203,7 @@ def range_guarded(run, what, on_retry=None):
             if on_retry is not None:
                 on_retry()
             out = run()
-            gemm_range_take()
+            gemm_range_take(device)
             if _range_strikes < RANGE_STRIKES_MAX and os.environ.get('BSG_GEMM_SPLIT', '1') != '0':
                 check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
     finally:

@@ -110,5 +110,5 @@ class FFT(FFTBlocks):
         def again():
             self._bound = None          # the hoisted condition part was projected by the same GEMMs: bind again
 
-        _lib.range_guarded(run, 'FFT denoiser forward', on_retry=again)
+        _lib.range_guarded(run, 'FFT denoiser forward', on_retry=again, device=self)
         return eps[:, None, :, :]

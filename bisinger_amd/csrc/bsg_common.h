@@ -74,6 +74,54 @@ int launch_gemm(const GemmArgs& g, hipStream_t st);
 // the split-fp16 forms (gemm.hip, fs2.hip flash attention): true while products are formed on the 16-bit matrix pipe (BSG_GEMM_SPLIT,
 // bsg_gemm_set_split); an operand that cannot be split is counted in the range-event counter (bsg_gemm_range_events)
 bool gemm_split_enabled();
+
+// Split-fp16 GEMM with PRE-SPLIT operands (gemm_h2w.hip): weights packed once as hi / lo fp16 MFMA fragments in execution order, the
+// activation as two fp16 planes [rows][K] of 16 x value written by its producer.
+struct H2wWeights {
+  unsigned short* pack = nullptr;   // [slice][tap][kk][plane][Wn / 32][64 lanes][8] fp16 of 16 x w (rows padded with zeros to a multiple of 128)
+  int Wn = 0, K = 0, taps = 0;      // Wn: padded row count
+  long long halfs = 0;
+  bool ok = false;                  // packed, and every |16 w| inside the fp16 range
+};
+struct H2wArgs {
+  const unsigned short* act;   // hi plane [rows][lda] fp16 of 16 x activation; the lo plane `act_plane` halfs behind it
+  long long act_plane;
+  int lda;
+  long long sAct;              // batch stride (halfs)
+  const unsigned short* wpack; // H2wWeights::pack
+  long long sW;                // stride between the packed weights of successive weight batches (halfs)
+  int zdiv;                    // batch index z: activation batch z % zdiv, weight batch z / zdiv (0: one weight set, zdiv = batch)
+  int rows, K, Wn, taps, tap_shift0;   // activation rows per batch item; output (i, n) = sum_tap sum_k act[i + tap_shift0 + tap][k] w[tap][n][k]
+  int act_is_a;                // 1: C[i][n] (tokens x features, ldc = row stride); 0: C[n][i] (features x frames: the [B, C, T] layout)
+  float* C;
+  int ldc;
+  long long sC;                // per batch index z
+  unsigned short* out;         // optional (act_is_a only): the result as hi / lo planes [rows][ldo] for the next GEMM, lo `out_plane` halfs behind
+  long long out_plane;
+  int ldo;
+  long long sO;
+  const float* bias;           // per weight row (+ weight batch x sBias)
+  long long sBias;
+  float alpha;                 // v = (acc + bias) * alpha for weight rows < alpha_ncols (0: all)
+  int alpha_ncols;
+  int act_fn;
+  const float* R;              // residual at the output position (ldr, + z x sR)
+  int ldr;
+  long long sR;
+  const float* rowscale;       // per activation row (+ activation batch x sRS)
+  long long sRS;
+  int batch;
+  unsigned* range_events;      // set by launch_gemm_h2w
+};
+bool h2w_supports(int rows, int Wn, int K, int taps, int lda);
+// W(tap, n, k) at src[tap * ts + n * rs + k * ks]; allocates w->pack on first use; |16 w| >= 65000 counted into *bad_dev (device word)
+int h2w_pack(H2wWeights* w, const float* src, int Wn, int K, int taps, long long ts, long long rs, long long ks, unsigned* bad_dev, hipStream_t st);
+int h2w_pack_into(unsigned short* dst, const float* src, int Wn, int K, int taps, long long ts, long long rs, long long ks, unsigned* bad_dev,
+                  hipStream_t st);   // Wn % 128 == 0: 2 * Wn * K * taps halfs at dst
+void h2w_free(H2wWeights* w);
+int h2w_split_rows(const float* src, unsigned short* hi, unsigned short* lo, long long rows, int K, long long ld, hipStream_t st);
+int h2w_split_transposed(const float* src, unsigned short* hi, unsigned short* lo, int B, int K, int T, hipStream_t st);   // [B][K][T] -> [B][T][K]
+int launch_gemm_h2w(const H2wArgs& g, hipStream_t st);
 unsigned* gemm_range_counter();   // device address of the range-event counter (null on error): kernels of other translation units add to it
 
 }  // namespace bsg

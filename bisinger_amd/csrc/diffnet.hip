@@ -1033,6 +1033,11 @@ struct bsg_diffnet {
   unsigned short* skip_h = nullptr;      // [B][C/4][T][4] bf16
   size_t cap_bt_h = 0;
   int prepared_compute = BSG_COMPUTE_F32;   // mode the bound condition was prepared for
+  unsigned short* wcond_pack = nullptr;  // [L][2 x 2C x H] the conditioner projections as pre-split fp16 fragments (gemm_h2w.hip)
+  unsigned* pack_bad = nullptr;          // device word: packed conditioner weights beyond the fp16 range (then wcond_pack is not used)
+  bool cond_h2w_ok = false;
+  unsigned short* cond_planes = nullptr; // [2][B][T][H] fp16: hi / lo of 16 x cond, transposed (the activation operand of the pre-split GEMM)
+  size_t cap_cond_planes = 0;            // B x T the planes are sized for
   float* w_cond = nullptr;  // [L][2C][H]
   float* b_cond = nullptr;  // [L][2C]  (b_cond + b_dil)
   float* b_out = nullptr;   // [L][2C]
@@ -1143,6 +1148,9 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->part_flags) (void)hipFree(h->part_flags);
   if (h->apack1q) (void)hipFree(h->apack1q);
   if (h->apack2q) (void)hipFree(h->apack2q);
+  if (h->wcond_pack) (void)hipFree(h->wcond_pack);
+  if (h->pack_bad) (void)hipFree(h->pack_bad);
+  if (h->cond_planes) (void)hipFree(h->cond_planes);
   delete h;
 }
 
@@ -1192,6 +1200,9 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   BSG_HIP(hipMalloc((void**)&h->apack2q, (size_t)L * 2 * 2 * C * C * sizeof(unsigned short)));
   BSG_HIP(hipMalloc((void**)&h->h2_scale, (size_t)(4 * L + 2 * L) * sizeof(float)));   // table + [2L] scratch of the max reduction
   TRY(dev_alloc(&h->w_cond, (size_t)L * 2 * C * C));
+  BSG_HIP(hipMalloc((void**)&h->wcond_pack, (size_t)L * 2 * 2 * C * C * sizeof(unsigned short)));
+  BSG_HIP(hipMalloc((void**)&h->pack_bad, sizeof(unsigned)));
+  BSG_HIP(hipMemsetAsync(h->pack_bad, 0, sizeof(unsigned), st));
   TRY(dev_alloc(&h->b_cond, (size_t)L * 2 * C));
   TRY(dev_alloc(&h->b_out, (size_t)L * 2 * C));
   TRY(dev_alloc(&h->w_skip, (size_t)C * C));
@@ -1241,6 +1252,7 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
                        h->b_cond + (size_t)l * 2 * C, 2 * C);
     if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: pack kernels failed"); rc = BSG_EHIP; break; }
     rc = copy_dev(h->w_cond + (size_t)l * 2 * C * C, lw[4], (size_t)2 * C * C, st);
+    if (rc == BSG_OK) rc = h2w_pack_into(h->wcond_pack + (size_t)l * 2 * 2 * C * C, (const float*)lw[4], 2 * C, C, 1, 0, C, 1, h->pack_bad, st);
     if (rc == BSG_OK) rc = copy_dev(h->b_out + (size_t)l * 2 * C, lw[7], 2 * C, st);
     // diffusion_projection of the tabulated step embedding -> dproj[s][l][:]            (net.py:67)
     if (rc == BSG_OK) rc = gemm_nt(dtab, (const float*)lw[2], h->dproj + (size_t)l * C, (const float*)lw[3], S, C, C, C, L * C, ACT_NONE, st);
@@ -1291,7 +1303,10 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
       rc = h2_tail_pack((const float*)tw[0], wo_pad, wi_pad96, h->tail_s, h->tail_s + 2 * C * C, h->tail_s + 2 * C * C + 2 * 96 * C,
                         reinterpret_cast<unsigned*>(h->tail_scale + 6), h->tail_scale, st);
   }
+  unsigned pack_bad = 1;
+  if (rc == BSG_OK && hipMemcpyAsync(&pack_bad, h->pack_bad, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) pack_bad = 1;
   hipError_t e = hipStreamSynchronize(st);
+  h->cond_h2w_ok = rc == BSG_OK && e == hipSuccess && pack_bad == 0;
   dev_free(hid);
   dev_free(dtab);
   dev_free(wo_pad);
@@ -1402,13 +1417,34 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     BSG_HIP(hipMalloc((void**)&h->skip_h, (size_t)C * bt * sizeof(unsigned short)));
     h->cap_bt_h = bt;
   }
-  if (B == 1) {
+  static int env_h2w = -1;   // BSG_GEMM_H2W=0: gemm_split_kernel (operands split while staged) instead of the pre-split GEMM
+  if (env_h2w < 0) { const char* e = getenv("BSG_GEMM_H2W"); env_h2w = e ? atoi(e) : 1; }
+  const bool h2w = env_h2w && h->cond_h2w_ok && gemm_split_enabled() && h2w_supports(T, 2 * C, C, 1, C) && (long long)h->L * B <= 65535;
+  if (h2w) {
+    // All L projections of all B rows as ONE launch on the 16-bit matrix pipe with pre-split operands (gemm_h2w.hip): cond is transposed and
+    // split once into hi / lo fp16 planes [B][T][H]; the weights were split at create; batch index z = l B + b writes condterm[l][b] =
+    // W_l cond_b + (b_cond + b_dil) as [2C][T] rows — lanes run along T
+    if (bt > h->cap_cond_planes) {
+      BSG_HIP(hipStreamSynchronize(st));
+      if (h->cond_planes) (void)hipFree(h->cond_planes);
+      h->cond_planes = nullptr;
+      h->cap_cond_planes = 0;
+      BSG_HIP(hipMalloc((void**)&h->cond_planes, 2 * bt * C * sizeof(unsigned short)));
+      h->cap_cond_planes = bt;
+    }
+    TRY(h2w_split_transposed(cond, h->cond_planes, h->cond_planes + bt * C, B, C, T, st));
+    H2wArgs g{};
+    g.act = h->cond_planes; g.act_plane = (long long)bt * C; g.lda = C; g.sAct = (long long)T * C; g.wpack = h->wcond_pack;
+    g.sW = (long long)2 * 2 * C * C; g.zdiv = B; g.rows = T; g.K = C; g.Wn = 2 * C; g.taps = 1; g.act_is_a = 0; g.C = h->condterm; g.ldc = T;
+    g.sC = (long long)2 * C * T; g.bias = h->b_cond; g.sBias = 2 * C; g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = h->L * B;
+    TRY(launch_gemm_h2w(g, st));
+  } else if (B == 1) {
     // a single utterance: the L projections are ONE GEMM of L x 2C rows ([L][2C][C] weights and [L][1][2C][T] outputs are contiguous) — twenty
     // launches of 64 workgroups each left most of the chip idle (1.0 -> 0.15 ms of a 25-ms pass)
     TRY(conv1x1(h->w_cond, h->b_cond, cond, h->condterm, h->L * 2 * C, C, 1, T, ACT_NONE, st));
   }
   for (int l = 0; l < h->L; ++l) {
-    if (B != 1)
+    if (B != 1 && !h2w)
       TRY(conv1x1(h->w_cond + (size_t)l * 2 * C * C, h->b_cond + (size_t)l * 2 * C, cond,
                   h->condterm + (size_t)l * 2 * C * bt, 2 * C, C, B, T, ACT_NONE, st));
     if (h->compute == BSG_COMPUTE_BF16)

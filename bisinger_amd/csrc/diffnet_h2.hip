@@ -1030,7 +1030,7 @@ struct KPass {
 };
 template <bool GEMM1>
 __device__ __forceinline__ KPass k_pass(int i0, int base, int dilrow) {
-  if (!GEMM1) return KPass{i0 & ~7, 0, 0};
+  if (!GEMM1) return KPass{i0 & ~7, base, 0};   // GEMM2: its 8 k-steps cyclically from the own channels of z too (round 4)
   const int t = i0 >> 3;   // 0: centre tap, 1: tap 0, 2: tap 2
   return KPass{t == 0 ? 8 : (t == 1 ? 0 : 16), t == 0 ? base : 0, t == 0 ? 0 : (t == 1 ? -dilrow : dilrow)};
 }
@@ -1518,25 +1518,29 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
       const rsrc_t rs_f = mk_rsrc(fz + P * tile_id, P * 4);
       __builtin_amdgcn_raw_buffer_store_b32(p.fbase + (unsigned)(l + 1), rs_f, q * 4, 0, 0);
     }
-    if (wave == 0) {
-      wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
-      if (l == 0 && lane < P - 1) {
-        // once per launch: do the partners really run on this XCD?  (Each part stored its XCC id in front of its first flag.)  If not —
-        // another dispatch order than workgroup i -> XCD i mod 8 — their plain stores are not visible here: count a give-up, the host
-        // repeats the evaluation without hand-offs and keeps them off
-        const unsigned theirs = __hip_atomic_load(xcc_tab + P * tile_id + (lane < q ? lane : lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (theirs != p.fbase + my_xcc) atomicAdd(p.status, 1u);
-      }
-    }
-    __syncthreads();   // the partners' parts of z are published
     QUAD_STAMP(4);
-    parts_in(zs, ZP, 0, [&](int part) { return zx_slot(tile_id, part); });
-    __syncthreads();   // (B) zs complete
-    QUAD_STAMP(5);
-    // ---- GEMM2: 8 k-steps of 32; yg = residual rows, yf = skip rows of the own channels ---------------------------------------------------
+    // ---- GEMM2: 8 k-steps of 32; yg = residual rows, yf = skip rows of the own channels.  Like GEMM1 it starts with the k-steps over the
+    // OWN channels of z — in LDS since (Z1) — and takes the partners' parts behind them: the way of the own z flag to the partners, their
+    // polls and the way of their parts back run under those MFMAs (round 4; before, GEMM2 started behind the whole exchange) -------------
     {
       const char* zb = zs + l15 * ROWQ + kb * 16;
-      mfma_pipe_part<false, true, 0, NC, NSQ, W == 8>(yg, yf, A, rs_a2, rs_a1n, vfrag, sa_g, sa_f, 8, OWN * q, 0, zb, ZP, [] {});
+      auto mid2 = [&]() {
+        if (wave == 0) {
+          wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
+          if (l == 0 && lane < P - 1) {
+            // once per launch: do the partners really run on this XCD?  (Each part stored its XCC id in front of its first flag.)  If not —
+            // another dispatch order than workgroup i -> XCD i mod 8 — their plain stores are not visible here: count a give-up, the host
+            // repeats the evaluation without hand-offs and keeps them off
+            const unsigned theirs = __hip_atomic_load(xcc_tab + P * tile_id + (lane < q ? lane : lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (theirs != p.fbase + my_xcc) atomicAdd(p.status, 1u);
+          }
+        }
+        __syncthreads();   // the partners' parts of z are published
+        parts_in(zs, ZP, 0, [&](int part) { return zx_slot(tile_id, part); });
+        __syncthreads();   // (B) zs complete
+        QUAD_STAMP(5);
+      };
+      mfma_pipe_part<false, true, OWN, NC, NSQ, W == 8>(yg, yf, A, rs_a2, rs_a1n, vfrag, sa_g, sa_f, 8, OWN * q, 0, zb, ZP, mid2);
     }
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct)

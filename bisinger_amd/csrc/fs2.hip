@@ -38,8 +38,11 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- LayerNorm over C = 256: one wave per row, 4 contiguous floats per lane ---------------------
 // y = (x - mean) * rsqrt(var + eps) * w + b, then * rowscale[row] (the reference's "* nonpadding").
+using ln_f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+// yh / yl (optional, instead of y): the result as hi / lo fp16 planes of 16 x value — the activation operand of gemm_h2w_kernel
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                 float* __restrict__ y, const float* __restrict__ rowscale, long long rows, float eps) {
+                                 float* __restrict__ y, const float* __restrict__ rowscale, long long rows, float eps,
+                                 _Float16* __restrict__ yh, _Float16* __restrict__ yl, unsigned* __restrict__ range_events) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -52,7 +55,21 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
   const float rs = rowscale ? rowscale[row] : 1.0f;
   f32x4 o = {(d0 * rstd * wv[0] + bv[0]) * rs, (d1 * rstd * wv[1] + bv[1]) * rs, (d2 * rstd * wv[2] + bv[2]) * rs,
              (d3 * rstd * wv[3] + bv[3]) * rs};
-  reinterpret_cast<f32x4*>(y + row * H)[lane] = o;
+  if (y) reinterpret_cast<f32x4*>(y + row * H)[lane] = o;
+  if (yh) {
+    ln_f16x4 hv, lv;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = o[e] * 16.0f;
+      bad |= !(fabsf(s) < 65000.0f);
+      hv[e] = (_Float16)s;
+      lv[e] = (_Float16)(s - (float)hv[e]);
+    }
+    reinterpret_cast<ln_f16x4*>(yh + row * H)[lane] = hv;
+    reinterpret_cast<ln_f16x4*>(yl + row * H)[lane] = lv;
+    if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(range_events, 1u);
+  }
 }
 
 // ---- masked softmax over keys: one 256-thread workgroup per (batch*head, query) row --------------
@@ -208,7 +225,8 @@ using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_split_kernel(const float* __restrict__ qkv, const float* __restrict__ keep,
                                                                       float* __restrict__ out, int T, int heads, int ld, int ldo,
-                                                                      unsigned* __restrict__ range_events) {
+                                                                      unsigned* __restrict__ range_events, _Float16* __restrict__ out_h,
+                                                                      long long out_plane) {
   constexpr int D = 128, BK = 32, KROW = 2 * D + 16, VROW = 2 * BK + 16;   // bytes per LDS row: 272 (68 dwords = 4 mod 64), 80
   constexpr float SIN = 16.0f, PSC = 1024.0f;
   __shared__ __attribute__((aligned(16))) char Kp[2 * BK * KROW];    // hi plane, lo plane
@@ -336,8 +354,29 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_split_kernel(const floa
       }
     }
   }
+  if (q_ok && out_h) {
+    // the attention output is read by the output projection only: written as the hi / lo fp16 planes of 16 x value that gemm_h2w_kernel
+    // stages (registers 4 g .. 4 g + 3 of a lane are 4 consecutive d: one 8-byte store per plane)
+    const float inv = 1.0f / (l * SIN * PSC);
+    _Float16* __restrict__ oph = out_h + ((long long)b * T + q_row) * ldo + hh * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f16x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = O[dt][4 * gq + e] * inv * SIN;
+          bad |= !(fabsf(x) < 65000.0f);
+          hv[e] = (_Float16)x;
+          lv[e] = (_Float16)(x - (float)hv[e]);
+        }
+        *reinterpret_cast<f16x4*>(oph + 32 * dt + 8 * gq + 4 * lh) = hv;
+        *reinterpret_cast<f16x4*>(oph + out_plane + 32 * dt + 8 * gq + 4 * lh) = lv;
+      }
+  }
   if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(range_events, 1u);
-  if (q_ok) {
+  if (q_ok && !out_h) {
     const float inv = 1.0f / (l * SIN * PSC);
     float* __restrict__ op = out + ((long long)b * T + q_row) * ldo + hh * D;
 #pragma unroll
@@ -571,6 +610,7 @@ using namespace bsg;
 
 struct FftLayerW {
   float *ln1w, *ln1b, *in_proj, *out_proj, *ln2w, *ln2b, *ffn1 /*[k][4H][H]*/, *ffn1b, *ffn2, *ffn2b;
+  H2wWeights p_in, p_out, p_ffn1, p_ffn2;   // the four weight matrices once more as pre-split fp16 fragments (gemm_h2w.hip)
 };
 
 struct bsg_fs2midi {
@@ -588,6 +628,9 @@ struct bsg_fs2midi {
   float *w_x = nullptr, *w_a = nullptr, *w_b = nullptr, *w_qkv = nullptr, *w_ffn = nullptr, *w_keep = nullptr, *w_scores = nullptr;
   float *w_c = nullptr;
   int* w_pos = nullptr;
+  unsigned short *w_ap = nullptr, *w_fp = nullptr;   // activation planes [2][rows][H] / [2][rows][4H] fp16 (operands of gemm_h2w_kernel)
+  unsigned* pack_bad = nullptr;                      // device word: packed weights beyond the fp16 range (then the pre-split GEMMs are not used)
+  bool h2w_ok = false;
 };
 
 static int fs2_alloc(bsg_fs2midi* h, float** p, size_t n) {
@@ -615,11 +658,20 @@ extern "C" void bsg_fs2midi_destroy(bsg_fs2midi* h) {
   for (float* p : ws)
     if (p) (void)hipFree(p);
   if (h->w_pos) (void)hipFree(h->w_pos);
+  if (h->w_ap) (void)hipFree(h->w_ap);
+  if (h->w_fp) (void)hipFree(h->w_fp);
+  if (h->pack_bad) (void)hipFree(h->pack_bad);
+  for (std::vector<FftLayerW>* v : {&h->enc, &h->dec})
+    for (FftLayerW& L : *v) { h2w_free(&L.p_in); h2w_free(&L.p_out); h2w_free(&L.p_ffn1); h2w_free(&L.p_ffn2); }
   delete h;
 }
 
 static int load_fft_layers(bsg_fs2midi* h, std::vector<FftLayerW>& out, const void* const* w, int n_layers, int ksz, hipStream_t st) {
   out.resize(n_layers);
+  if (!h->pack_bad) {
+    BSG_HIP(hipMalloc((void**)&h->pack_bad, sizeof(unsigned)));
+    BSG_HIP(hipMemsetAsync(h->pack_bad, 0, sizeof(unsigned), st));
+  }
   for (int i = 0; i < n_layers; ++i) {
     const void* const* lw = w + 10 * i;
     FftLayerW& L = out[i];
@@ -633,6 +685,11 @@ static int load_fft_layers(bsg_fs2midi* h, std::vector<FftLayerW>& out, const vo
     TRY(fs2_copy(h, &L.ffn1b, lw[7], 4 * H, st));
     TRY(fs2_copy(h, &L.ffn2, lw[8], (size_t)H * 4 * H, st));
     TRY(fs2_copy(h, &L.ffn2b, lw[9], H, st));
+    // pre-split fragments: Linear weights [N][K]; the conv from its original [4H][H][k] layout (tap stride 1, k stride `ksz`)
+    TRY(h2w_pack(&L.p_in, (const float*)lw[2], 3 * H, H, 1, 0, H, 1, h->pack_bad, st));
+    TRY(h2w_pack(&L.p_out, (const float*)lw[3], H, H, 1, 0, H, 1, h->pack_bad, st));
+    if (ksz <= 17) TRY(h2w_pack(&L.p_ffn1, (const float*)lw[6], 4 * H, H, ksz, 1, (long long)H * ksz, ksz, h->pack_bad, st));
+    TRY(h2w_pack(&L.p_ffn2, (const float*)lw[8], H, 4 * H, 1, 0, 4 * H, 1, h->pack_bad, st));
   }
   return BSG_OK;
 }
@@ -684,7 +741,10 @@ static int fs2_create_impl(bsg_fs2midi* h, const void* const* w, const float* de
   TRY(fs2_copy(h, &h->Estyle, w[i++], (size_t)3 * H, st));
   TRY(fs2_copy(h, &h->dec_table, dec_table, (size_t)c.n_pos * H, st));
   TRY(fs2_copy(h, &h->rel_table, rel_table, (size_t)c.n_rel * H, st));
+  unsigned bad = 0;
+  BSG_HIP(hipMemcpyAsync(&bad, h->pack_bad, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   BSG_HIP(hipStreamSynchronize(st));
+  h->h2w_ok = bad == 0 && c.enc_ffn_kernel_size <= 17 && c.dec_ffn_kernel_size <= 17;
   return BSG_OK;
 }
 
@@ -724,6 +784,8 @@ static int ensure_ws(bsg_fs2midi* h, size_t rows, size_t scores, hipStream_t st)
     float** bufs[] = {&h->w_x, &h->w_a, &h->w_b, &h->w_c, &h->w_qkv, &h->w_ffn, &h->w_keep};
     for (float** p : bufs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (h->w_pos) { (void)hipFree(h->w_pos); h->w_pos = nullptr; }
+    if (h->w_ap) { (void)hipFree(h->w_ap); h->w_ap = nullptr; }
+    if (h->w_fp) { (void)hipFree(h->w_fp); h->w_fp = nullptr; }
     h->cap_rows = 0;
     BSG_HIP(hipMalloc((void**)&h->w_x, rows * H * sizeof(float)));
     BSG_HIP(hipMalloc((void**)&h->w_a, rows * H * sizeof(float)));
@@ -733,6 +795,8 @@ static int ensure_ws(bsg_fs2midi* h, size_t rows, size_t scores, hipStream_t st)
     BSG_HIP(hipMalloc((void**)&h->w_ffn, rows * 4 * H * sizeof(float)));
     BSG_HIP(hipMalloc((void**)&h->w_keep, rows * sizeof(float)));
     BSG_HIP(hipMalloc((void**)&h->w_pos, rows * sizeof(int)));
+    BSG_HIP(hipMalloc((void**)&h->w_ap, 2 * rows * H * sizeof(unsigned short)));
+    BSG_HIP(hipMalloc((void**)&h->w_fp, 2 * rows * 4 * H * sizeof(unsigned short)));
     h->cap_rows = rows;
   }
   (void)scores;   // the score tensor of the unfused attention is allocated on demand (ensure_scores)
@@ -761,9 +825,26 @@ static int linear(const float* X, const float* W, const float* bias, float* Y, l
 }
 
 static int ln(const float* x, const float* w, const float* b, float* y, const float* rowscale, long long rows, float eps, hipStream_t st) {
-  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, b, y, rowscale, rows, eps);
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, b, y, rowscale, rows, eps, (_Float16*)nullptr,
+                     (_Float16*)nullptr, (unsigned*)nullptr);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+// LayerNorm whose result is read by a pre-split GEMM only: hi / lo fp16 planes [2][rows][H]
+static int ln_planes(const float* x, const float* w, const float* b, unsigned short* planes, long long rows, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, b, (float*)nullptr, (const float*)nullptr, rows, eps,
+                     reinterpret_cast<_Float16*>(planes), reinterpret_cast<_Float16*>(planes) + rows * H, gemm_range_counter());
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+// y[rows][N] = epi(planes[rows][K] W^T): Linear through gemm_h2w_kernel (W pre-split); `planes_out`: the result as planes [2][rows][N] instead
+static int linear_h2w(const unsigned short* planes, const H2wWeights& W, int N, const float* bias, float* Y, unsigned short* planes_out, long long rows,
+                      int act, const float* R, const float* rowscale, hipStream_t st, float alpha = 1.f, int alpha_ncols = 0) {
+  H2wArgs g{};
+  g.act = planes; g.act_plane = rows * W.K; g.lda = W.K; g.wpack = W.pack; g.rows = (int)rows; g.K = W.K; g.Wn = W.Wn; g.taps = 1;
+  g.act_is_a = 1; g.C = Y; g.ldc = N; g.out = planes_out; g.out_plane = rows * N; g.ldo = N; g.bias = bias; g.alpha = alpha;
+  g.alpha_ncols = alpha_ncols; g.act_fn = act; g.R = R; g.ldr = N; g.rowscale = rowscale; g.batch = 1;
+  return launch_gemm_h2w(g, st);
 }
 
 // EncSALayer x FFTBlocks tail (common_layers.py:706-730, tts_modules.py:298-305); x [B*T, H] in place
@@ -772,6 +853,39 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
   const long long rows = (long long)B * T;
   const int heads = h->cfg.num_heads, hd = H / heads;
   const float qscale = (float)sqrt(1.0 / (double)hd);
+  static int env_h2w = -1;   // BSG_GEMM_H2W=0: gemm_split_kernel (operands split while staged) instead of the pre-split GEMMs
+  if (env_h2w < 0) { const char* e = getenv("BSG_GEMM_H2W"); env_h2w = e ? atoi(e) : 1; }
+  static int fsplit_env = -1;
+  if (fsplit_env < 0) { const char* e = getenv("BSG_FLASH_SPLIT"); fsplit_env = e ? atoi(e) : 1; }
+  const bool h2w = env_h2w && h->h2w_ok && gemm_split_enabled() && fsplit_env && hd == 128 && !getenv("BSG_NO_FLASH_ATTN") &&
+                   h2w_supports(T, 4 * H, H, ksz, H) && h2w_supports((int)rows, 3 * H, H, 1, H) && rows * 4 * H * 2 < (1LL << 31);
+  if (h2w) {
+    // Every product on the 16-bit matrix pipe with PRE-SPLIT operands (gemm_h2w.hip): the weights were split into hi / lo fp16 fragments at
+    // create, and each activation is written as hi / lo fp16 planes by the kernel that produces it (LayerNorm, the fused attention, the
+    // GELU epilogue of the FFN convolution) — no kernel splits an operand while it stages it.  Same arithmetic as the path below.
+    unsigned short* ap = h->w_ap;   // [2][rows][H]
+    unsigned short* fp = h->w_fp;   // [2][rows][4H]
+    for (const FftLayerW& L : layers) {
+      TRY(ln_planes(x, L.ln1w, L.ln1b, ap, rows, 1e-5f, st));
+      TRY(linear_h2w(ap, L.p_in, 3 * H, nullptr, h->w_qkv, nullptr, rows, ACT_NONE, nullptr, nullptr, st, qscale, H));
+      const long long wg4 = (long long)cdiv(T, 128) * B * heads;
+      if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
+      else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
+      BSG_LAUNCH_CHECK();
+      TRY(linear_h2w(ap, L.p_out, H, nullptr, h->w_b, nullptr, rows, ACT_NONE, x, keep, st));   // x1 = (x + attn) * keep
+      TRY(ln_planes(h->w_b, L.ln2w, L.ln2b, ap, rows, 1e-5f, st));
+      {
+        H2wArgs g{};   // Conv1d(H -> 4H, k, SAME) * k^-1/2 -> GELU, written as the planes the second Linear reads
+        g.act = ap; g.act_plane = rows * H; g.lda = H; g.sAct = (long long)T * H; g.wpack = L.p_ffn1.pack; g.rows = T; g.K = H; g.Wn = 4 * H;
+        g.taps = ksz; g.tap_shift0 = -(ksz / 2); g.act_is_a = 1; g.out = fp; g.out_plane = rows * 4 * H; g.ldo = 4 * H; g.sO = (long long)T * 4 * H;
+        g.bias = L.ffn1b; g.alpha = (float)pow((double)ksz, -0.5); g.act_fn = ACT_GELU; g.batch = B;
+        TRY(launch_gemm_h2w(g, st));
+      }
+      TRY(linear_h2w(fp, L.p_ffn2, H, L.ffn2b, x, nullptr, rows, ACT_NONE, h->w_b, keep, st));   // x = (x1 + ffn) * keep
+    }
+    TRY(ln(x, lnw, lnb, x, keep, rows, 1e-5f, st));
+    return BSG_OK;
+  }
   for (const FftLayerW& L : layers) {
     // --- self attention ---
     TRY(ln(x, L.ln1w, L.ln1b, h->w_a, nullptr, rows, 1e-5f, st));
@@ -782,8 +896,8 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
       static int fsplit = -1;   // BSG_FLASH_SPLIT=0: the fp32-MFMA form even while the GEMMs run split-fp16
       if (fsplit < 0) { const char* e = getenv("BSG_FLASH_SPLIT"); fsplit = e ? atoi(e) : 1; }
       if (fsplit && gemm_split_enabled()) {
-        if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H, gemm_range_counter());
-        else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H, gemm_range_counter());
+        if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H, gemm_range_counter(), (_Float16*)nullptr, 0LL);
+        else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H, gemm_range_counter(), (_Float16*)nullptr, 0LL);
       } else if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
       else hipLaunchKernelGGL(flash_attn_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, h->w_a, T, heads, 3 * H, H);
       BSG_LAUNCH_CHECK();
@@ -979,6 +1093,7 @@ extern "C" void bsg_fftden_destroy(bsg_fftden* h) {
   float* ws[] = {h->condpart, h->xT, h->xp, h->te, h->tvec, h->mel};
   for (float* p : ws)
     if (p) (void)hipFree(p);
+  for (FftLayerW& L : h->layers) { h2w_free(&L.p_in); h2w_free(&L.p_out); h2w_free(&L.p_ffn1); h2w_free(&L.p_ffn2); }
   bsg_fs2midi_destroy(h->core);
   delete h;
 }
@@ -1025,7 +1140,10 @@ extern "C" int bsg_fftden_create(bsg_fftden** out, int32_t in_dims, int32_t n_la
   if ((rc = fs2_alloc(c, &h->dtab, (size_t)max_steps * H)) != BSG_OK) return fail(rc);
   if ((rc = linear(step_table, m0w, m0b, hid, max_steps, 4 * H, H, ACT_MISH, nullptr, nullptr, st)) != BSG_OK) return fail(rc);
   if ((rc = linear(hid, m2w, m2b, h->dtab, max_steps, H, 4 * H, ACT_NONE, nullptr, nullptr, st)) != BSG_OK) return fail(rc);
-  if (hipStreamSynchronize(st) != hipSuccess) { set_error("fftden_create: sync failed"); return fail(BSG_EHIP); }
+  unsigned pack_bad = 1;
+  if (hipMemcpyAsync(&pack_bad, c->pack_bad, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) { set_error("fftden_create: sync failed"); return fail(BSG_EHIP); }
+  c->h2w_ok = pack_bad == 0 && ffn_kernel <= 17;
   *out = h;
   return BSG_OK;
 }

@@ -29,6 +29,14 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDP = BK + 1;
 
+// GELU / Mish of the epilogues as ONE out-of-line function: inlined at each of the 64 accumulator registers of a lane, erff / tanhf /
+// log1pf / expf made every GEMM kernel 57-113 KB of code — more than the instruction cache — and each launch paid for streaming it
+// (round 4: the same epilogue cost gemm_h2w_kernel ~10 us per workgroup)
+__device__ __attribute__((noinline)) float act_slow(float v, int act) {
+  if (act == ACT_GELU) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  return v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+}
+
 template <bool TRANS_B>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   __shared__ float As[BM * LDP];
@@ -198,8 +206,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           if (g.bias_m) v += g.bias_m[row];
           if (g.alpha_ncols == 0 || col < g.alpha_ncols) v *= g.alpha;
           if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-          else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          else if (g.act >= ACT_GELU) v = act_slow(v, g.act);
           if (g.post_scale_n) v = v * ps_v + pb_v;
           if (R) v += R[(long long)row * g.ldr + col];
           if (RS) v *= RS[row];
@@ -359,8 +366,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs g) {
           if (g.bias_m) v += g.bias_m[row];
           if (g.alpha_ncols == 0 || col < g.alpha_ncols) v *= g.alpha;
           if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-          else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          else if (g.act >= ACT_GELU) v = act_slow(v, g.act);
           if (g.post_scale_n) v = v * ps_v + pb_v;
           if (R) v += R[(long long)row * g.ldr + col];
           if (RS) v *= RS[row];
@@ -549,8 +555,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
           if (g.bias_m) v += g.bias_m[row];
           if (g.alpha_ncols == 0 || col < g.alpha_ncols) v *= g.alpha;
           if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (g.act == ACT_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-          else if (g.act == ACT_MISH) v = v * tanhf(v > 20.f ? v : log1pf(expf(v)));
+          else if (g.act >= ACT_GELU) v = act_slow(v, g.act);
           if (g.post_scale_n) v = v * ps_v + pb_v;
           if (R) v += R[(long long)row * g.ldr + col];
           if (RS) v *= RS[row];

@@ -194,7 +194,8 @@ class DiffNet(nn.Module):
         the on-chip stack launch whose tiles exchange edges every layer).  Otherwise nothing below synchronises."""
         from ctypes import c_int32
         u = c_int32()
-        _lib.check(_lib.load().bsg_diffnet_uses_handoffs(self.handle(), B, T, byref(u)), 'bsg_diffnet_uses_handoffs')
+        with _lib.on_device(self):
+            _lib.check(_lib.load().bsg_diffnet_uses_handoffs(self.handle(), B, T, byref(u)), 'bsg_diffnet_uses_handoffs')
         return bool(u.value)
 
     def take_handoff_timeouts(self):
@@ -204,11 +205,12 @@ class DiffNet(nn.Module):
         return give + rng
 
     def take_health(self):
-        """Wait for the current stream; (hand-off spins that gave up, values beyond the fp16 range seen by the split-fp16 stack launch)
-        since the last take; resets both."""
+        """Wait for the current stream of the handle's device; (hand-off spins that gave up, values beyond the fp16 range seen by the
+        split-fp16 stack launch) since the last take; resets both."""
         from ctypes import c_int32
         c = (c_int32 * 2)()
-        _lib.check(_lib.load().bsg_diffnet_health_take(self._h, c, _lib.stream_ptr()), 'bsg_diffnet_health_take')
+        with _lib.on_device(self):
+            _lib.check(_lib.load().bsg_diffnet_health_take(self._h, c, _lib.stream_ptr()), 'bsg_diffnet_health_take')
         return c[0], c[1]
 
     CLEAN_CALLS_TO_REENABLE = 32     # guarded calls without a give-up after which a demoted handle tries hand-off launches again
@@ -225,7 +227,9 @@ class DiffNet(nn.Module):
             fp32 matrix pipe until the next prepare() (the event is a property of the bound input), and the work is repeated;
           * a workgroup gave up waiting for its neighbour (not resident: the GPU is shared with another process) -> hand-off launches
             off for this handle (one workgroup per tile), the work repeated; they are tried again after CLEAN_CALLS_TO_REENABLE clean calls."""
-        if torch.cuda.is_current_stream_capturing():
+        with _lib.on_device(self):
+            capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
             run()
             return
 
@@ -234,20 +238,25 @@ class DiffNet(nn.Module):
                 self.prepare(self._bound[0])
             if restore is not None:
                 restore()
-        _lib.range_guarded(lambda: self._guarded_handoffs(run, B, T, restore), 'DiffNet', on_retry=again)
+        _lib.range_guarded(lambda: self._guarded_handoffs(run, B, T, restore), 'DiffNet', on_retry=again, device=self)
 
     def _guarded_handoffs(self, run, B, T, restore):
         import warnings
         run()
+        if getattr(self, 'split_disabled', False):
+            # a demoted handle launches nothing that hands data between workgroups (bsg_diffnet_uses_handoffs is 0 for every shape while
+            # the split is off), so the call just made is clean by construction: count it HERE, before the early return below, and give
+            # the hand-off launches another try after CLEAN_CALLS_TO_REENABLE of them (a give-up is a property of the moment — another
+            # process on the GPU — not of the handle)
+            self._clean_calls = getattr(self, '_clean_calls', 0) + 1
+            if self._clean_calls >= self.CLEAN_CALLS_TO_REENABLE:
+                _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
+                self.split_disabled, self._clean_calls = False, 0
+            return
         if not self.uses_handoffs(B, T):
             return
         give, rng = self.take_health()
         if not give and not rng:
-            if getattr(self, 'split_disabled', False):
-                self._clean_calls = getattr(self, '_clean_calls', 0) + 1
-                if self._clean_calls >= self.CLEAN_CALLS_TO_REENABLE:
-                    _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
-                    self.split_disabled, self._clean_calls = False, 0
             return
         if rng and not give:
             warnings.warn(f'bisinger_amd: {rng} waves saw an activation beyond the fp16 range of the split-fp16 launch (|x + d| >= 60000); '
@@ -255,7 +264,7 @@ class DiffNet(nn.Module):
                           f'evaluation is repeated')
             _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
             self._h2_range_off = self._bound[0] if self._bound is not None else True
-            if _lib.gemm_range_peek():
+            if _lib.gemm_range_peek(self):
                 # a split-fp16 GEMM counted an operand too.  Cause and effect cannot be told apart here (a NaN condition makes the launch
                 # trip; a launch that tripped feeds NaN to the GEMMs behind it): the GEMM guard around this call repeats everything
                 # with the GEMMs on the fp32 matrix pipe — and this handle off the 16-bit pipe — in ONE more pass

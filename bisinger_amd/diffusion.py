@@ -138,7 +138,7 @@ class GaussianDiffusion(nn.Module):
             def again():
                 x.copy_(keep)
                 self.denoise_fn.prepare(cond)
-            _lib.range_guarded(loop, 'FFT denoiser sampler loop', on_retry=None if capturing else again)
+            _lib.range_guarded(loop, 'FFT denoiser sampler loop', on_retry=None if capturing else again, device=x)
             return x
         n = t if n_steps is None else n_steps
         if noise is not None:
@@ -204,7 +204,7 @@ class GaussianDiffusion(nn.Module):
         # one range guard around the whole call (FS2, the conditioner projections, the sampler): an operand beyond the fp16 range of the
         # split-fp16 GEMMs repeats all of it on the fp32 matrix pipe (_lib.range_guarded; the nested guards leave the check to this one)
         return _lib.range_guarded(lambda: self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows,
-                                                              **kwargs), 'GaussianDiffusion.forward')
+                                                              **kwargs), 'GaussianDiffusion.forward', device=self)
 
     def _forward_infer(self, txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs):
         B_total = txt_tokens.shape[0]

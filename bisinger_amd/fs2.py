@@ -329,7 +329,7 @@ class FastSpeech2MIDI(nn.Module):
         """``rows`` (slice, extension): decode only these batch rows — the token-level front still sees the whole
         batch, which is what keeps a sharded run identical to the unsharded reference."""
         return _lib.range_guarded(lambda: self._forward(txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs),
-                                  'FastSpeech2MIDI.forward')
+                                  'FastSpeech2MIDI.forward', device=self)
 
     def _forward(self, txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs):
         ret = {}

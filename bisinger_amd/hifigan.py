@@ -190,7 +190,7 @@ class HifiGanGenerator(nn.Module):
         (numpy RandomState(seed) for the 9 initial phases, the library's Philox stream 0x4E5346 for the noise)."""
         # range guard of the split-fp16 ResBlock pairs (an activation beyond the fp16 range is counted by the kernels, never clipped):
         # read once per outermost call; on an event the call is repeated on the fp32 matrix pipe (_lib.range_guarded)
-        return _lib.range_guarded(lambda: self._forward(x, f0, rand_ini, noise, seed), 'HifiGanGenerator.forward')
+        return _lib.range_guarded(lambda: self._forward(x, f0, rand_ini, noise, seed), 'HifiGanGenerator.forward', device=self)
 
     def _forward(self, x, f0, rand_ini, noise, seed):
         hd = self.handle()

@@ -129,7 +129,7 @@ class PitchExtractor(nn.Module):
     @torch.no_grad()
     def forward(self, mel_input=None):
         """mel [B,T,80] -> {'pitch_pred': [B,T,2], 'f0_denorm_pred': [B,T]}   (pe.py:136-149)."""
-        return _lib.range_guarded(lambda: self._forward(mel_input), 'PitchExtractor.forward')
+        return _lib.range_guarded(lambda: self._forward(mel_input), 'PitchExtractor.forward', device=self)
 
     def _forward(self, mel_input):
         h = self.handle()

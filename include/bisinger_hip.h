@@ -352,6 +352,15 @@ int bsg_gemm_set_split(int32_t enable);
 int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable);   /* 0: this handle's residual stack on the fp32 matrix pipe only (as BSG_H2=0) */
 int bsg_gemm_range_events(int32_t* events, int32_t reset, void* stream);
 
+/* Round 4: the same products with PRE-SPLIT operands (csrc/gemm_h2w.hip gemm_h2w_kernel) — weights split once into hi / lo fp16 MFMA
+ * fragments at create, activations written as hi / lo fp16 planes by their producers; FS2's Linear / Conv1d-FFN layers
+ * (TB/modules/commons/common_layers.py:625-644,706-730) and the hoisted conditioner projections (TB/usr/diff/net.py:68) run on it
+ * (BSG_GEMM_H2W=0: gemm_split_kernel).  Exported for unit tests and micro-benchmarks: out = epi(conv_taps(act, w) + bias), SAME padding,
+ *   act [batch][rows][K], w [taps][Wn][K], out act_is_a ? [batch][rows][Wn] : [batch][Wn][rows];  Wn % 128 == 0, K % 64 == 0, taps <= 17;
+ *   the launch is repeated `reps` times (timing); waits for `stream`. */
+int bsg_gemm_presplit_f32(const float* act, const float* w, float* out, const float* bias, int32_t rows, int32_t Wn, int32_t K,
+                          int32_t taps, int32_t act_is_a, int32_t batch, int32_t relu, int32_t reps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,32 @@ def test_gemm_f32(M, N, K, trans_b, batch):
     assert maxabs(c, ref) <= 2e-6 * K ** 0.5 * 4 + 1e-5
 
 
+@pytest.mark.parametrize('rows,Wn,K,taps,act_is_a,batch', [(128, 128, 64, 1, 1, 1), (1000, 768, 256, 1, 1, 1), (333, 1024, 256, 9, 1, 3),
+                                                           (77, 256, 1024, 1, 1, 2), (1000, 512, 256, 1, 0, 5), (50, 256, 256, 3, 1, 4),
+                                                           (130, 128, 128, 17, 0, 2), (1, 128, 64, 5, 1, 2)])
+def test_gemm_presplit(rows, Wn, K, taps, act_is_a, batch):
+    """gemm_h2w_kernel (pre-split weights, activation planes; FS2 linears, the k-tap Conv1d FFN with SAME padding per batch item, and the
+    [feature][frame] form of the conditioner projections) against float64: ragged row counts, both tile heights, both output layouts."""
+    rs = np.random.RandomState(rows + Wn + K + taps)
+    A = rs.standard_normal((batch, rows, K)).astype(np.float32)
+    W = rs.standard_normal((taps, Wn, K)).astype(np.float32)
+    bias = rs.standard_normal(Wn).astype(np.float32)
+    pad = taps // 2
+    Ap = np.pad(A.astype(np.float64), ((0, 0), (pad, pad), (0, 0)))
+    ref = sum(np.einsum('brk,nk->brn', Ap[:, t:t + rows], W[t].astype(np.float64)) for t in range(taps)) + bias[None, None, :]
+    ref = np.maximum(ref, 0)
+    if not act_is_a:
+        ref = ref.transpose(0, 2, 1)
+    a, w, bi = T_(A).cuda(), T_(W).cuda(), T_(bias).cuda()
+    c = torch.full(ref.shape, float('nan'), device='cuda')
+    lib = _lib.load()
+    _lib.check(lib.bsg_gemm_presplit_f32(_lib.ptr(a), _lib.ptr(w), _lib.ptr(c), _lib.ptr(bi), rows, Wn, K, taps, act_is_a, batch, 1, 1,
+                                         _lib.stream_ptr()), 'gemm_presplit')
+    torch.cuda.synchronize()
+    assert maxabs(c, ref) <= 2e-6 * (K * taps) ** 0.5 * 4 + 1e-5
+    assert _lib.gemm_range_take() == 0
+
+
 @pytest.mark.parametrize('B,T', [(2, 64), (3, 77), (1, 31), (5, 333), (2, 1000)])
 @pytest.mark.parametrize('layer', [0, 3, 19])
 def test_residual_layer(net, B, T, layer):
