@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
 if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
     LIB_PATH = os.environ['BSG_LIB']
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class BsgError(RuntimeError):
@@ -74,7 +74,7 @@ _SIGS = {
     'bsg_diffnet_debug_stack_stamps': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'bsg_diffnet_status': (c_int32, [c_void_p, POINTER(c_int32)]),
     'bsg_diffnet_set_compute': (c_int32, [c_void_p, c_int32]),
-    'bsg_diffnet_status_async': (c_int32, [c_void_p, c_void_p, c_void_p]),
+    'bsg_diffnet_status_async': (c_int32, [c_void_p, c_void_p, c_void_p]),     # host_counts: THREE words (ABI v5)
     'bsg_diffnet_handoff_take': (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
     'bsg_diffnet_health_take': (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
     'bsg_diffnet_uses_handoffs': (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32)]),
@@ -105,6 +105,7 @@ _SIGS = {
     'bsg_gemm_set_split': (c_int32, [c_int32]),
     'bsg_diffnet_set_h2': (c_int32, [c_void_p, c_int32]),
     'bsg_gemm_range_events': (c_int32, [POINTER(c_int32), c_int32, c_void_p]),
+    'bsg_gemm_range_events_async': (c_int32, [c_void_p, c_void_p]),
     'bsg_gemm_presplit_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                         c_int32, c_void_p]),
 }
@@ -175,6 +176,113 @@ def gemm_range_peek(device=None):
     return n.value
 
 
+_in_retry = False      # True while range_guarded runs the REPEATED pass (every GEMM on the fp32 matrix pipe): handles keep their fallbacks
+_restore_split_after = False   # deferred mode: a detection moved the GEMMs to the fp32 pipe for the next call; that call puts them back
+
+
+def guard_mode():
+    """hparams['guard_mode']: 'same_call' (default: every guarded entry waits for its stream once and repeats its own work on an event —
+    nothing invalid ever leaves a call) or 'deferred' (no wait: the health words are copied to pinned host memory behind the work, and
+    the NEXT guarded call — or check_deferred() — raises BsgError if the previous result was invalid, after switching the fallback on.
+    For callers that overlap consecutive batches on several streams and can afford to discard one result)."""
+    from .hparams import hparams
+    return str(hparams.get('guard_mode', 'same_call'))
+
+
+class _DeferredWord:
+    """Pending non-blocking reads of `n` int32 health words: each arm() takes a pinned host buffer (the caller enqueues the copy into
+    next_buf() first) and records an event behind it; take() returns the words of every read whose event has PASSED — it never waits unless
+    block=True — oldest first.  A check therefore trails the work by as many calls as the GPU is behind the host."""
+
+    def __init__(self, n):
+        self.n = n
+        self.pending = []      # [(buf, event)]
+        self.free = []
+        self.cur = None
+
+    def next_buf(self):
+        import torch
+        self.cur = self.free.pop() if self.free else torch.zeros(self.n, dtype=torch.int32).pin_memory()
+        return self.cur
+
+    def armed(self):
+        return bool(self.pending)
+
+    def arm(self):
+        import torch
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((self.cur, ev))
+        self.cur = None
+
+    def take(self, block=False):
+        out = []
+        while self.pending:
+            buf, ev = self.pending[0]
+            if not ev.query():
+                if not block:
+                    break
+                ev.synchronize()
+            self.pending.pop(0)
+            out.append([int(v) for v in buf.tolist()])
+            self.free.append(buf)
+        return out
+
+
+_deferred_gemm = {}    # device index -> _DeferredWord(1)
+import weakref  # noqa: E402
+_deferred_objs = weakref.WeakSet()   # handles (DiffNet) with health words of their own: _check_deferred_own() raises for the previous call
+
+
+def _device_index(device):
+    import torch
+    with on_device(device):
+        return torch.cuda.current_device()
+
+
+def check_deferred(device=None, block=False):
+    """Deferred guard mode: raise BsgError if a guarded call on `device` whose work has completed since the last check left an invalid
+    result — a split-fp16 GEMM staged an operand beyond the fp16 range (the GEMMs are then on the fp32 matrix pipe for the next call), or
+    one of the registered handles (DiffNet) reports a give-up / a range event.  Never waits for the GPU unless block=True (then every
+    pending read is waited for: call it before trusting the last results of a stream of requests).  The counters are per DEVICE: with
+    several streams in flight an event cannot be attributed to one of them — treat every result issued since the last clean check as
+    suspect."""
+    global _range_strikes, range_retries, _restore_split_after
+    idx = _device_index(device)
+    errs = []
+    rec = _deferred_gemm.get(idx)
+    if rec is not None and rec.armed():
+        n = sum(w[0] for w in rec.take(block))
+        if n:
+            gemm_range_take(device)      # waits for the stream and resets the counter;
+            rec.pending.clear()          # reads enqueued before this point repeat the same (cumulative) count
+            with on_device(device):
+                check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
+            _range_strikes += 1
+            range_retries += 1
+            _restore_split_after = _range_strikes < RANGE_STRIKES_MAX and os.environ.get('BSG_GEMM_SPLIT', '1') != '0'
+            errs.append(f'{n} split-fp16 GEMM waves of a PREVIOUS call staged an operand beyond the fp16 range (|v| >= 4062): its result '
+                        f'was invalid (guard_mode=deferred).  Every GEMM is on the fp32 matrix pipe for the next call: repeat the work')
+    for obj in list(_deferred_objs):      # one error for everything the previous call left, whichever entry looks first
+        if _device_index(obj) == idx:
+            try:
+                obj._check_deferred_own(block)
+            except BsgError as e:
+                errs.append(str(e))
+    if errs:
+        raise BsgError(' | '.join(errs))
+
+
+def _deferred_enqueue(device):
+    idx = _device_index(device)
+    rec = _deferred_gemm.get(idx)
+    if rec is None:
+        rec = _deferred_gemm[idx] = _DeferredWord(1)
+    with on_device(device):
+        check(load().bsg_gemm_range_events_async(c_void_p(rec.next_buf().data_ptr()), stream_ptr()), 'bsg_gemm_range_events_async')
+        rec.arm()
+
+
 def range_guarded(run, what, on_retry=None, device=None):
     """Every public entry that may enqueue split-fp16 products outside the residual stack (FS2 linears and fused attention, the
     conditioner / input projections, HiFi-GAN's ResBlock pairs, PitchExtractor, the FFT denoiser) goes through here, so that an operand
@@ -183,8 +291,9 @@ def range_guarded(run, what, on_retry=None, device=None):
     (bsg_gemm_set_split(0)), warns and runs `run()` again (`on_retry()` first restores what run() consumed).  The split form comes
     back for the next call — the event was a property of this input — until RANGE_STRIKES_MAX events have been seen in the process.
     Inside a stream capture nothing can wait: the counter is left for the next guarded call (which then repeats its own work).
-    `device`: where the guarded work runs (device, tensor or module): the counter of THAT device is read on ITS current stream."""
-    global _range_depth, range_retries, _range_strikes
+    `device`: where the guarded work runs (device, tensor or module): the counter of THAT device is read on ITS current stream.
+    guard_mode 'deferred' (see guard_mode()): no wait; the previous call's counter is looked at instead, and a BsgError raised for it."""
+    global _range_depth, range_retries, _range_strikes, _in_retry, _restore_split_after
     import torch
     with on_device(device):
         capturing = torch.cuda.is_current_stream_capturing()
@@ -192,6 +301,16 @@ def range_guarded(run, what, on_retry=None, device=None):
         return run()
     _range_depth += 1
     try:
+        if guard_mode() == 'deferred':
+            check_deferred(device)
+            restore = _restore_split_after
+            _restore_split_after = False
+            out = run()
+            if restore:
+                with on_device(device):
+                    check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
+            _deferred_enqueue(device)
+            return out
         out = run()
         if gemm_range_take(device):
             import warnings
@@ -200,9 +319,13 @@ def range_guarded(run, what, on_retry=None, device=None):
             check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
             range_retries += 1
             _range_strikes += 1
-            if on_retry is not None:
-                on_retry()
-            out = run()
+            _in_retry = True
+            try:
+                if on_retry is not None:
+                    on_retry()
+                out = run()
+            finally:
+                _in_retry = False
             gemm_range_take(device)
             if _range_strikes < RANGE_STRIKES_MAX and os.environ.get('BSG_GEMM_SPLIT', '1') != '0':
                 check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')

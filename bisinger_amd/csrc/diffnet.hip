@@ -1072,7 +1072,7 @@ struct bsg_diffnet {
   float* hx = nullptr;
   unsigned* flags = nullptr;
   size_t flags_cap = 0;                // tiles the exchange array and the flags are sized for
-  unsigned stack_epoch = 0;
+  unsigned* epoch_dev = nullptr;       // [2] launch epoch of the stack / part launches in device memory + workgroups done (diffnet_res.h StackArgs::epoch)
   unsigned long long* clk = nullptr;   // [4] s_memtime / s_memrealtime at the start and end of tile 0 of the last profiled stack launch
   int occ_stack_h = -1;                // the same for residual_stack_bf16_kernel
   int occ_stack43 = -1;                // the same for residual_stack_f43_kernel
@@ -1127,6 +1127,7 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   for (float** p : all) dev_free(*p);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
   if (h->flags) (void)hipFree(h->flags);
+  if (h->epoch_dev) (void)hipFree(h->epoch_dev);
   if (h->hx) (void)hipFree(h->hx);
   if (h->split_flags) (void)hipFree(h->split_flags);
   if (h->st2) (void)hipStreamDestroy(h->st2);
@@ -1387,6 +1388,11 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       h->flags_cap = 0;
       BSG_HIP(hipMalloc((void**)&h->flags, (need + 4) * sizeof(unsigned)));
       BSG_HIP(hipMemsetAsync(h->flags, 0, (need + 4) * sizeof(unsigned), st));
+      if (!h->epoch_dev) {   // epochs start at 1: a zeroed flag word is older than every launch (flag values = epoch * 64 + layers published)
+        BSG_HIP(hipMalloc((void**)&h->epoch_dev, 2 * sizeof(unsigned)));
+        const unsigned init[2] = {1u, 0u};
+        BSG_HIP(hipMemcpy(h->epoch_dev, init, sizeof(init), hipMemcpyHostToDevice));
+      }
       BSG_HIP(hipMalloc((void**)&h->hx, 2 * need * 2 * C * 8 * sizeof(float)));
       h->flags_cap = need;
       if (!h->clk) {
@@ -1600,9 +1606,12 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
     // CU, whole rows per launch group, every batch size.  BSG_H2=0 / bsg_diffnet_set_h2(h, 0): off (the kernels of the fp32 matrix pipe)
     static int envh2 = -1;
     if (envh2 < 0) { const char* e = getenv("BSG_H2"); envh2 = e ? atoi(e) : 1; }
+    // (round 4: the launch epoch of the flags lives in device memory, so these launches can be captured and replayed; only the part forms'
+    // exchange buffers must exist already — their first eager call allocates them)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (st) (void)hipStreamIsCapturing(st, &cap);
-    if (envh2 && !h->h2_off && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && h->apack1s && cap == hipStreamCaptureStatusNone) {
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (envh2 && !h->h2_off && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && h->apack1s && h->epoch_dev) {
       // tile width: 32 frames (one column tile per workgroup) while those tiles fit ONE launch group, else 64 frames (two column tiles:
       // half the weight stream per frame).  ms per 100-step pass at T = 1000 on one box (tools/bench_small.py), 32-frame / 64-frame /
       // fp32-pipe kernels (BSG_H2=0):  B=1 55 / 70 / 60,  B=2 53 / 70 / 64,  B=4 52 / 70 / 84,  B=6 56 / 74 / 119,  B=8 69 / 76 / 132,
@@ -1633,7 +1642,8 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
           return true;
         };
         const long long t32 = (long long)B * cdiv(T, 32), t64 = (long long)B * cdiv(T, 64);
-        if (env_part && env_nct == 0 && h->apack1q) {
+        const bool part_bufs = !capturing || (size_t)(2 * t64) <= h->part_cap;   // (sized in 32-frame tile equivalents; 2 t64 >= t32)
+        if (env_part && env_nct == 0 && h->apack1q && part_bufs) {
           if (env_quad && 4 * 8 * cdiv(t32, 8) <= h->num_cus && take_quad(1)) return B;
           if (env_quad64 && 4 * 8 * cdiv(t64, 8) <= h->num_cus && take_quad(2)) return B;
           static int env_pair64 = -1;
@@ -1666,9 +1676,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
     // >= 90 % full (B = 15, 16, 29..32, .. at T = 1000): it is ~6 % faster than two chains of per-layer F(2,3) launches, not more.
     static int env43 = -1;
     if (env43 < 0) { const char* e = getenv("BSG_STACK43"); env43 = e ? atoi(e) : 1; }
-    hipStreamCaptureStatus cap43 = hipStreamCaptureStatusNone;
-    if (st) (void)hipStreamIsCapturing(st, &cap43);
-    if (env43 && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && cap43 == hipStreamCaptureStatusNone) {
+    if (env43 && h->compute == BSG_COMPUTE_F32 && !h->split_off && h->num_cus && h->hx && h->epoch_dev) {
       if (h->occ_stack43 < 0) h->occ_stack43 = stack_f43_occupancy() >= 1 ? 1 : 0;
       const int tpr43 = cdiv(T, 64);
       if (h->occ_stack43 >= 1 && tpr43 <= h->num_cus) {
@@ -1685,17 +1693,16 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
   return 0;
 }
 
-// flag values of one stack launch: fbase + layers published (L < 64)
-constexpr unsigned kFlagSpan = 64;
-// next launch epoch of the handle's flags; before the 32-bit flag values could come round to a slot that was last written long ago
-// (a large tile index after > 2^25 launches of smaller batches) the flags are zeroed, in stream order, and the epochs start again
-static int next_stack_epoch(bsg_diffnet* h, hipStream_t st, unsigned* fbase) {
-  if (++h->stack_epoch >= (1u << 25)) {
-    BSG_HIP(hipMemsetAsync(h->flags, 0, h->flags_cap * sizeof(unsigned), st));
-    if (h->part_flags) BSG_HIP(hipMemsetAsync(h->part_flags, 0, 2 * h->part_cap * 4 * sizeof(unsigned), st));
-    h->stack_epoch = 1;
-  }
-  *fbase = h->stack_epoch * kFlagSpan;
+// flag values of one stack launch: launch epoch x 64 + layers published (L < 64)
+// The launch epoch of the handle's flags lives in device memory (round 4: a captured launch can be replayed): every workgroup reads it at
+// entry, the last one through its layers advances it and, before the 32-bit flag values could come round to a slot that was last written
+// long ago (a large tile index after > 2^25 launches of smaller batches), zeroes the flags and starts the epochs again (diffnet_res.h).
+static int next_stack_epoch(bsg_diffnet* h, StackArgs& p) {
+  BSG_REQUIRE(h->epoch_dev, "stack launch: no launch epoch (bsg_diffnet_prepare allocates it)");
+  p.epoch = h->epoch_dev;
+  p.fbase = 0;
+  p.flag_words = (int)h->flags_cap;
+  p.pflag_words = 0;   // part forms: set with p.pflags
   return BSG_OK;
 }
 
@@ -1719,7 +1726,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.n_tiles = nb * tpr; p.cycle = h->cfg.dilation_cycle_length;
     BSG_REQUIRE((size_t)p.n_tiles <= h->flags_cap && h->L < 64, "stack launch: %d tiles exceed the exchange array (%zu)", p.n_tiles, h->flags_cap);
     p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
-    TRY(next_stack_epoch(h, st, &p.fbase));
+    TRY(next_stack_epoch(h, p));
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
@@ -1728,6 +1735,9 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       const size_t need32 = (size_t)p.n_tiles * nct;   // slots scale with the tile width: size the buffers in 32-frame tile equivalents
       if (need32 > h->part_cap) {
+        hipStreamCaptureStatus capst = hipStreamCaptureStatusNone;
+        if (st) (void)hipStreamIsCapturing(st, &capst);
+        BSG_REQUIRE(capst == hipStreamCaptureStatusNone, "part launch: the exchange buffers of this shape are allocated by its first eager call; run it once before capturing");
         BSG_HIP(hipStreamSynchronize(st));
         if (h->part_zx) (void)hipFree(h->part_zx);
         if (h->part_ix) (void)hipFree(h->part_ix);
@@ -1742,6 +1752,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
         h->part_cap = cap;
       }
       p.zx = h->part_zx; p.ix = h->part_ix; p.pflags = h->part_flags;
+      p.pflag_words = (int)(2 * h->part_cap * 4);
       p.apack1q = h->apack1q; p.apack2q = h->apack2q;
       TRY(launch_residual_part_h2(p, st, h->stack_parts, nct));
     } else if (h2) {
@@ -1779,10 +1790,8 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
 static int stack_rows_bf16(bsg_diffnet* h, int B, int T, hipStream_t st) {
   static int env = -1;
   if (env < 0) { const char* e = getenv("BSG_STACK_BF16"); env = e ? atoi(e) : 1; }
-  if (!env || h->compute != BSG_COMPUTE_BF16 || h->split_off || !h->num_cus || !h->hx) return 0;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (st) (void)hipStreamIsCapturing(st, &cap);
-  if (cap != hipStreamCaptureStatusNone) return 0;   // a replay would reuse the launch epoch of the flags
+  if (!env || h->compute != BSG_COMPUTE_BF16 || h->split_off || !h->num_cus || !h->hx || !h->epoch_dev) return 0;
+  (void)st;
   if (h->occ_stack_h < 0) h->occ_stack_h = stack_bf16_occupancy() >= 1 ? 1 : 0;
   const int tpr = cdiv(T, 64);
   const long long slots = (long long)h->occ_stack_h * h->num_cus;
@@ -1811,7 +1820,7 @@ static int launch_stack_bf16(bsg_diffnet* h, const long long* t_dev, int t_unifo
     p.n_tiles = nb * tpr; p.cycle = h->cfg.dilation_cycle_length;
     BSG_REQUIRE((size_t)p.n_tiles <= h->flags_cap && h->L < 64, "bf16 stack launch: %d tiles exceed the exchange array (%zu)", p.n_tiles, h->flags_cap);
     p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
-    TRY(next_stack_epoch(h, st, &p.fbase));
+    TRY(next_stack_epoch(h, p));
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
@@ -2203,9 +2212,10 @@ extern "C" int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launche
 extern "C" int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream) {
   BSG_REQUIRE(h && host_counts, "diffnet_status_async: null argument");
   hipStream_t st = (hipStream_t)stream;
-  host_counts[0] = host_counts[1] = 0;
-  if (h->flags) BSG_HIP(hipMemcpyAsync(&host_counts[0], h->flags + h->flags_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  if (h->split_flags) BSG_HIP(hipMemcpyAsync(&host_counts[1], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  host_counts[0] = host_counts[1] = host_counts[2] = 0;
+  // words 0 and 1 of the stack launches' status are adjacent: one copy fills host_counts[0] (give-ups) and [1] (range events)
+  if (h->flags) BSG_HIP(hipMemcpyAsync(&host_counts[0], h->flags + h->flags_cap, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  if (h->split_flags) BSG_HIP(hipMemcpyAsync(&host_counts[2], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   return BSG_OK;
 }
 

@@ -407,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (tile_id >= n_tiles) return;
+  p.fbase = stack_epoch_take(p);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
     STK_STAMP(7);
   }
 #undef STK_STAMP
+  if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   // ---- the skip sum / sqrt(L) (net.py:126): rounded to bf16 ONCE (the per-layer kernel rounds the running sum after every layer) and
   // stored in channel-quad order, the layout the bf16 step tail stages with 8-byte loads -----------------------------------------

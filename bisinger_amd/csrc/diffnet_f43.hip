@@ -269,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (tile_id >= n_tiles) return;
+  p.fbase = stack_epoch_take(p);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5, p16 = lane & 15, lq = lane >> 4;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
     STK_STAMP(7);
   }
 #undef STK_STAMP
+  if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
 }
 #undef BSG_MFMA16
 #undef BSG_MFMA32

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (tile_id >= n_tiles) return;
+  p.fbase = stack_epoch_take(p);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     STK_STAMP(7);
   }
 #undef STK_STAMP
+  if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
   if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock: end of the last layer ...
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if constexpr (!TAIL) {
@@ -1222,6 +1224,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + slot / P;
   const int q = slot % P;
   if (slot / P >= per_xcd || tile_id >= n_tiles) return;
+  p.fbase = stack_epoch_take(p);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kb = lane >> 4;
@@ -1566,6 +1569,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     cond_request(l + 1);   // (behind the flag: in front of the drain its way from HBM would delay the flag — vmcnt counts in order)
   }
 #undef QUAD_STAMP
+  if (tid == 0) stack_epoch_done(p, p.fbase, P * n_tiles);
   if (p.clk && tile_id == 0 && q == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);
   // ---- the skip sum / sqrt(L) of the own channels (net.py:126), fp32 [C][T] rows: what step_tail_kernel reads ---------------------------

@@ -58,7 +58,14 @@ struct StackArgs {
   unsigned* flags;        // [n_tiles]
   unsigned* status;       // += 1 for every spin that gave up
   int t_uniform, T, L, tiles_per_row, n_tiles, cycle;
-  unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published
+  unsigned fbase;         // launch epoch * 64: flag value = fbase + layers published (host-side epoch: diagnostics; otherwise `epoch`)
+  // Round 4: the launch epoch lives in DEVICE memory, so that a captured launch can be replayed (a replay repeats its kernel arguments):
+  // epoch[0] = epoch of the launch that runs next, epoch[1] = workgroups of the running launch that are through their layers.  Every
+  // workgroup takes fbase = epoch[0] * 64 at entry; the LAST one through its layer loop (all others have read the epoch long ago)
+  // advances it — and, before the 32-bit flag values could come round, zeroes every flag word and starts the epochs again.
+  unsigned* epoch;        // null: p.fbase
+  int flag_words;         // words of `flags` to zero at a wrap (the status words behind them are not touched)
+  int pflag_words;        // the same for `pflags` (part forms)
   int inject;             // fault injection: consumers do not wait
   // part forms of the split-fp16 launch (residual_part_h2_kernel, small batches): exchange of the P channel parts of a tile
   unsigned short* zx;     // [n_tiles][P parts][2 planes][tile frames][C/P] fp16: gated activation parts
@@ -67,6 +74,27 @@ struct StackArgs {
   unsigned long long* stamps;   // diagnostic (bsg_diffnet_debug_stack_stamps) or null: [n_tiles][L][8] s_memrealtime at the phase boundaries
   unsigned long long* clk;      // null, or [4]: tile 0 stores s_memtime / s_memrealtime at its start and end (sustained shader clock, bench.py)
 };
+
+// Launch epoch in device memory (StackArgs::epoch): taken at entry by every workgroup ...
+__device__ __forceinline__ unsigned stack_epoch_take(const StackArgs& p) {
+  if (!p.epoch) return p.fbase;
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * 64u;
+}
+// ... and advanced by the last of the launch's `n_wgs` workgroups to leave its layer loop (one thread of each calls this once)
+__device__ __forceinline__ void stack_epoch_done(const StackArgs& p, unsigned fbase, int n_wgs) {
+  if (!p.epoch) return;
+  const unsigned done = atomicAdd(p.epoch + 1, 1u);
+  if (done + 1u != (unsigned)n_wgs) return;
+  unsigned next = fbase / 64u + 1u;
+  if (next >= (1u << 25)) {   // flag values = epoch * 64 + layer in 32 bits: start again from zeroed flags, as nothing else runs on them now
+    for (int i = 0; i < p.flag_words; ++i) p.flags[i] = 0u;
+    if (p.pflags)
+      for (int i = 0; i < p.pflag_words; ++i) p.pflags[i] = 0u;
+    next = 1u;
+  }
+  __hip_atomic_store(p.epoch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p.epoch, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // bf16 stack launch: 64-frame tiles, one workgroup per CU (see diffnet_bf16.hip); grid = p.n_tiles rounded up to 8
 int launch_residual_stack_bf16(const StackArgs& p, hipStream_t st);

@@ -668,3 +668,11 @@ extern "C" int bsg_gemm_range_events(int32_t* events, int32_t reset, void* strea
   *events = (int32_t)v;
   return BSG_OK;
 }
+
+// Non-blocking read of the range-event counter (ABI v5): enqueues a copy of the current device's counter into *host_word (pinned host
+// memory, caller-owned) on `stream`; valid once the stream has passed that point.  Nothing is reset.
+extern "C" int bsg_gemm_range_events_async(int32_t* host_word, void* stream) {
+  BSG_REQUIRE(host_word, "gemm_range_events_async: null argument");
+  BSG_HIP(hipMemcpyFromSymbolAsync(host_word, HIP_SYMBOL(bsg::g_gemm_range_events), sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return BSG_OK;
+}

@@ -151,8 +151,13 @@ class DiffNet(nn.Module):
         h = self.handle()
         off = getattr(self, '_h2_range_off', False)
         if off is not False and off is not cond:        # a range event of the split-fp16 launch was a property of the condition bound then
-            _lib.check(_lib.load().bsg_diffnet_set_h2(h, 1), 'bsg_diffnet_set_h2')
-            self._h2_range_off = False
+            if _lib._in_retry or getattr(self, '_h2_strikes', 0) >= self.H2_STRIKES_MAX:
+                # the repeated pass of an outer guarded call (GaussianDiffusion.forward recomputes cond: a NEW tensor with the same values),
+                # or a handle whose inputs keep leaving the range: stay on the fp32 matrix pipe
+                self._h2_range_off = cond
+            else:
+                _lib.check(_lib.load().bsg_diffnet_set_h2(h, 1), 'bsg_diffnet_set_h2')
+                self._h2_range_off = False
         cond = cond.contiguous().float()
         B, H, T = cond.shape
         assert H == self.encoder_hidden
@@ -214,6 +219,7 @@ class DiffNet(nn.Module):
         return c[0], c[1]
 
     CLEAN_CALLS_TO_REENABLE = 32     # guarded calls without a give-up after which a demoted handle tries hand-off launches again
+    H2_STRIKES_MAX = 3               # range events of the split-fp16 stack launch after which the handle stays on the fp32 matrix pipe
 
     def guarded(self, run, B, T, restore=None):
         """Run ``run()`` (which enqueues evaluations on this handle) so that an invalid result never leaves the call.  Three events are
@@ -231,6 +237,13 @@ class DiffNet(nn.Module):
             capturing = torch.cuda.is_current_stream_capturing()
         if capturing:
             run()
+            return
+        if _lib.guard_mode() == 'deferred':
+            # no wait: look at what the PREVIOUS call on this handle left (BsgError, after switching the fallback on), run, and enqueue
+            # the non-blocking copy of the health words behind this call's work
+            _lib.check_deferred(self)
+            _lib.range_guarded(run, 'DiffNet', device=self)
+            self._deferred_enqueue()
             return
 
         def again():
@@ -264,6 +277,7 @@ class DiffNet(nn.Module):
                           f'evaluation is repeated')
             _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
             self._h2_range_off = self._bound[0] if self._bound is not None else True
+            self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
             if _lib.gemm_range_peek(self):
                 # a split-fp16 GEMM counted an operand too.  Cause and effect cannot be told apart here (a NaN condition makes the launch
                 # trip; a launch that tripped feeds NaN to the GEMMs behind it): the GEMM guard around this call repeats everything
@@ -288,6 +302,56 @@ class DiffNet(nn.Module):
         give, rng = self.take_health()
         if give or rng:
             raise _lib.BsgError(f'{give + rng} inter-workgroup hand-offs gave up with split launches off: the result is invalid')
+
+    # ------------------------------------------------------------------ guard_mode = 'deferred'
+    def _deferred_enqueue(self):
+        rec = getattr(self, '_deferred', None)
+        if rec is None:
+            rec = self._deferred = _lib._DeferredWord(3)
+        _lib._deferred_objs.add(self)
+        with _lib.on_device(self):
+            _lib.check(_lib.load().bsg_diffnet_status_async(self._h, c_void_p(rec.next_buf().data_ptr()), _lib.stream_ptr()), 'bsg_diffnet_status_async')
+            rec.arm()
+
+    def check_deferred(self, block=True):
+        """guard_mode 'deferred': raise BsgError if the previous guarded call produced an invalid result — on this handle: a workgroup gave
+        up waiting for a partner (hand-off launches are then off for CLEAN_CALLS_TO_REENABLE calls) or a value left the fp16 range of the
+        split-fp16 launch (the handle then runs the fp32 matrix pipe while this condition is bound); on its device: an operand of a
+        split-fp16 GEMM left the fp16 range.  No-op when nothing is pending."""
+        _lib.check_deferred(self, block)
+
+    def _check_deferred_own(self, block=False):
+        rec = getattr(self, '_deferred', None)
+        if rec is None or not rec.armed() or self._h is None:
+            return
+        words = rec.take(block)
+        if not words:
+            return
+        # the words are cumulative until a take resets them: the newest completed read says everything
+        give, rng, give_split = words[-1]
+        if not (give or rng or give_split):
+            if getattr(self, 'split_disabled', False):
+                self._clean_calls = getattr(self, '_clean_calls', 0) + len(words)
+                if self._clean_calls >= self.CLEAN_CALLS_TO_REENABLE:
+                    _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
+                    self.split_disabled, self._clean_calls = False, 0
+            return
+        self.take_health()      # waits for the stream and resets the words;
+        rec.pending.clear()     # reads enqueued before this point repeat the same (cumulative) counts: dropped — repeat everything issued since the last clean check
+        what = []
+        if rng:
+            _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
+            self._h2_range_off = self._bound[0] if self._bound is not None else True
+            self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
+            what.append(f'{rng} waves saw a value beyond the fp16 range of the split-fp16 launch (this handle now runs the fp32 matrix pipe '
+                        f'while this condition is bound)')
+        if give or give_split:
+            _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
+            self.split_disabled, self._clean_calls = True, 0
+            what.append(f'{give + give_split} inter-workgroup hand-offs gave up (hand-off launches are off for the next '
+                        f'{self.CLEAN_CALLS_TO_REENABLE} calls)')
+        raise _lib.BsgError('a PREVIOUS call on this DiffNet handle produced an invalid result (guard_mode=deferred): ' + '; '.join(what) +
+                            '.  Repeat the work')
 
     def debug_inject_giveup(self, n_launches):
         """Fault injection (tests): the next ``n_launches`` channel-split launches give up their hand-offs without waiting."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSG_ABI_VERSION 4
+#define BSG_ABI_VERSION 5
 
 #define BSG_OK 0
 #define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
@@ -151,9 +151,13 @@ int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode);
  * tiles exchange their edges every layer, and the channel-split launch used for small batches): number of inter-workgroup hand-off spins that
  * gave up since the handle was bound (must be 0; non-zero means a result is invalid). */
 int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
-/* Asynchronous form: enqueues copies of the two give-up counters into host_counts[0..1] (pinned host memory, caller-owned)
- * on `stream` and returns; the values are valid once the stream has passed that point (e.g. an event recorded after the
- * call).  Lets a caller fail loudly one call later without adding a synchronisation to the path. */
+/* Asynchronous form (ABI v5: THREE words): enqueues copies of the handle's health words into host_counts[0..2] (pinned host memory,
+ * caller-owned) on `stream` and returns; the values are valid once the stream has passed that point (e.g. an event recorded after the
+ * call): [0] hand-off give-ups of the stack / part launches, [1] values beyond the fp16 range seen by the split-fp16 stack / part / tail
+ * launches (|x + d| >= 60000: the result is invalid, repeat with bsg_diffnet_set_h2(h, 0)), [2] give-ups of the channel-split launches.
+ * Nothing is reset (bsg_diffnet_health_take does that).  Lets a caller fail loudly — or repeat — one call later without adding a
+ * synchronisation to the path: what a replayed capture of the sampler loop (round 4: the stack / part launches keep their launch epoch in
+ * device memory and can be captured) and the `deferred` guard mode of the Python drop-ins use. */
 int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, void* stream);
 /* Same-call form (what the Python drop-ins use): waits for `stream`, returns the give-up count accumulated since the last
  * take and resets it.  bsg_diffnet_uses_handoffs says whether launches of shape (B,T) on this handle may hand data between
@@ -351,6 +355,8 @@ int bsg_gemm_f32(const float* A, const float* Bm, float* C, const float* bias_m,
 int bsg_gemm_set_split(int32_t enable);
 int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable);   /* 0: this handle's residual stack on the fp32 matrix pipe only (as BSG_H2=0) */
 int bsg_gemm_range_events(int32_t* events, int32_t reset, void* stream);
+/* ABI v5, non-blocking: enqueues a copy of the counter into *host_word (pinned host memory) on `stream`; nothing is reset. */
+int bsg_gemm_range_events_async(int32_t* host_word, void* stream);
 
 /* Round 4: the same products with PRE-SPLIT operands (csrc/gemm_h2w.hip gemm_h2w_kernel) — weights split once into hi / lo fp16 MFMA
  * fragments at create, activations written as hi / lo fp16 planes by their producers; FS2's Linear / Conv1d-FFN layers

@@ -185,3 +185,81 @@ def test_bound_condition_is_not_keyed_on_the_address():
     c = T_(c2).cuda()
     y2 = m.p_sample(x, torch.full((B,), 9, device='cuda'), c, noise=torch.zeros_like(x)).clone()
     assert not torch.equal(y1, y2)
+
+
+def test_demoted_handle_tries_handoffs_again_after_clean_calls():
+    """a give-up demotes the handle to launches without hand-offs; that must EXPIRE.  After CLEAN_CALLS_TO_REENABLE guarded
+    calls (a demoted handle launches nothing that can give up, so every one of them counts) the hand-off forms are back."""
+    B, T = 1, 320
+    rs = np.random.RandomState(5)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    x0 = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
+    t = torch.full((B,), 17, device='cuda', dtype=torch.long)
+    m = _model()
+    net = m.denoise_fn
+    want = net(x0, t, cond).clone()
+    path0 = net.last_path()
+    assert net.uses_handoffs(B, T)
+    net.debug_inject_giveup(20)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = net(x0, t, cond).clone()
+    assert any('hand-offs gave up' in str(x.message) for x in w)
+    assert getattr(net, 'split_disabled', False) and not net.uses_handoffs(B, T)
+    assert maxabs(got, want) <= 1e-5
+    net.debug_inject_giveup(0)          # (one part launch took one of the 20 injections: drop the rest)
+    demoted_path = net.last_path()
+    assert demoted_path != path0
+    for i in range(net.CLEAN_CALLS_TO_REENABLE):
+        assert getattr(net, 'split_disabled', False), f'came back after {i} calls'
+        out = net(x0, t, cond)
+    assert not getattr(net, 'split_disabled', False) and net.uses_handoffs(B, T)
+    out = net(x0, t, cond)
+    assert net.last_path() == path0 and torch.equal(out, want)
+    assert net.handoff_timeouts() == 0
+
+
+def test_deferred_guard_mode_raises_one_call_late():
+    """hparams['guard_mode'] = 'deferred': no stream wait inside a guarded call; the health words are copied to pinned host memory behind the
+    work, and a LATER call (the first one that finds the copy completed; check_deferred() waits for it) raises for the invalid result —
+    after switching the fallback on, so that the repeated work is valid."""
+    from bisinger_amd import _lib
+    B, T = 1, 320
+    rs = np.random.RandomState(6)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    noise = T_(synth.synth_noise(6, B, 80, T, seed=9)).cuda()
+    x0 = noise[0][:, None].contiguous()
+    m = _model()
+    net = m.denoise_fn
+    want = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=6).clone()
+    hparams['guard_mode'] = 'deferred'
+    try:
+        got = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=6)
+        assert torch.equal(got, want)
+        net.check_deferred()                       # clean: nothing raised
+        _lib.check_deferred(cond)
+        net.debug_inject_giveup(3)
+        bad = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=6)      # invalid, and nobody waited for it
+        with pytest.raises(_lib.BsgError, match='PREVIOUS call'):
+            net.check_deferred()
+        assert getattr(net, 'split_disabled', False)
+        redo = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=6)     # the repeated work: valid, without hand-offs
+        net.check_deferred()
+        assert maxabs(redo, want) <= 1e-5
+        del bad
+        # a split-fp16 GEMM operand beyond the fp16 range (the conditioner projection of a huge cond): raised by the next call too
+        big = cond * 1e4
+        m.sample(big, x0.clone(), noise=noise[1:3], n_steps=2)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.BsgError, match='PREVIOUS call'):
+            m.sample(cond, x0.clone(), noise=noise[1:], n_steps=6)
+        ok = m.sample(cond, x0.clone(), noise=noise[1:], n_steps=6)
+        net.check_deferred()
+        _lib.check_deferred(cond)
+        assert maxabs(ok, want) <= 1e-5
+    finally:
+        hparams.pop('guard_mode', None)
+        torch.cuda.synchronize()
+        _lib.gemm_range_take()
+        net.take_health()
+        _lib.check(_lib.load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')

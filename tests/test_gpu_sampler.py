@@ -244,11 +244,11 @@ def test_sampler_loop_is_graph_capturable(model, B, T, n):
     rs = np.random.RandomState(17)
     cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
     x0 = T_(rs.standard_normal((B, 1, 80, T)).astype(np.float32)).cuda()
-    eager = model.sample(cond, x0.clone(), seed=11, n_steps=n).clone()      # also warms up (workspaces, function attributes)
+    eager = model.sample(cond, x0.clone(), seed=11, n_steps=n).clone()      # also warms up (workspaces, function attributes, exchange buffers)
     torch.cuda.synchronize()
-    # a stack launch (flags carry a launch epoch) is never taken inside a capture: when the eager call ran one, the captured loop runs
-    # the per-layer F(2,3) kernels instead — another rounding of the same sums (1e-5); otherwise the replay is bit-identical
-    eager_is_stack = model.denoise_fn.last_path().startswith('stack')
+    eager_path = model.denoise_fn.last_path()
+    # round 4: the stack / part launches keep their launch epoch in device memory (every workgroup reads it at entry, the last one through
+    # its layers advances it), so the captured loop runs the SAME launches as the eager call and every replay is bit-identical to it
     xg = x0.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -256,18 +256,21 @@ def test_sampler_loop_is_graph_capturable(model, B, T, n):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
             model.sample(cond, xg, seed=11, n_steps=n)
+        assert model.denoise_fn.last_path() == eager_path
     torch.cuda.current_stream().wait_stream(side)
-    first = None
-    for _ in range(2):
+    for _ in range(3):
         xg.copy_(x0)
         g.replay()
         torch.cuda.synchronize()
-        if eager_is_stack:
-            assert maxabs(xg, eager) <= 1e-5
-        else:
-            assert torch.equal(xg, eager)
-        first = xg.clone() if first is None else first
-        assert torch.equal(xg, first)
+        assert torch.equal(xg, eager)
+    # an eager call between replays advances the same device-side epoch: both stay valid
+    again = model.sample(cond, x0.clone(), seed=11, n_steps=n)
+    assert torch.equal(again, eager)
+    xg.copy_(x0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xg, eager)
+    assert model.denoise_fn.take_handoff_timeouts() == 0
 
 
 def test_single_layer_graph_replays(model):

@@ -61,6 +61,8 @@ if F43 or H2:
     cyc = raw[:, L - 1, 7] - raw[:, L - 1, 6]
     us = (raw[:, L - 1, 5] - raw[:, 0, 0]) / 100.0
     print(f'shader clock held over the launch: {np.median(cyc / us):.0f} MHz (s_memtime cycles / s_memrealtime span, median over tiles)')
+    tpr_ = (T + NTILE - 1) // NTILE
+    print('  per-row shader clock (MHz):', ' '.join(f'{v:.0f}' for v in (cyc / us).reshape(B, tpr_).mean(1)))
 inner = s[:, 1:L - 1]                                                          # layers with all 8 stamps and a successor
 d = [inner[:, :, i + 1] - inner[:, :, i] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
 period = s[:, 2:L, 0] - s[:, 1:L - 1, 0]
@@ -78,3 +80,9 @@ print('  per-row end of last layer (us): ', ' '.join(f'{v:.0f}' for v in (s[:, L
 print('  per-row spread inside a row at layer 10 (us):', ' '.join(f'{v:.0f}' for v in (rows.max(1) - rows.min(1))))
 per = (s[:, 2:L, 0] - s[:, 1:L - 1, 0]).reshape(B, tpr, -1).mean((1, 2))
 print('  per-row mean layer period (us):', ' '.join(f'{v:.0f}' for v in per))
+if H2 or PAIR:
+    # per-row phase means (rows 2 r, 2 r + 1 of the B = 16 launch run on XCD r): which phase makes the rows of some XCDs slower?
+    print('  per-row phase means (us):')
+    for n, v in zip(names, d):
+        vr = v.reshape(B, tpr, -1).mean((1, 2))
+        print(f'    {n[:44]:44s} ' + ' '.join(f'{x:5.2f}' for x in vr))
