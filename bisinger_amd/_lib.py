@@ -32,7 +32,8 @@ class HifiganCfg(Structure):
     _fields_ = [('n_mel', c_int32), ('upsample_initial_channel', c_int32), ('n_ups', c_int32),
                 ('upsample_rates', c_int32 * 8), ('upsample_kernel_sizes', c_int32 * 8), ('n_kernels', c_int32),
                 ('resblock_kernel_sizes', c_int32 * 8), ('n_dil', c_int32), ('resblock_dilations', (c_int32 * 4) * 8),
-                ('weight_norm', c_int32), ('use_nsf', c_int32), ('sample_rate', c_int32), ('harmonic_num', c_int32)]
+                ('weight_norm', c_int32), ('use_nsf', c_int32), ('sample_rate', c_int32), ('harmonic_num', c_int32),
+                ('resblock', c_int32)]
 
 
 class PitchextCfg(Structure):
@@ -60,6 +61,8 @@ _SIGS = {
                                   c_int32, c_int32, c_int32, c_void_p]),
     'bsg_plms_sample': (c_int32, [c_void_p, POINTER(Schedule), c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_ddpm_step': (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(Schedule), c_int32, c_int64, c_uint64, c_uint64, c_void_p]),
+    'bsg_plms_step': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, POINTER(Schedule), c_int32, c_int32,
+                                c_int64, c_void_p]),
     'bsg_fftden_n_weights': (c_int32, [c_int32]),
     'bsg_fftden_create': (c_int32, [POINTER(c_void_p), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p), c_int32,
                                     c_void_p, c_void_p, c_void_p]),

@@ -2384,3 +2384,27 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   }
   return dual_join(h, n_sub, st, rc);
 }
+
+// One PLMS update given the noise predictions (p_sample_plms :168-201 without the denoiser calls), for denoisers that are not a
+// bsg_diffnet (ABI v5): x_out = x + x_delta(eps') with eps' the multistep blend of e0 (newest) and the n_hist <= 3 older predictions
+// e1..e3 (NULL beyond n_hist):  n_hist = 0, avg = 0: eps' = e0 (the predictor half-step of the first iteration);  n_hist = 1, avg = 1:
+// (e0 + e1) / 2 (its corrector);  n_hist = 1: (3 e0 - e1) / 2;  2: (23 e0 - 16 e1 + 5 e2) / 12;  3: (55 e0 - 59 e1 + 37 e2 - 9 e3) / 24.
+extern "C" int bsg_plms_step(const float* x, float* x_out, const float* e0, const float* e1, const float* e2, const float* e3, int32_t n_hist,
+                             int32_t avg, const bsg_schedule* s, int32_t t, int32_t t_prev, int64_t n, void* stream) {
+  TRY(check_schedule(s, "plms_step", true));
+  BSG_REQUIRE(x && x_out && e0 && n > 0 && n_hist >= 0 && n_hist <= 3 && t >= 0 && t < s->num_timesteps && t_prev >= 0 && t_prev <= t,
+              "plms_step: bad argument");
+  BSG_REQUIRE((n_hist < 1 || e1) && (n_hist < 2 || e2) && (n_hist < 3 || e3), "plms_step: %d history tensors expected", n_hist);
+  PlmsCoef c{};
+  c.a_t = s->alphas_cumprod[t];
+  c.a_prev = s->alphas_cumprod[t_prev];
+  c.inv = 1.f;
+  if (n_hist == 1 && avg) { c.w0 = 1.f; c.inv = 2.f; }
+  else if (n_hist == 1) { c.w0 = 3.f; c.inv = 2.f; }
+  else if (n_hist == 2) { c.w0 = 23.f; c.w1 = -16.f; c.w2 = 5.f; c.inv = 12.f; }
+  else if (n_hist == 3) { c.w0 = 55.f; c.w1 = -59.f; c.w2 = 37.f; c.w3 = -9.f; c.inv = 24.f; }
+  hipLaunchKernelGGL(plms_step_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, x_out, e0, n_hist >= 1 ? e1 : nullptr,
+                     n_hist >= 2 ? e2 : nullptr, n_hist >= 3 ? e3 : nullptr, c, (long long)n);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}

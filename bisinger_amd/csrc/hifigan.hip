@@ -1123,9 +1123,10 @@ int launch_pair(const PairArgs& a, int K, int C, int B, hipStream_t st) {
 int launch_conv(const ConvArgs& a, int K, int B, hipStream_t st) {
   switch (K) {
     case 3: return launch_conv_k<3>(a, B, st);
+    case 5: return launch_conv_k<5>(a, B, st);      // ResBlock2 configurations (HiFi-GAN V3: kernels 3, 5, 7)
     case 7: return launch_conv_k<7>(a, B, st);
     case 11: return launch_conv_k<11>(a, B, st);
-    default: set_error("hifigan: conv kernel size %d not built (3, 7, 11)", K); return BSG_EINVAL;
+    default: set_error("hifigan: conv kernel size %d not built (3, 5, 7, 11)", K); return BSG_EINVAL;
   }
 }
 
@@ -1260,7 +1261,7 @@ static int pack_convT(bsg_hifigan* h, ConvW& c, int u, hipStream_t st) {
 }
 
 extern "C" int bsg_hifigan_n_weights(const bsg_hifigan_cfg* c) {
-  const int convs = 2 + c->n_ups + 2 * c->n_ups * c->n_kernels * c->n_dil;
+  const int convs = 2 + c->n_ups + (c->resblock == 2 ? 1 : 2) * c->n_ups * c->n_kernels * c->n_dil;
   return convs * (c->weight_norm ? 3 : 2) + (c->use_nsf ? 2 + 2 * c->n_ups : 0);
 }
 
@@ -1277,6 +1278,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   BSG_REQUIRE(cfg->n_ups > 0 && cfg->n_ups <= 8 && cfg->n_kernels > 0 && cfg->n_kernels <= 8 && cfg->n_dil > 0 && cfg->n_dil <= 4,
               "hifigan_create: bad stage counts");
   BSG_REQUIRE(cfg->n_mel > 0 && cfg->upsample_initial_channel >= (1 << cfg->n_ups), "hifigan_create: bad channel config");
+  BSG_REQUIRE(cfg->resblock >= 0 && cfg->resblock <= 2, "hifigan_create: resblock=%d (1 or 2)", cfg->resblock);
   BSG_REQUIRE(!cfg->use_nsf || (cfg->harmonic_num >= 0 && cfg->harmonic_num <= 31 && cfg->sample_rate > 0), "hifigan_create: bad NSF config");
   BSG_REQUIRE(n_weights == bsg_hifigan_n_weights(cfg), "hifigan_create: expected %d weight tensors, got %d",
               bsg_hifigan_n_weights(cfg), n_weights);
@@ -1286,7 +1288,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   }
   for (int j = 0; j < cfg->n_kernels; ++j) {
     const int k = cfg->resblock_kernel_sizes[j];
-    BSG_REQUIRE(k == 3 || k == 7 || k == 11, "hifigan_create: resblock kernel %d not built (3, 7, 11)", k);
+    BSG_REQUIRE(k == 3 || k == 7 || k == 11 || (k == 5 && cfg->resblock == 2), "hifigan_create: resblock kernel %d not built (3, 7, 11; 5 with ResBlock2)", k);
     for (int m = 0; m < cfg->n_dil; ++m)
       BSG_REQUIRE(cfg->resblock_dilations[j][m] >= 1 && cfg->resblock_dilations[j][m] <= 16, "hifigan_create: dilation out of range");
   }
@@ -1337,16 +1339,16 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   }
   const int nrb = cfg->n_ups * cfg->n_kernels;
   h->rb1.resize((size_t)nrb * cfg->n_dil);
-  h->rb2.resize((size_t)nrb * cfg->n_dil);
+  if (cfg->resblock != 2) h->rb2.resize((size_t)nrb * cfg->n_dil);
   for (int r = 0; r < nrb; ++r) {
     const int ch = C0 >> (r / cfg->n_kernels + 1);
     const int k = cfg->resblock_kernel_sizes[r % cfg->n_kernels];
-    for (int pass = 0; pass < 2; ++pass)
+    for (int pass = 0; pass < (cfg->resblock == 2 ? 1 : 2); ++pass)
       for (int m = 0; m < cfg->n_dil; ++m) {
         ConvW& c = (pass == 0 ? h->rb1 : h->rb2)[(size_t)r * cfg->n_dil + m];
         c.cin = c.cout = ch; c.k = k;
         if ((rc = take_conv(h, c, w, ch, ch * k, st)) != BSG_OK) return fail(rc);
-        if ((rc = pack_conv(h, c, st, true)) != BSG_OK) return fail(rc);
+        if ((rc = pack_conv(h, c, st, cfg->resblock != 2)) != BSG_OK) return fail(rc);   // (the fused pair forms are ResBlock1's)
       }
   }
   h->post.cout = 1; h->post.cin = C0 >> cfg->n_ups; h->post.k = 7;
@@ -1442,8 +1444,15 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
       for (int m = 0; m < c.n_dil; ++m) {
         const bool last = m == c.n_dil - 1;
         const ConvW& c1 = h->rb1[(size_t)r * c.n_dil + m];
-        const ConvW& c2 = h->rb2[(size_t)r * c.n_dil + m];
         float* dst = last ? sum : (y == ya ? yb : ya);
+        if (c.resblock == 2) {
+          // ResBlock2 (hifigan.py:70-91): x = conv_d(lrelu(x)) + x per dilation; the MRF sum / mean in the last one's epilogue (:161-167)
+          TRY(run_conv(c1, y, dst, B, L, c.resblock_dilations[j][m], slope, y, (last && j > 0) ? sum : nullptr,
+                       (last && j == c.n_kernels - 1) ? (float)c.n_kernels : 1.0f, 0, st));
+          y = dst;
+          continue;
+        }
+        const ConvW& c2 = h->rb2[(size_t)r * c.n_dil + m];
         static int fused_env = -1;
         if (fused_env < 0) { const char* e = getenv("BSG_HG_FUSED"); fused_env = e ? atoi(e) : 1; }
         // fused pair (one HBM round trip instead of two and a half) unless the launch would leave most CUs without a workgroup

@@ -118,18 +118,44 @@ class GaussianDiffusion(nn.Module):
         t = self.K_step
         from .diffnet import DiffNet
         if not isinstance(self.denoise_fn, DiffNet):
-            # any other denoise_fn (DIFF_DECODERS['fft']): the reference loop (:265-267) step by step
-            if hparams.get('pndm_speedup'):
-                raise NotImplementedError('PLMS is fused with the wavenet denoiser only')
+            # any other denoise_fn (DIFF_DECODERS['fft']): the reference loops (:258-267) step by step — the denoiser through its own
+            # kernels, the update of x through the generic step entries (bsg_ddpm_step / bsg_plms_step)
             n = t if n_steps is None else n_steps
             capturing = torch.cuda.is_current_stream_capturing()
             keep = None if capturing else x.clone()
+            interval = int(hparams.get('pndm_speedup') or 0)
+
+            def tt(i):
+                return torch.full((B,), i, device=x.device, dtype=torch.long)
+
+            def loop_plms():
+                # p_sample_plms (:168-201): a 4-deep history of the noise predictions; the first iteration is a predictor / corrector
+                # pair (two evaluations).  Batched semantics as bsg_plms_sample's: t - interval clamps at 0 per element
+                hist = []                                  # newest first
+                with torch.cuda.device(x.device):
+                    for i in reversed(range(0, t, interval)):
+                        ip = max(i - interval, 0)
+                        e0 = self.denoise_fn(x, tt(i), cond).contiguous()
+                        if not hist:
+                            xp = torch.empty_like(x)
+                            _lib.check(lib.bsg_plms_step(_lib.ptr(x), _lib.ptr(xp), _lib.ptr(e0), None, None, None, 0, 0, byref(s), i, ip,
+                                                         x.numel(), _lib.stream_ptr()), 'bsg_plms_step')
+                            e1 = self.denoise_fn(xp, tt(ip), cond).contiguous()
+                            _lib.check(lib.bsg_plms_step(_lib.ptr(x), _lib.ptr(x), _lib.ptr(e0), _lib.ptr(e1), None, None, 1, 1, byref(s), i, ip,
+                                                         x.numel(), _lib.stream_ptr()), 'bsg_plms_step')
+                        else:
+                            h = hist + [None] * (3 - len(hist))
+                            _lib.check(lib.bsg_plms_step(_lib.ptr(x), _lib.ptr(x), _lib.ptr(e0), _lib.ptr(h[0]), _lib.ptr(h[1]), _lib.ptr(h[2]),
+                                                         len(hist), 0, byref(s), i, ip, x.numel(), _lib.stream_ptr()), 'bsg_plms_step')
+                        hist = [e0] + hist[:2]
 
             def loop():
+                if interval:
+                    return loop_plms()
                 with torch.cuda.device(x.device):
                     for k in range(n):
                         i = t - 1 - k
-                        eps = self.denoise_fn(x, torch.full((B,), i, device=x.device, dtype=torch.long), cond)
+                        eps = self.denoise_fn(x, tt(i), cond)
                         nz = None if noise is None else noise[k].contiguous()
                         _lib.check(lib.bsg_ddpm_step(_lib.ptr(x), _lib.ptr(eps.contiguous()), _lib.ptr(nz), byref(s), i, x.numel(), seed,
                                                      row0 * M * T, _lib.stream_ptr()), 'bsg_ddpm_step')

@@ -80,13 +80,24 @@ class ResBlock1(nn.Module):
             c.fold()
 
 
+class ResBlock2(nn.Module):
+    """hifigan.py:70-91 (parameters only): per dilation ONE conv, x = conv_d(lrelu(x)) + x."""
+
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.convs = nn.ModuleList([_WNConv((channels, channels, kernel_size), channels) for _ in dilation])
+
+    def remove_weight_norm(self):
+        for c in self.convs:
+            c.fold()
+
+
 class HifiGanGenerator(nn.Module):
     def __init__(self, h, c_out=1):
         super().__init__()
         self.h = h
         self.use_nsf = bool(h.get('use_pitch_embed'))
-        if str(h['resblock']) != '1':
-            raise NotImplementedError("only resblock: '1' (TB/configs/tts/hifigan.yaml:3) is built")
+        self.resblock = 1 if str(h['resblock']) == '1' else 2      # hifigan.py:117
         assert c_out == 1
         self.num_kernels = len(h['resblock_kernel_sizes'])
         self.num_upsamples = len(h['upsample_rates'])
@@ -113,7 +124,7 @@ class HifiGanGenerator(nn.Module):
         for i in range(len(self.ups)):
             ch = C0 // (2 ** (i + 1))
             for k, d in zip(h['resblock_kernel_sizes'], h['resblock_dilation_sizes']):
-                self.resblocks.append(ResBlock1(h, ch, k, d))
+                self.resblocks.append((ResBlock1 if self.resblock == 1 else ResBlock2)(h, ch, k, d))
         self.conv_post = _WNConv((c_out, ch, 7), c_out)
         self._h = None
         self._h_key = None
@@ -162,6 +173,7 @@ class HifiGanGenerator(nn.Module):
         cfg.use_nsf = int(self.use_nsf)
         cfg.sample_rate = int(h.get('audio_sample_rate', 22050))
         cfg.harmonic_num = self.harmonic_num if self.use_nsf else 0
+        cfg.resblock = self.resblock
         lib = _lib.load()
         assert lib.bsg_hifigan_n_weights(byref(cfg)) == len(ws), (lib.bsg_hifigan_n_weights(byref(cfg)), len(ws))
         arr = (c_void_p * len(ws))(*[p.data_ptr() for p in ws])

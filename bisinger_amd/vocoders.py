@@ -3,7 +3,8 @@
 ``register_vocoder`` / ``get_vocoder_cls(hparams)`` (short name, or the reference's dotted path
 ``vocoders.hifigan.HifiGAN``), ``BaseVocoder.spec2wav(mel[T,80]) -> wav[T*hop]``.  ``HifiGAN`` loads
 ``<vocoder_ckpt>/config.yaml`` + the newest ``model_ckpt_steps_*.ckpt`` (``['state_dict']['model_gen']``, weight-norm
-layout, strict), folds the weight norm and runs the generator on the HIP kernels.  PWG and the spectral
+layout, strict) — or, when there is no config.yaml, the original release's ``config.json`` + ``generator_v1``
+(``['generator']``) — folds the weight norm and runs the generator on the HIP kernels.  PWG and the spectral
 denoiser (vocoder_denoise_c, needs librosa) are out of scope.
 """
 import importlib
@@ -45,13 +46,25 @@ class BaseVocoder:
 
 
 def load_model(config_path, checkpoint_path, device=None):
+    """vocoders/hifigan.py:17-33: `config.yaml` + a trainer checkpoint (['state_dict']['model_gen']), or the layout of the original HiFi-GAN
+    release: `config.json` + `generator_v1` (['generator']).  Strict load in the weight-norm layout, then the fold."""
     from .hifigan import HifiGanGenerator
     device = device or torch.device('cuda')
     ckpt = torch.load(checkpoint_path, map_location='cpu')
-    config = set_hparams(config_path, global_hparams=False, print_hparams=False)
-    config.setdefault('use_pitch_embed', False)
+    if '.yaml' in config_path:
+        config = set_hparams(config_path, global_hparams=False, print_hparams=False)
+        state = ckpt['state_dict']['model_gen']
+    elif '.json' in config_path:
+        import json
+        config = json.load(open(config_path, 'r'))
+        state = ckpt['generator']
+        if 'audio_sample_rate' not in config and 'sampling_rate' in config:      # the release's key; only the NSF source reads it
+            config['audio_sample_rate'] = config['sampling_rate']
+    else:
+        raise ValueError(f'{config_path}: expected config.yaml or config.json')
+    config.setdefault('use_pitch_embed', False)       # absent from both config chains; the reference reads it unconditionally (hifigan.py:111)
     model = HifiGanGenerator(config)
-    model.load_state_dict(ckpt['state_dict']['model_gen'], strict=True)
+    model.load_state_dict(state, strict=True)
     model = model.eval().to(device)
     model.remove_weight_norm()
     print(f'| Loaded model parameters from {checkpoint_path}.')
@@ -63,9 +76,14 @@ class HifiGAN(BaseVocoder):
     def __init__(self, device=None):
         base_dir = hparams['vocoder_ckpt']
         config_path = f'{base_dir}/config.yaml'
-        ckpt = latest_ckpt(base_dir)
-        assert os.path.exists(config_path) and ckpt, f'no HiFi-GAN checkpoint under {base_dir}'
-        print('| load HifiGAN: ', ckpt)
+        if os.path.exists(config_path):                                   # vocoders/hifigan.py:41-47
+            ckpt = latest_ckpt(base_dir)
+            assert ckpt, f'no model_ckpt_steps_*.ckpt under {base_dir}'
+            print('| load HifiGAN: ', ckpt)
+        else:                                                             # :48-52: the original release's files
+            config_path, ckpt = f'{base_dir}/config.json', f'{base_dir}/generator_v1'
+            assert os.path.exists(config_path) and os.path.exists(ckpt), f'no HiFi-GAN checkpoint under {base_dir}'
+            print('| load HifiGAN: ', ckpt)
         self.model, self.config, self.device = load_model(config_path, ckpt, device)
 
     def spec2wav(self, mel, **kwargs):

@@ -118,6 +118,14 @@ int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float
 int bsg_ddpm_step(float* x, const float* eps, const float* noise, const bsg_schedule* s, int32_t t, int64_t n,
                   uint64_t seed, uint64_t offset, void* stream);
 
+/* One PLMS update given the noise predictions (p_sample_plms :168-201 without the denoiser calls; ABI v5), for denoisers that are not a
+ * bsg_diffnet — DIFF_DECODERS['fft'] under pndm_speedup: x_out = x + x_delta(eps'), eps' = the multistep blend of e0 (the newest prediction)
+ * with the n_hist <= 3 older ones e1..e3 (NULL beyond n_hist): n_hist 0: e0 (the predictor half-step of the first iteration); n_hist 1 with
+ * avg: (e0 + e1) / 2 (its corrector); 1: (3 e0 - e1) / 2; 2: (23 e0 - 16 e1 + 5 e2) / 12; 3: (55 e0 - 59 e1 + 37 e2 - 9 e3) / 24.
+ * alphas_cumprod at t and t_prev = max(t - interval, 0).  x_out may alias x. */
+int bsg_plms_step(const float* x, float* x_out, const float* e0, const float* e1, const float* e2, const float* e3, int32_t n_hist,
+                  int32_t avg, const bsg_schedule* s, int32_t t, int32_t t_prev, int64_t n, void* stream);
+
 /* x[0..n) <- N(0,1) from the same Philox4x32-10 stream family: element i = lane i%4 of counter
  * ((offset+i)/4, stream_id, 0, 0), key = seed (x_T under gaussian_start uses stream_id 0, the step with
  * timestep i uses stream_id i+1).  n and offset must be multiples of 4. */
@@ -290,7 +298,7 @@ typedef struct {
   int32_t n_ups;                      /* len(h['upsample_rates'])                                        */
   int32_t upsample_rates[8];
   int32_t upsample_kernel_sizes[8];
-  int32_t n_kernels;                  /* len(h['resblock_kernel_sizes']); kernels must be 3, 7 or 11     */
+  int32_t n_kernels;                  /* len(h['resblock_kernel_sizes']); kernels must be 3, 5, 7 or 11  */
   int32_t resblock_kernel_sizes[8];
   int32_t n_dil;                      /* dilations per ResBlock1 (3)                                     */
   int32_t resblock_dilations[8][4];
@@ -298,11 +306,13 @@ typedef struct {
   int32_t use_nsf;                    /* h['use_pitch_embed']: NSF harmonic source (hifigan.py:111-132)   */
   int32_t sample_rate;                /* h['audio_sample_rate'] (NSF only)                               */
   int32_t harmonic_num;               /* 8 (hifigan.py:112)                                              */
+  int32_t resblock;                   /* ABI v5: h['resblock']: 1 = ResBlock1 (hifigan.py:30-52), 2 = ResBlock2 (:70-91: per dilation
+                                         ONE conv, x = conv_d(lrelu(x)) + x; 0 reads as 1)                   */
 } bsg_hifigan_cfg;
 
 int bsg_hifigan_n_weights(const bsg_hifigan_cfg* cfg);
 /* dev_weights in HifiGanGenerator.state_dict() order: conv_pre, ups.i, resblocks.r.convs1.m (all m), then
- * resblocks.r.convs2.m, ..., conv_post; each conv contributes (bias, weight) — the layout after
+ * resblocks.r.convs2.m (ResBlock2: resblocks.r.convs.m only), ..., conv_post; each conv contributes (bias, weight) — the layout after
  * remove_weight_norm() — or (bias, weight_g, weight_v) when cfg->weight_norm (checkpoint layout; folded here
  * as w = g * v / ||v||, norm over dims != 0).  Synchronises `stream` before returning. */
 int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg, const void* const* dev_weights,

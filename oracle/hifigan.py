@@ -1,7 +1,7 @@
 """HiFi-GAN generator forward — CPU oracle.
 
 Follows /root/reference/train_bisinger/modules/hifigan/hifigan.py:
-  ResBlock1.forward :54-61, HifiGanGenerator.__init__ :105-142, forward :144-173
+  ResBlock1.forward :54-61, ResBlock2.forward :83-87, HifiGanGenerator.__init__ :105-142, forward :144-173
   (note the default-slope 0.01 leaky_relu before conv_post, :169), remove_weight_norm :175-182.
 Config: TB/configs/tts/hifigan.yaml:3-10.  NSF (use_pitch_embed) is SURVEY.md §8 row f2 (next).
 """
@@ -48,6 +48,9 @@ def hifigan_forward(sd, mel, cfg=None, prefix='', dtype=torch.float32):
             y = x
             for m, d in enumerate(dil):
                 xt = F.leaky_relu(y, LRELU_SLOPE)
+                if str(cfg['resblock']) != '1':      # ResBlock2.forward :83-87: one conv per dilation
+                    y = F.conv1d(xt, g(f'{p}convs.{m}.weight'), g(f'{p}convs.{m}.bias'), dilation=d, padding=(ks * d - d) // 2) + y
+                    continue
                 xt = F.conv1d(xt, g(f'{p}convs1.{m}.weight'), g(f'{p}convs1.{m}.bias'),
                               dilation=d, padding=(ks * d - d) // 2)
                 xt = F.leaky_relu(xt, LRELU_SLOPE)

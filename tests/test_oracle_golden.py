@@ -289,3 +289,25 @@ def test_bf16_emulation_noise_floor(gd_sd):
     cost, floor = rms(e32, f32), rms(e64, e32)
     assert 2e-4 < cost < 3e-3
     assert 0.3 * cost < floor < 1.5 * cost
+
+
+def test_r4_resblock2_and_plms_over_the_fft_denoiser(gold, sd_spec):
+    """Round 4 fixtures (tools/make_golden_r4.py, reference outputs): HifiGanGenerator with ResBlock2 (hifigan.py:70-91) and the PLMS loop
+    over DIFF_DECODERS['fft'] (shallow_diffusion_tts.py:168-201 with candidate_decoder.FFT as denoise_fn) pin the oracle's restatements."""
+    from collections import OrderedDict
+    from bisinger_amd import synth
+    from oracle import candidate_decoder as ocd, diffusion as odf, hifigan as ohg
+    g = gold('r4')
+    spec = OrderedDict((k, tuple(s)) for k, s in sd_spec['HifiGanGenerator_rb2_weight_norm'])
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, 27).items()}
+    rs = np.random.RandomState(31)
+    mel = (rs.standard_normal((2, 80, 37)) * 1.5 - 3.0).astype(np.float32)
+    y = ohg.hifigan_forward(sd, torch.from_numpy(mel), sd_spec['hifigan_rb2_cfg'])
+    assert float((y - torch.from_numpy(g['rb2.wav'])).abs().max()) <= 2e-6
+    fspec = OrderedDict((k, tuple(s)) for k, s in sd_spec['FFT'])
+    fsd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(fspec, seed=17).items()}
+    rs = np.random.RandomState(43)
+    cond = torch.from_numpy(rs.standard_normal((1, 256, 40)).astype(np.float32))
+    xT = torch.from_numpy(rs.standard_normal((1, 1, 80, 40)).astype(np.float32))
+    x0 = odf.plms_sample(odf.make_schedule(100, 'linear', 0.06), lambda x_, t_: ocd.fft_denoiser_forward(fsd, x_, t_, cond), xT, 100, 5)
+    assert float((x0 - torch.from_numpy(g['plmsfft.x0'])).abs().max()) <= 5e-5
