@@ -1730,6 +1730,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
+    if (stamps) { const char* e = getenv("BSG_STAMP_MODE"); p.stamp_mode = e ? atoi(e) : 0; }
     if (h2 && h->stack_parts) {
       BSG_REQUIRE(!tail && nb == B, "part launch: whole batch, no fused tail");
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;

@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
           wait_flags(fl, want);
         }
         __syncthreads();   // (D) the polling lanes have seen the flags
-        QUAD_STAMP(1);
+        if (!p.stamp_mode) QUAD_STAMP(1);
         parts_in(xs, XP, HALO, [&](int part) { return ix_slot(l & 1, tile_id, part); });   // the partners' channels of the core frames
         {
           // halo rows, both planes, all channels: rows 0..7 = the left tile's last 8 frames (its edge slot 1), rows NT+8..NT+15 = the right
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
           }
         }
         __syncthreads();   // (A) the whole image is in place
-        QUAD_STAMP(2);
+        if (!p.stamp_mode) QUAD_STAMP(2);
       };
       mfma_pipe_part<true, false, OWN, NC, NSQ, W == 8>(yg, yf, A, rs_a1, rs_a2, vfrag, sa_g, sa_f, 24, OWN * q, dil * ROWQ, xb, XP, mid);
     }
@@ -1504,6 +1504,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
         yf[ct][r] = bs * s2;
       }
     }
+    if (p.stamp_mode) QUAD_STAMP(1);   // gate evaluated, own z in LDS (this wave)
     __syncthreads();   // (Z1) the own quarter of z is complete in LDS; every wave is done reading xs and this layer's biases
 #pragma unroll
     for (int k = 0; k < TPT; ++k)
@@ -1515,6 +1516,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     // partners' L1-bypassing loads are served there at the same-XCD rate; write-through stores would drop them from L2
     // (MI355X_MICROARCH.md, stores of each flavour)
     if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q), std::integral_constant<int, 0>{});
+    if (p.stamp_mode) QUAD_STAMP(2);   // barrier Z1 passed, the z part copied out of LDS (stores issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached L2
     __syncthreads();
     if (tid == 0) {   // the z flag is polled by the partners only (this XCD): a plain store too — it stays in L2, where their polls are served

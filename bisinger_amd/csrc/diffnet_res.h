@@ -66,6 +66,7 @@ struct StackArgs {
   unsigned* epoch;        // null: p.fbase
   int flag_words;         // words of `flags` to zero at a wrap (the status words behind them are not touched)
   int pflag_words;        // the same for `pflags` (part forms)
+  int stamp_mode;         // diagnostics (BSG_STAMP_MODE, part forms): 1 = stamp slots 1 / 2 mark the gate phase's inner boundaries instead of GEMM1's
   int inject;             // fault injection: consumers do not wait
   // part forms of the split-fp16 launch (residual_part_h2_kernel, small batches): exchange of the P channel parts of a tile
   unsigned short* zx;     // [n_tiles][P parts][2 planes][tile frames][C/P] fp16: gated activation parts
