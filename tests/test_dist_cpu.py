@@ -74,7 +74,8 @@ def test_shard_rows_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_bench_starts_its_own_workers_from_a_bare_shell():
+@pytest.mark.parametrize('n', [2, 8])      # 8: the rank count of BASELINE configs[3] (the driver's SCALE run)
+def test_bench_starts_its_own_workers_from_a_bare_shell(n):
     """`python bench.py --gpus N` without torchrun must start N fresh worker processes itself (the parent touches no GPU),
     hand them the torchrun environment and print rank 0's record as the LAST stdout line.  Here: the process-management
     self-test over gloo (no GPU in this container); without --selftest-procs it must refuse cleanly, not hang."""
@@ -83,11 +84,11 @@ def test_bench_starts_its_own_workers_from_a_bare_shell():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--selftest-procs'], env=env,
-                       capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--selftest-procs'], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     last = [l for l in p.stdout.splitlines() if l.strip()][-1]
-    assert json.loads(last) == {'selftest': True, 'n_gpus': 2, 'ranks': [0, 1]}
-    if not torch.cuda.is_available():
+    assert json.loads(last) == {'selftest': True, 'n_gpus': n, 'ranks': list(range(n))}
+    if not torch.cuda.is_available() and n == 2:
         p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and 'GPUs' in p.stderr

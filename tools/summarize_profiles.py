@@ -32,7 +32,7 @@ def short(name):
     return n.split('(')[0].strip()
 
 
-for cfg in ('f32', 'bf16', 'voc'):
+for cfg in ('f32', 'bf16', 'voc', 'voc1', 'rank', 'b1'):
     st = glob.glob(f'{src}/{cfg}/stats/*/*_kernel_stats.csv')
     avg_us = {}
     if st:
@@ -110,6 +110,15 @@ for cfg in ('f32', 'bf16', 'voc'):
                            'unit': 'one layer over the whole batch (launch bytes x launch groups / 20)' if path.startswith('stack') else 'one launch',
                            'condition': 'solo launch (PMC passes serialise kernels)'}
         break
+    if cfg == 'voc1':
+        # HBM-side bytes of ONE vocoder forward at B = 1, T = 1000: sum over the kernels of (mean bytes per launch x launches) / forwards
+        # (tools/prof_vocoder.py runs PN = 5 forwards per pass) -> profiles/traffic_voc.json, read by bench.py's configs[4] roofline
+        fw = 5
+        tot = sum(e['hbm_bytes_per_launch'] * out[k]['FETCH_SIZE']['n'] for k, e in per_kernel.items() if 'hbm_bytes_per_launch' in e and k in out)
+        json.dump({'B': 1, 'T': 1000, 'forwards': fw, 'hbm_bytes_per_forward': tot / fw, 'build_sha256': BUILD,
+                   'algorithmic_bytes_per_forward': 80 * 1000 * 4 + 256000 * 4,
+                   'source': 'bench_voc1_pmc_summary.json of the same passes (tools/run_profiles.sh): 2 x FETCH_SIZE + WRITE_SIZE over every launch'},
+                  open(f'{dst}/traffic_voc.json', 'w'), indent=1)
     json.dump(summ, open(f'{dst}/bench_{cfg}_pmc_summary.json', 'w'), indent=1)
     if 'traffic' in summ and cfg in ('f32', 'bf16'):   # what bench.py reads (profiles/traffic.json, profiles/traffic_bf16.json)
         json.dump(dict(summ['traffic'], source=f'bench_{cfg}_pmc_summary.json of the same passes (tools/run_profiles.sh)'),
