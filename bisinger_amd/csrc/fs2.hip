@@ -387,6 +387,246 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_split_kernel(const floa
 }
 
 // ---- token embeddings ----------------------------------------------------------------------------
+constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80) + 2 * 32 * 4;   // flash_attn_planes_kernel: two K | V^T buffers + keep flags = 76 032 B
+// ---- round 4: the fused attention on PRE-SPLIT operands -------------------------------------------------------------------------------
+// flash_attn_split_kernel splits K and V while it stages every 32-key block — and transposes V with 2-byte LDS writes — once per 64 or 128
+// queries: at T = 1000 a K / V element is split 8-16 times, between two barriers and with its global loads exposed.  Here
+// qkv_split_kernel splits the QKV projection's output ONCE into fp16 planes — Q and K as [row][256] (hi, lo), V TRANSPOSED as
+// [b][256 (head, d)][Tp keys] (Tp = T rounded up to 32, the padding zeroed) — and flash_attn_planes_kernel stages a key block as plain
+// 16-byte copies into a second LDS buffer while the MFMAs of the current one run: one barrier per block, no vector arithmetic in the
+// staging.  Same arithmetic, fragments and key order as flash_attn_split_kernel (its comment above).
+__global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, _Float16* __restrict__ qk, long long qk_plane,
+                                                        _Float16* __restrict__ vt, long long vt_plane, int T, int Tp,
+                                                        unsigned* __restrict__ range_events) {
+  __shared__ __attribute__((aligned(16))) _Float16 vh[32][H + 8], vl[32][H + 8];   // the tile's V rows for the transpose
+  const int b = blockIdx.y, t0 = blockIdx.x * 32, tid = threadIdx.x;
+  bool bad = false;
+  // Q | K: 32 rows x 512 columns, 8 values per item -> [row][512] planes (Q = columns 0..255, K = 256..511)
+  for (int it = tid; it < 32 * 96; it += 256) {
+    const int r = it / 96, c8 = (it - r * 96) * 8, t = t0 + r;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = a;
+    if (t < T) {
+      const float* p = qkv + ((long long)b * T + t) * (3 * H) + c8;
+      a = *reinterpret_cast<const f32x4*>(p);
+      c = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (e < 4 ? a[e] : c[e - 4]) * 16.0f;
+      bad |= !(fabsf(x) < 65000.0f);
+      h[e] = (_Float16)x;
+      l[e] = (_Float16)(x - (float)h[e]);
+    }
+    if (c8 < 2 * H) {
+      if (t < T) {
+        _Float16* d = qk + ((long long)b * T + t) * (2 * H) + c8;
+        *reinterpret_cast<f16x8*>(d) = h;
+        *reinterpret_cast<f16x8*>(d + qk_plane) = l;
+      }
+    } else {
+      *reinterpret_cast<f16x8*>(&vh[r][c8 - 2 * H]) = h;      // rows t >= T: zeros
+      *reinterpret_cast<f16x8*>(&vl[r][c8 - 2 * H]) = l;
+    }
+  }
+  __syncthreads();
+  // V^T: thread = one (head, d) row, 32 keys = 64 bytes per plane
+  {
+    const int d = tid;
+    _Float16 th[32], tl[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { th[r] = vh[r][d]; tl[r] = vl[r][d]; }
+    _Float16* dst = vt + ((long long)b * H + d) * Tp + t0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<f16x8*>(dst + 8 * g) = f16x8{th[8 * g], th[8 * g + 1], th[8 * g + 2], th[8 * g + 3], th[8 * g + 4], th[8 * g + 5], th[8 * g + 6], th[8 * g + 7]};
+      *reinterpret_cast<f16x8*>(dst + vt_plane + 8 * g) = f16x8{tl[8 * g], tl[8 * g + 1], tl[8 * g + 2], tl[8 * g + 3], tl[8 * g + 4], tl[8 * g + 5], tl[8 * g + 6], tl[8 * g + 7]};
+    }
+  }
+  if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && (tid & 63) == 0) atomicAdd(range_events, 1u);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_planes_kernel(const _Float16* __restrict__ qk, long long qk_plane,
+                                                                       const _Float16* __restrict__ vt, long long vt_plane,
+                                                                       const float* __restrict__ keep, int T, int Tp, int heads,
+                                                                       _Float16* __restrict__ out_h, long long out_plane, int ldo,
+                                                                       unsigned* __restrict__ range_events) {
+  constexpr int D = 128, BK = 32, KROW = 2 * D + 16, VROW = 2 * BK + 16;   // bytes per LDS row: 272 (68 dwords = 4 mod 64), 80
+  constexpr int KB = 2 * BK * KROW, VB = 2 * D * VROW, STAGE = KB + VB;    // one buffer: K hi | K lo | V^T hi | V^T lo
+  constexpr int NTH = 64 * NW, NPC = 1024 / NTH;                           // 16-byte pieces of a block's K (or V^T) per thread
+  constexpr float SIN = 16.0f, PSC = 1024.0f;
+  extern __shared__ __attribute__((aligned(16))) char fl[];                // [2 buffers][STAGE] + keep flags [2][BK]
+  float* kpf = reinterpret_cast<float*>(fl + 2 * STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y / heads, hh = blockIdx.y - b * heads;
+  const int q_row = (blockIdx.x * NW + wave) * 32 + l31;
+  const bool q_ok = q_row < T;
+  const _Float16* __restrict__ qkb = qk + (long long)b * T * (2 * H) + hh * D;          // Q of this head; K at + H
+  const _Float16* __restrict__ vtb = vt + ((long long)b * H + hh * D) * Tp;
+  f16x8 qh[8], ql[8];   // d = 16 s + 8 lh + 0..7
+  {
+    const _Float16* qp = qkb + (long long)(q_ok ? q_row : T - 1) * (2 * H) + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      qh[s] = *reinterpret_cast<const f16x8*>(qp + 16 * s);
+      ql[s] = *reinterpret_cast<const f16x8*>(qp + 16 * s + qk_plane);
+    }
+  }
+  // staging: K of a block = 1024 16-byte pieces (plane p >> 9, key (p >> 4) & 31, chunk p & 15), V^T likewise (plane p >> 9, row d = (p >> 2) & 127,
+  // chunk p & 3).  One register set serves both: K of the next block is in flight under the barrier and the Q K^T MFMAs, V^T of the next block
+  // under the softmax and the P V MFMAs.
+  u32x4_t st[NPC];
+  auto load_k = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int p = tid + NTH * j, pl = p >> 9, key = (p >> 4) & 31, ch = p & 15, kt = k0 + key;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (kt < T) v = *reinterpret_cast<const u32x4_t*>(qkb + (long long)kt * (2 * H) + H + 8 * ch + (pl ? qk_plane : 0));
+      st[j] = v;
+    }
+  };
+  auto store_k = [&](int buf, int k0) {
+    char* sb = fl + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int p = tid + NTH * j, pl = p >> 9, key = (p >> 4) & 31, ch = p & 15;
+      *reinterpret_cast<u32x4_t*>(sb + pl * BK * KROW + key * KROW + 16 * ch) = st[j];
+    }
+    if (tid < BK) kpf[buf * BK + tid] = (k0 + tid < T) ? keep[(long long)b * T + k0 + tid] : 0.f;
+  };
+  auto load_v = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int p = tid + NTH * j, pl = p >> 9, d = (p >> 2) & 127, ch = p & 3;
+      st[j] = *reinterpret_cast<const u32x4_t*>(vtb + (long long)d * Tp + k0 + 8 * ch + (pl ? vt_plane : 0));   // k0 + 32 <= Tp: padded, zeroed
+    }
+  };
+  auto store_v = [&](int buf) {
+    char* sb = fl + buf * STAGE + KB;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int p = tid + NTH * j, pl = p >> 9, d = (p >> 2) & 127, ch = p & 3;
+      *reinterpret_cast<u32x4_t*>(sb + pl * D * VROW + d * VROW + 16 * ch) = st[j];
+    }
+  };
+  f32x16 O[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  load_k(0);
+  store_k(0, 0);
+  load_v(0);
+  store_v(0);
+  if (BK < T) load_k(BK);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < T; k0 += BK, cur ^= 1) {
+    const char* Kp = fl + cur * STAGE;
+    const char* Vp = Kp + KB;
+    const float* kp = kpf + cur * BK;
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    {
+      const char* kr = Kp + l31 * KROW + 16 * lh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(kr + 32 * s);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(kr + 32 * s + BK * KROW);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], S, 0, 0, 0);
+      }
+    }
+    // the next block's K goes to the other buffer (every wave finished reading it before the barrier that ended the previous iteration)
+    const bool more = k0 + BK < T;
+    if (more) {
+      store_k(cur ^ 1, k0 + BK);
+      load_v(k0 + BK);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] *= 1.0f / (SIN * SIN);
+      if (kp[acc_row(r, lh)] == 0.f) S[r] = -INFINITY;
+      mx = fmaxf(mx, S[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float ms = m_new == -INFINITY ? 0.f : m_new;     // a block of masked keys only must not produce inf - inf
+    const float scale = expf(m - ms);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = expf(S[r] - ms);
+      ps += S[r];
+    }
+    ps += __shfl_xor(ps, 32);
+    l = l * scale + ps;
+    m = m_new;
+    f16x8 ph[2], pl[2];   // step t: registers 8t .. 8t+7 = keys 16 t + 4 lh + (j & 3) + 8 (j >> 2)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = S[8 * t + j] * PSC;
+        ph[t][j] = (_Float16)x;
+        pl[t][j] = (_Float16)(x - (float)ph[t][j]);
+      }
+    const bool rescale = __any(scale != 1.0f);   // wave-uniform: once the running maxima have settled nothing is rescaled
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (rescale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] *= scale;
+      }
+      const char* vr = Vp + (32 * dt + l31) * VROW + 8 * lh;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u32x2_t h0 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t), h1 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + 16);
+        const u32x2_t l0 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + D * VROW), l1 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + 16 + D * VROW);
+        const f16x8 ah = __builtin_bit_cast(f16x8, u32x4_t{h0[0], h0[1], h1[0], h1[1]});
+        const f16x8 al = __builtin_bit_cast(f16x8, u32x4_t{l0[0], l0[1], l1[0], l1[1]});
+        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph[t], O[dt], 0, 0, 0);
+        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl[t], O[dt], 0, 0, 0);
+        O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph[t], O[dt], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_v(cur ^ 1);
+      if (k0 + 2 * BK < T) load_k(k0 + 2 * BK);
+    }
+    __syncthreads();   // this block is consumed; the next one is complete in the other buffer
+  }
+  bool bad = false;
+  if (q_ok) {
+    // the attention output is read by the output projection only: hi / lo fp16 planes of 16 x value (registers 4 g .. 4 g + 3 of a lane are 4
+    // consecutive d: one 8-byte store per plane)
+    const float inv = 1.0f / (l * SIN * PSC);
+    _Float16* __restrict__ oph = out_h + ((long long)b * T + q_row) * ldo + hh * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f16x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = O[dt][4 * gq + e] * inv * SIN;
+          bad |= !(fabsf(x) < 65000.0f);
+          hv[e] = (_Float16)x;
+          lv[e] = (_Float16)(x - (float)hv[e]);
+        }
+        *reinterpret_cast<f16x4*>(oph + 32 * dt + 8 * gq + 4 * lh) = hv;
+        *reinterpret_cast<f16x4*>(oph + out_plane + 32 * dt + 8 * gq + 4 * lh) = lv;
+      }
+  }
+  if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(range_events, 1u);
+}
+
 // x0 = sqrt(H) * E_tok[txt]; lang_e = E_lang[lang]                      (diffsinger_midi/fs2.py:28,122)
 __global__ void embed_tokens_kernel(const long long* __restrict__ txt, const long long* __restrict__ lang,
                                     const float* __restrict__ Etok, const float* __restrict__ Elang, float* __restrict__ x0,
@@ -865,11 +1105,31 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
     // GELU epilogue of the FFN convolution) — no kernel splits an operand while it stages it.  Same arithmetic as the path below.
     unsigned short* ap = h->w_ap;   // [2][rows][H]
     unsigned short* fp = h->w_fp;   // [2][rows][4H]
+    static int fplanes = -1;        // BSG_FLASH_PLANES=0: flash_attn_split_kernel (K / V split while staged) instead of the pre-split attention
+    if (fplanes < 0) {
+      const char* e = getenv("BSG_FLASH_PLANES");
+      fplanes = e ? atoi(e) : 1;
+      if (fplanes && (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_planes_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FLP_LDS) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_planes_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FLP_LDS) != hipSuccess)) {
+        (void)hipGetLastError();
+        fplanes = 0;
+      }
+    }
+    const int Tp = cdiv(T, 32) * 32;
     for (const FftLayerW& L : layers) {
       TRY(ln_planes(x, L.ln1w, L.ln1b, ap, rows, 1e-5f, st));
       TRY(linear_h2w(ap, L.p_in, 3 * H, nullptr, h->w_qkv, nullptr, rows, ACT_NONE, nullptr, nullptr, st, qscale, H));
       const long long wg4 = (long long)cdiv(T, 128) * B * heads;
-      if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
+      if (fplanes && Tp <= 4 * T) {
+        // Q | K planes [2][rows][2H] in the (not yet written) FFN planes buffer, V^T planes [2][B][H][Tp] in the fp32 FFN buffer this path does not use
+        _Float16* qk = reinterpret_cast<_Float16*>(fp);
+        _Float16* vt = reinterpret_cast<_Float16*>(h->w_ffn);
+        const long long vplane = (long long)B * H * Tp;
+        hipLaunchKernelGGL(qkv_split_kernel, dim3(Tp / 32, B), dim3(256), 0, st, (const float*)h->w_qkv, qk, rows * 2 * H, vt, vplane, T, Tp, gemm_range_counter());
+        BSG_LAUNCH_CHECK();
+        if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_planes_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, keep, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter());
+        else hipLaunchKernelGGL(flash_attn_planes_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, keep, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter());
+      } else if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
       else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
       BSG_LAUNCH_CHECK();
       TRY(linear_h2w(ap, L.p_out, H, nullptr, h->w_b, nullptr, rows, ACT_NONE, x, keep, st));   // x1 = (x + attn) * keep
