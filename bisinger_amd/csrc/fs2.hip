@@ -16,6 +16,7 @@
 // and simplicity; the unfused attention materialises the [B*H,T,T] score matrix in HBM.
 #include <math.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "bsg_common.h"
@@ -387,20 +388,31 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_split_kernel(const floa
 }
 
 // ---- token embeddings ----------------------------------------------------------------------------
-constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80) + 2 * 32 * 4;   // flash_attn_planes_kernel: two K | V^T buffers + keep flags = 76 032 B
+constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80);   // flash_attn_planes_kernel: two K and two V^T buffers = 75 776 B
 // ---- round 4: the fused attention on PRE-SPLIT operands -------------------------------------------------------------------------------
 // flash_attn_split_kernel splits K and V while it stages every 32-key block — and transposes V with 2-byte LDS writes — once per 64 or 128
 // queries: at T = 1000 a K / V element is split 8-16 times, between two barriers and with its global loads exposed.  Here
 // qkv_split_kernel splits the QKV projection's output ONCE into fp16 planes — Q and K as [row][256] (hi, lo), V TRANSPOSED as
-// [b][256 (head, d)][Tp keys] (Tp = T rounded up to 32, the padding zeroed) — and flash_attn_planes_kernel stages a key block as plain
-// 16-byte copies into a second LDS buffer while the MFMAs of the current one run: one barrier per block, no vector arithmetic in the
-// staging.  Same arithmetic, fragments and key order as flash_attn_split_kernel (its comment above).
+// [b][256 (head, d)][Tp keys] (Tp = T rounded up to 32, the padding zeroed) — plus one mask word per (utterance, 32-key block), and
+// flash_attn_planes_kernel stages a key block as plain 16-byte copies while the MFMAs of the blocks before it run: K two blocks ahead, V^T one,
+// one barrier per block, no vector arithmetic in the staging, the softmax in the log2 domain (v_exp_f32, the 2^10 of the P operand folded into the
+// exponent), its two cross-half reductions as v_permlane32_swap, blocks whose mask word is all ones skip the masking.  Same products, fragments
+// and key order as flash_attn_split_kernel (its comment above).
+// Measured (T = 1000, decoder layer): 118 -> 95 us at B = 16, 99 -> 69 us at B = 1 against the first planes form (the split-in-kernel form: 270 /
+// 200 us).  PMC of this kernel (profiles/r04_flash_planes_pmc.txt): matrix pipe busy 25 % of the wave cycles, vector issue 29 %, LDS 8 %,
+// s_waitcnt 18 % — the grid is B x heads x T / 32 = 1024 waves at B = 16, ONE wave per SIMD, so nothing hides the in-order dependences of a wave;
+// the next step would be to split the keys of a query tile over two workgroups (twice the waves), not more work on this loop.
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, _Float16* __restrict__ qk, long long qk_plane,
                                                         _Float16* __restrict__ vt, long long vt_plane, int T, int Tp,
+                                                        const float* __restrict__ keep, unsigned* __restrict__ kmask,
                                                         unsigned* __restrict__ range_events) {
   __shared__ __attribute__((aligned(16))) _Float16 vh[32][H + 8], vl[32][H + 8];   // the tile's V rows for the transpose
   const int b = blockIdx.y, t0 = blockIdx.x * 32, tid = threadIdx.x;
   bool bad = false;
+  if (tid < 64) {   // bit j of the tile's mask word: key t0 + j takes part in the softmax (keep != 0, j < T)
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(tid < 32 && t0 + tid < T && keep[(long long)b * T + t0 + tid] != 0.f);
+    if (tid == 0) kmask[b * (Tp / 32) + blockIdx.x] = (unsigned)mk;
+  }
   // Q | K: 32 rows x 512 columns, 8 values per item -> [row][512] planes (Q = columns 0..255, K = 256..511)
   for (int it = tid; it < 32 * 96; it += 256) {
     const int r = it / 96, c8 = (it - r * 96) * 8, t = t0 + r;
@@ -447,17 +459,17 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_planes_kernel(const _Float16* __restrict__ qk, long long qk_plane,
+__global__ __launch_bounds__(64 * NW, 1) void flash_attn_planes_kernel(const _Float16* __restrict__ qk, long long qk_plane,
                                                                        const _Float16* __restrict__ vt, long long vt_plane,
-                                                                       const float* __restrict__ keep, int T, int Tp, int heads,
+                                                                       const unsigned* __restrict__ kmask, int T, int Tp, int heads,
                                                                        _Float16* __restrict__ out_h, long long out_plane, int ldo,
                                                                        unsigned* __restrict__ range_events) {
   constexpr int D = 128, BK = 32, KROW = 2 * D + 16, VROW = 2 * BK + 16;   // bytes per LDS row: 272 (68 dwords = 4 mod 64), 80
-  constexpr int KB = 2 * BK * KROW, VB = 2 * D * VROW, STAGE = KB + VB;    // one buffer: K hi | K lo | V^T hi | V^T lo
+  constexpr int KB = 2 * BK * KROW, VB = 2 * D * VROW;                     // K hi | K lo, V^T hi | V^T lo of one key block
   constexpr int NTH = 64 * NW, NPC = 1024 / NTH;                           // 16-byte pieces of a block's K (or V^T) per thread
-  constexpr float SIN = 16.0f, PSC = 1024.0f;
-  extern __shared__ __attribute__((aligned(16))) char fl[];                // [2 buffers][STAGE] + keep flags [2][BK]
-  float* kpf = reinterpret_cast<float*>(fl + 2 * STAGE);
+  constexpr float SIN = 16.0f;
+  constexpr float C2 = 1.4426950408889634f / (SIN * SIN);                  // scores -> log2 domain (operands carry SIN each)
+  extern __shared__ __attribute__((aligned(16))) char fl[];                // K buffers [2][KB] | V^T buffers [2][VB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y / heads, hh = blockIdx.y - b * heads;
@@ -465,6 +477,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_planes_ke
   const bool q_ok = q_row < T;
   const _Float16* __restrict__ qkb = qk + (long long)b * T * (2 * H) + hh * D;          // Q of this head; K at + H
   const _Float16* __restrict__ vtb = vt + ((long long)b * H + hh * D) * Tp;
+  const unsigned* __restrict__ kmb = kmask + b * (Tp / 32);
   f16x8 qh[8], ql[8];   // d = 16 s + 8 lh + 0..7
   {
     const _Float16* qp = qkb + (long long)(q_ok ? q_row : T - 1) * (2 * H) + 8 * lh;
@@ -475,40 +488,54 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_planes_ke
     }
   }
   // staging: K of a block = 1024 16-byte pieces (plane p >> 9, key (p >> 4) & 31, chunk p & 15), V^T likewise (plane p >> 9, row d = (p >> 2) & 127,
-  // chunk p & 3).  One register set serves both: K of the next block is in flight under the barrier and the Q K^T MFMAs, V^T of the next block
-  // under the softmax and the P V MFMAs.
-  u32x4_t st[NPC];
-  auto load_k = [&](int k0) {
+  // chunk p & 3).  One register set serves both.  The loop is software-pipelined: iteration i forms the scores of block i + 1 (matrix pipe)
+  // while the softmax of block i runs (vector pipe), so K is staged TWO blocks ahead and V^T one:
+  //   iteration i reads K(i+1) from K buffer (i+1)&1 and V^T(i) from V buffer i&1, writes K(i+2) to K buffer i&1 (last read in iteration i-1) and
+  //   V^T(i+1) to V buffer (i+1)&1 (last read in iteration i-1); one barrier per iteration.
+  u32x4_t st[NPC], sv[NPC];
+  // piece j of thread tid: K key (tid >> 4) + KPP j' (j' = j mod NPC/2), chunk tid & 15, plane j / (NPC/2); V^T row (tid >> 2) + VPP j', chunk
+  // tid & 3.  Per thread ONE 32-bit offset each for K, V^T and the two LDS images; everything that depends on j or on the block is wave-uniform.
+  constexpr int KPP = NTH / 16, VPP = NTH / 4, HP = NPC / 2;
+  const unsigned koff = ((tid >> 4) * (2 * H) + (tid & 15) * 8) * 2, kls = (tid >> 4) * KROW + (tid & 15) * 16;
+  const unsigned voff = ((tid >> 2) * Tp + (tid & 3) * 8) * 2, vls = (tid >> 2) * VROW + (tid & 3) * 16;
+  const char* __restrict__ kbase = reinterpret_cast<const char*>(qkb + H);
+  const char* __restrict__ vbase = reinterpret_cast<const char*>(vtb);
+  auto load_k = [&](int k0) {   // rows past T (k0 is clamped to the padded length): the next utterance's keys or stale workspace — their scores are masked
+    k0 = min(k0, Tp - BK);
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      const int p = tid + NTH * j, pl = p >> 9, key = (p >> 4) & 31, ch = p & 15, kt = k0 + key;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (kt < T) v = *reinterpret_cast<const u32x4_t*>(qkb + (long long)kt * (2 * H) + H + 8 * ch + (pl ? qk_plane : 0));
-      st[j] = v;
+      const char* bj = kbase + ((long long)(k0 + KPP * (j % HP)) * (2 * H) + (j / HP ? qk_plane : 0)) * 2;
+      st[j] = *reinterpret_cast<const u32x4_t*>(bj + koff);
     }
   };
-  auto store_k = [&](int buf, int k0) {
-    char* sb = fl + buf * STAGE;
+  auto store_k = [&](int buf) {
+    char* sb = fl + buf * KB + kls;
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
-      const int p = tid + NTH * j, pl = p >> 9, key = (p >> 4) & 31, ch = p & 15;
-      *reinterpret_cast<u32x4_t*>(sb + pl * BK * KROW + key * KROW + 16 * ch) = st[j];
-    }
-    if (tid < BK) kpf[buf * BK + tid] = (k0 + tid < T) ? keep[(long long)b * T + k0 + tid] : 0.f;
+    for (int j = 0; j < NPC; ++j) *reinterpret_cast<u32x4_t*>(sb + (j / HP) * BK * KROW + KPP * (j % HP) * KROW) = st[j];
   };
-  auto load_v = [&](int k0) {
+  auto load_v = [&](int k0) {   // k0 + 32 <= Tp: the planes are padded to Tp keys and the padding is zero
+    k0 = min(k0, Tp - BK);
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      const int p = tid + NTH * j, pl = p >> 9, d = (p >> 2) & 127, ch = p & 3;
-      st[j] = *reinterpret_cast<const u32x4_t*>(vtb + (long long)d * Tp + k0 + 8 * ch + (pl ? vt_plane : 0));   // k0 + 32 <= Tp: padded, zeroed
+      const char* bj = vbase + ((long long)(VPP * (j % HP)) * Tp + k0 + (j / HP ? vt_plane : 0)) * 2;
+      sv[j] = *reinterpret_cast<const u32x4_t*>(bj + voff);
     }
   };
   auto store_v = [&](int buf) {
-    char* sb = fl + buf * STAGE + KB;
+    char* sb = fl + 2 * KB + buf * VB + vls;
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
-      const int p = tid + NTH * j, pl = p >> 9, d = (p >> 2) & 127, ch = p & 3;
-      *reinterpret_cast<u32x4_t*>(sb + pl * D * VROW + d * VROW + 16 * ch) = st[j];
+    for (int j = 0; j < NPC; ++j) *reinterpret_cast<u32x4_t*>(sb + (j / HP) * D * VROW + VPP * (j % HP) * VROW) = sv[j];
+  };
+  auto scores = [&](int buf, f32x16& S) {   // S[key][query] = sum_d K Q, 3 fp16 products per fp32 product
+    const char* kr = fl + buf * KB + l31 * KROW + 16 * lh;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(kr + 32 * s);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(kr + 32 * s + BK * KROW);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], s == 0 ? zero : S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], S, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], S, 0, 0, 0);
     }
   };
   f32x16 O[4];
@@ -516,74 +543,59 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_planes_ke
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  load_k(0);
-  store_k(0, 0);
-  load_v(0);
-  store_v(0);
-  if (BK < T) load_k(BK);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = 0; k0 < T; k0 += BK, cur ^= 1) {
-    const char* Kp = fl + cur * STAGE;
-    const char* Vp = Kp + KB;
-    const float* kp = kpf + cur * BK;
-    f32x16 S;
+  float m = -INFINITY, l = 0.f;   // running maximum (log2 domain), running sum (carries the 2^10 of the P operand)
+  // One key block: S = this block's scores (formed in the previous iteration), Sn <- the next block's.  Straight-line code — the staging is
+  // unconditional (past the end it moves clamped rows nobody reads) — so that the scheduler can run the Q K^T MFMAs of block i + 1 under the softmax
+  // of block i and the staging under the P V MFMAs.
+  auto block = [&](auto masked, auto curc, int k0, f32x16& S, f32x16& Sn, unsigned km) {
+    constexpr bool MASKED = decltype(masked)::value;
+    constexpr int cur = decltype(curc)::value;
+    store_k(cur);            // K(i+2), requested at the start of the previous iteration
+    load_k(k0 + 3 * BK);
+    load_v(k0 + BK);
+    scores(cur ^ 1, Sn);
+    if constexpr (MASKED) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      for (int r = 0; r < 16; ++r)
+        if (!((km >> acc_row(r, lh)) & 1u)) S[r] = -INFINITY;
+    }
+    float mx = S[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
     {
-      const char* kr = Kp + l31 * KROW + 16 * lh;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(kr + 32 * s);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(kr + 32 * s + BK * KROW);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], S, 0, 0, 0);
-      }
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);   // the other 16 keys of this query
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    // the next block's K goes to the other buffer (every wave finished reading it before the barrier that ended the previous iteration)
-    const bool more = k0 + BK < T;
-    if (more) {
-      store_k(cur ^ 1, k0 + BK);
-      load_v(k0 + BK);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      S[r] *= 1.0f / (SIN * SIN);
-      if (kp[acc_row(r, lh)] == 0.f) S[r] = -INFINITY;
-      mx = fmaxf(mx, S[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m, mx);
+    const float m_new = fmaxf(m, mx * C2);
     const float ms = m_new == -INFINITY ? 0.f : m_new;     // a block of masked keys only must not produce inf - inf
-    const float scale = expf(m - ms);
+    const float scale = __builtin_amdgcn_exp2f(m - ms);
+    const float off = 10.0f - ms;                          // P carries 2^10: the fp16 hi / lo split of values <= 1024
     float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      S[r] = expf(S[r] - ms);
-      ps += S[r];
-    }
-    ps += __shfl_xor(ps, 32);
-    l = l * scale + ps;
-    m = m_new;
     f16x8 ph[2], pl[2];   // step t: registers 8t .. 8t+7 = keys 16 t + 4 lh + (j & 3) + 8 (j >> 2)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float x = S[8 * t + j] * PSC;
+        const float x = __builtin_amdgcn_exp2f(fmaf(S[8 * t + j], C2, off));
+        ps += x;
         ph[t][j] = (_Float16)x;
         pl[t][j] = (_Float16)(x - (float)ph[t][j]);
       }
-    const bool rescale = __any(scale != 1.0f);   // wave-uniform: once the running maxima have settled nothing is rescaled
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
+      ps = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    l = l * scale + ps;
+    m = m_new;
+    if (__any(scale != 1.0f)) {   // wave-uniform: once the running maxima have settled nothing is rescaled
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      if (rescale) {
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[dt][r] *= scale;
-      }
+    }
+    const char* Vp = fl + 2 * KB + cur * VB;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
       const char* vr = Vp + (32 * dt + l31) * VROW + 8 * lh;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -596,17 +608,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_planes_ke
         O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph[t], O[dt], 0, 0, 0);
       }
     }
-    if (more) {
-      store_v(cur ^ 1);
-      if (k0 + 2 * BK < T) load_k(k0 + 2 * BK);
-    }
-    __syncthreads();   // this block is consumed; the next one is complete in the other buffer
+    store_v(cur ^ 1);        // V^T(i+1)
+    __syncthreads();         // this block is consumed; K(i+2) and V^T(i+1) are complete
+  };
+  using std::integral_constant;
+  load_k(0);
+  store_k(0);
+  load_k(BK);
+  store_k(1);
+  load_v(0);
+  store_v(0);
+  load_k(2 * BK);
+  __syncthreads();
+  f32x16 S0, S1;
+  scores(0, S0);
+  __syncthreads();   // K buffer 0 is free for K(2)
+  for (int k0 = 0; k0 < T; k0 += 2 * BK) {
+    const unsigned km0 = kmb[k0 >> 5];   // wave-uniform
+    if (km0 == 0xffffffffu) block(integral_constant<bool, false>{}, integral_constant<int, 0>{}, k0, S0, S1, km0);
+    else block(integral_constant<bool, true>{}, integral_constant<int, 0>{}, k0, S0, S1, km0);
+    if (k0 + BK >= T) break;
+    const unsigned km1 = kmb[(k0 >> 5) + 1];
+    if (km1 == 0xffffffffu) block(integral_constant<bool, false>{}, integral_constant<int, 1>{}, k0 + BK, S1, S0, km1);
+    else block(integral_constant<bool, true>{}, integral_constant<int, 1>{}, k0 + BK, S1, S0, km1);
   }
   bool bad = false;
   if (q_ok) {
     // the attention output is read by the output projection only: hi / lo fp16 planes of 16 x value (registers 4 g .. 4 g + 3 of a lane are 4
     // consecutive d: one 8-byte store per plane)
-    const float inv = 1.0f / (l * SIN * PSC);
+    const float inv = 1.0f / (l * SIN);   // l carries the 2^10 of P
     _Float16* __restrict__ oph = out_h + ((long long)b * T + q_row) * ldo + hh * D;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -1109,8 +1139,7 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
     if (fplanes < 0) {
       const char* e = getenv("BSG_FLASH_PLANES");
       fplanes = e ? atoi(e) : 1;
-      if (fplanes && (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_planes_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FLP_LDS) != hipSuccess ||
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_planes_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FLP_LDS) != hipSuccess)) {
+      if (fplanes && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_planes_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FLP_LDS) != hipSuccess) {
         (void)hipGetLastError();
         fplanes = 0;
       }
@@ -1120,15 +1149,16 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
       TRY(ln_planes(x, L.ln1w, L.ln1b, ap, rows, 1e-5f, st));
       TRY(linear_h2w(ap, L.p_in, 3 * H, nullptr, h->w_qkv, nullptr, rows, ACT_NONE, nullptr, nullptr, st, qscale, H));
       const long long wg4 = (long long)cdiv(T, 128) * B * heads;
-      if (fplanes && Tp <= 4 * T) {
+      if (fplanes && Tp <= 3 * T && rows >= 32) {
         // Q | K planes [2][rows][2H] in the (not yet written) FFN planes buffer, V^T planes [2][B][H][Tp] in the fp32 FFN buffer this path does not use
         _Float16* qk = reinterpret_cast<_Float16*>(fp);
         _Float16* vt = reinterpret_cast<_Float16*>(h->w_ffn);
         const long long vplane = (long long)B * H * Tp;
-        hipLaunchKernelGGL(qkv_split_kernel, dim3(Tp / 32, B), dim3(256), 0, st, (const float*)h->w_qkv, qk, rows * 2 * H, vt, vplane, T, Tp, gemm_range_counter());
+        unsigned* km = reinterpret_cast<unsigned*>(vt + 2 * vplane);   // key mask words [B][Tp / 32] behind the V^T planes
+        hipLaunchKernelGGL(qkv_split_kernel, dim3(Tp / 32, B), dim3(256), 0, st, (const float*)h->w_qkv, qk, rows * 2 * H, vt, vplane, T, Tp, keep, km, gemm_range_counter());
         BSG_LAUNCH_CHECK();
-        if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_planes_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, keep, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter());
-        else hipLaunchKernelGGL(flash_attn_planes_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, keep, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter());
+        // 2 waves (64 queries) per workgroup at every size: the pipelined loop keeps two score tiles live and does not fit 4 waves x 2 workgroups
+        hipLaunchKernelGGL(flash_attn_planes_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, (const unsigned*)km, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter());
       } else if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
       else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
       BSG_LAUNCH_CHECK();
