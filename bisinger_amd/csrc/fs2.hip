@@ -393,12 +393,12 @@ constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80);   // flash_attn_plane
 // flash_attn_split_kernel splits K and V while it stages every 32-key block — and transposes V with 2-byte LDS writes — once per 64 or 128
 // queries: at T = 1000 a K / V element is split 8-16 times, between two barriers and with its global loads exposed.  Here
 // qkv_split_kernel splits the QKV projection's output ONCE into fp16 planes — Q and K as [row][256] (hi, lo), V TRANSPOSED as
-// [b][256 (head, d)][Tp keys] (Tp = T rounded up to 32, the padding zeroed) — plus one mask word per (utterance, 32-key block), and
+// [b][256 (head, d)][Tp keys] (Tp = T rounded up to 32, the padding zeroed; keys in fragment order within groups of 16) — plus one mask word per (utterance, 32-key block), and
 // flash_attn_planes_kernel stages a key block as plain 16-byte copies while the MFMAs of the blocks before it run: K two blocks ahead, V^T one,
 // one barrier per block, no vector arithmetic in the staging, the softmax in the log2 domain (v_exp_f32, the 2^10 of the P operand folded into the
 // exponent), its two cross-half reductions as v_permlane32_swap, blocks whose mask word is all ones skip the masking.  Same products, fragments
 // and key order as flash_attn_split_kernel (its comment above).
-// Measured (T = 1000, decoder layer): 118 -> 95 us at B = 16, 99 -> 69 us at B = 1 against the first planes form (the split-in-kernel form: 270 /
+// Measured (T = 1000, decoder layer): 118 -> 88 us at B = 16, 99 -> 63 us at B = 1 against the first planes form (the split-in-kernel form: 270 /
 // 200 us).  PMC of this kernel (profiles/r04_flash_planes_pmc.txt): matrix pipe busy 25 % of the wave cycles, vector issue 29 %, LDS 8 %,
 // s_waitcnt 18 % — the grid is B x heads x T / 32 = 1024 waves at B = 16, ONE wave per SIMD, so nothing hides the in-order dependences of a wave;
 // the next step would be to split the keys of a query tile over two workgroups (twice the waves), not more work on this loop.
@@ -450,9 +450,12 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict_
     for (int r = 0; r < 32; ++r) { th[r] = vh[r][d]; tl[r] = vl[r][d]; }
     _Float16* dst = vt + ((long long)b * H + d) * Tp + t0;
 #pragma unroll
+    // within a group of 16 keys the stored order is 0-3, 8-11, 4-7, 12-15: the 8 keys one lane feeds to a P V MFMA (16 t + 4 lh + (j & 3) + 8 (j >> 2))
+    // are then 16 contiguous bytes
     for (int g = 0; g < 4; ++g) {
-      *reinterpret_cast<f16x8*>(dst + 8 * g) = f16x8{th[8 * g], th[8 * g + 1], th[8 * g + 2], th[8 * g + 3], th[8 * g + 4], th[8 * g + 5], th[8 * g + 6], th[8 * g + 7]};
-      *reinterpret_cast<f16x8*>(dst + vt_plane + 8 * g) = f16x8{tl[8 * g], tl[8 * g + 1], tl[8 * g + 2], tl[8 * g + 3], tl[8 * g + 4], tl[8 * g + 5], tl[8 * g + 6], tl[8 * g + 7]};
+      const int k = 16 * (g >> 1) + 4 * (g & 1);
+      *reinterpret_cast<f16x8*>(dst + 8 * g) = f16x8{th[k], th[k + 1], th[k + 2], th[k + 3], th[k + 8], th[k + 9], th[k + 10], th[k + 11]};
+      *reinterpret_cast<f16x8*>(dst + vt_plane + 8 * g) = f16x8{tl[k], tl[k + 1], tl[k + 2], tl[k + 3], tl[k + 8], tl[k + 9], tl[k + 10], tl[k + 11]};
     }
   }
   if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && (tid & 63) == 0) atomicAdd(range_events, 1u);
@@ -596,13 +599,11 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_planes_kernel(const _Fl
     const char* Vp = fl + 2 * KB + cur * VB;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const char* vr = Vp + (32 * dt + l31) * VROW + 8 * lh;
+      const char* vr = Vp + (32 * dt + l31) * VROW + 16 * lh;   // the keys of a lane are contiguous (qkv_split_kernel's order): one 16-byte read, conflict-free
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const u32x2_t h0 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t), h1 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + 16);
-        const u32x2_t l0 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + D * VROW), l1 = *reinterpret_cast<const u32x2_t*>(vr + 32 * t + 16 + D * VROW);
-        const f16x8 ah = __builtin_bit_cast(f16x8, u32x4_t{h0[0], h0[1], h1[0], h1[1]});
-        const f16x8 al = __builtin_bit_cast(f16x8, u32x4_t{l0[0], l0[1], l1[0], l1[1]});
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(vr + 32 * t);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(vr + 32 * t + D * VROW);
         O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph[t], O[dt], 0, 0, 0);
         O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl[t], O[dt], 0, 0, 0);
         O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph[t], O[dt], 0, 0, 0);
