@@ -112,6 +112,9 @@ struct H2wArgs {
   long long sRS;
   int batch;
   unsigned* range_events;      // set by launch_gemm_h2w
+  // polyphase output (act_is_a = 0 only; up_u = 0: off) — a transposed convolution with kernel 2 u, stride u as ONE 2-tap product: weight row
+  // n = co * up_u + r, activation row q; C[co * ldc + q * up_u + r - up_p] for positions inside [0, up_lout); bias per co
+  int up_u, up_p, up_lout;
 };
 bool h2w_supports(int rows, int Wn, int K, int taps, int lda);
 // W(tap, n, k) at src[tap * ts + n * rs + k * ks]; allocates w->pack on first use; |16 w| >= 65000 counted into *bad_dev (device word)
@@ -121,6 +124,9 @@ int h2w_pack_into(unsigned short* dst, const float* src, int Wn, int K, int taps
 void h2w_free(H2wWeights* w);
 int h2w_split_rows(const float* src, unsigned short* hi, unsigned short* lo, long long rows, int K, long long ld, hipStream_t st);
 int h2w_split_transposed(const float* src, unsigned short* hi, unsigned short* lo, int B, int K, int T, hipStream_t st);   // [B][K][T] -> [B][T][K]
+// the same with LeakyReLU(slope) applied first, `rows_per_b` >= T rows per batch item and Kp >= K columns per row in the planes (the padding is zero)
+int h2w_split_transposed_lrelu(const float* src, unsigned short* hi, unsigned short* lo, int B, int K, int Kp, int T, int rows_per_b, float slope,
+                               hipStream_t st);
 int launch_gemm_h2w(const H2wArgs& g, hipStream_t st);
 unsigned* gemm_range_counter();   // device address of the range-event counter (null on error): kernels of other translation units add to it
 

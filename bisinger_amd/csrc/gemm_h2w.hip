@@ -75,26 +75,29 @@ __global__ void h2w_split_rows_kernel(const float* __restrict__ src, _Float16* _
   if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(range_events, 1u);
 }
 
-// fp32 [B][K][T] (the [B, C, T] layout of the reference's cond) -> planes [B][T][K]: a 32 x 32 tile through LDS per 256-thread workgroup
+// fp32 [B][K][T] (the [B, C, T] layout of the reference's cond) -> planes [B][TR][KP] (TR >= T rows per item, KP >= K columns; rows T.. and
+// columns K.. zero) of 16 x lrelu_slope(value): a 32 x 32 tile through LDS per 256-thread workgroup
 __global__ __launch_bounds__(256) void h2w_split_transposed_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                                                   _Float16* __restrict__ lo, int K, int T, unsigned* __restrict__ range_events) {
+                                                                   _Float16* __restrict__ lo, int K, int KP, int T, int TR, float slope,
+                                                                   unsigned* __restrict__ range_events) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, k0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int j = ty; j < 32; j += 8) {
     const int k = k0 + j, t = t0 + tx;
-    tile[j][tx] = (k < K && t < T) ? src[((long long)b * K + k) * T + t] : 0.f;
+    const float v = (k < K && t < T) ? src[((long long)b * K + k) * T + t] : 0.f;
+    tile[j][tx] = fmaxf(v, v * slope);   // slope in [0, 1]; 1: the identity
   }
   __syncthreads();
   bool bad = false;
   for (int j = ty; j < 32; j += 8) {
     const int t = t0 + j, k = k0 + tx;
-    if (t < T && k < K) {
+    if (t < TR && k < KP) {
       const float x = tile[tx][j] * H2W_IN;
       bad |= !(fabsf(x) < 65000.0f);
       const _Float16 h = (_Float16)x;
-      hi[((long long)b * T + t) * K + k] = h;
-      lo[((long long)b * T + t) * K + k] = (_Float16)(x - (float)h);
+      hi[((long long)b * TR + t) * KP + k] = h;
+      lo[((long long)b * TR + t) * KP + k] = (_Float16)(x - (float)h);
     }
   }
   if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(range_events, 1u);
@@ -287,6 +290,40 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
   constexpr int ER = ACT_IS_A ? BMA : 128, EC = ACT_IS_A ? 128 : BMA, EP = EC + 4;   // image rows x columns (columns = the output's contiguous axis), pitch
   float* et = reinterpret_cast<float*>(lds);
   __syncthreads();   // every wave is done reading the stages
+  if (!ACT_IS_A && g.up_u) {
+    // polyphase output (H2wArgs::up_u = 8): the image as [activation row q][weight row n = 8 co + r] (pitch 132), so that the 4 phases r0 .. r0 + 3
+    // of one (co, q) are one 16-byte LDS read and one 16-byte store at C[co][8 q + r0 - p]; a wave's stores cover (q, r0) in address order:
+    // 1 KB contiguous per co
+    constexpr int UP = 132;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et[(mi * 32 + l31) * UP + wave * 32 + acc_row(r, lh)] = c[mi][r];
+    __syncthreads();
+    const int wrow0u = wt128 * 128;
+#pragma unroll 1
+    for (int it = tid; it < BMA * 32; it += 256) {
+      const int cg = it / (2 * BMA), rem = it - cg * (2 * BMA), q = rem >> 1, c4 = cg * 8 + 4 * (rem & 1);
+      const int arow = arow0 + q;
+      if (arow >= g.rows) continue;
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(et + q * UP + c4);
+      const int wrow = wrow0u + c4, co = wrow >> 3;
+      const float bv = bias ? bias[co] : 0.f;
+      const int o0 = arow * 8 + (wrow & 7) - g.up_p;
+      float* __restrict__ dst = Cp + (long long)co * g.ldc;
+      f32x4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = a4[e] * H2W_OUT + bv;
+      if (o0 >= 0 && o0 + 3 < g.up_lout && ((((uintptr_t)(dst + o0)) & 15) == 0)) {
+        *reinterpret_cast<f32x4*>(dst + o0) = o4;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (o0 + e >= 0 && o0 + e < g.up_lout) dst[o0 + e] = o4[e];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -352,7 +389,8 @@ template <bool ACT_IS_A, int MI, int KK>
 int h2w_launch(const H2wArgs& g, hipStream_t st) {
   constexpr int BMA = 32 * MI;
   // the two stages; the epilogue's fp32 image of the workgroup tile aliases them (pitch = contiguous extent + 4 floats)
-  constexpr size_t epi = ACT_IS_A ? (size_t)BMA * 132 * 4 : (size_t)128 * (BMA + 4) * 4;
+  constexpr size_t epi_a = (size_t)BMA * 132 * 4, epi_w = (size_t)128 * (BMA + 4) * 4;   // (the polyphase output of the weights-as-A form uses the [row][132] image too)
+  constexpr size_t epi = ACT_IS_A ? epi_a : (epi_a > epi_w ? epi_a : epi_w);
   const size_t stages = (size_t)2 * 2 * (BMA + g.taps - 1) * (32 * KK + 16);
   const size_t lds = stages > epi ? stages : epi;
   const int nwg = cdiv(g.rows, BMA) * (g.Wn / 128) * g.batch;
@@ -411,12 +449,18 @@ int h2w_split_rows(const float* src, unsigned short* hi, unsigned short* lo, lon
   return BSG_OK;
 }
 
-int h2w_split_transposed(const float* src, unsigned short* hi, unsigned short* lo, int B, int K, int T, hipStream_t st) {
-  BSG_REQUIRE(src && hi && lo && B > 0 && K > 0 && T > 0 && B <= 65535, "h2w_split_transposed: B=%d K=%d T=%d", B, K, T);
-  hipLaunchKernelGGL(h2w_split_transposed_kernel, dim3(cdiv(T, 32), cdiv(K, 32), B), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(hi),
-                     reinterpret_cast<_Float16*>(lo), K, T, gemm_range_counter());
+int h2w_split_transposed_lrelu(const float* src, unsigned short* hi, unsigned short* lo, int B, int K, int Kp, int T, int rows_per_b, float slope,
+                               hipStream_t st) {
+  BSG_REQUIRE(src && hi && lo && B > 0 && K > 0 && Kp >= K && T > 0 && B <= 65535 && rows_per_b >= T && slope >= 0.f && slope <= 1.f,
+              "h2w_split_transposed: B=%d K=%d Kp=%d T=%d rows=%d slope=%g", B, K, Kp, T, rows_per_b, (double)slope);
+  hipLaunchKernelGGL(h2w_split_transposed_kernel, dim3(cdiv(rows_per_b, 32), cdiv(Kp, 32), B), dim3(256), 0, st, src, reinterpret_cast<_Float16*>(hi),
+                     reinterpret_cast<_Float16*>(lo), K, Kp, T, rows_per_b, slope, gemm_range_counter());
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+
+int h2w_split_transposed(const float* src, unsigned short* hi, unsigned short* lo, int B, int K, int T, hipStream_t st) {
+  return h2w_split_transposed_lrelu(src, hi, lo, B, K, K, T, T, 1.0f, st);
 }
 
 int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
@@ -427,6 +471,9 @@ int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
   BSG_REQUIRE(!g.out || g.act_is_a, "gemm_h2w: plane output needs the [token][feature] form");
   BSG_REQUIRE(g.act_fn == ACT_NONE || g.act_fn == ACT_RELU || g.act_fn == ACT_GELU, "gemm_h2w: activation %d not built", g.act_fn);
   BSG_REQUIRE(!g.out || (g.ldo % 4 == 0 && g.out_plane % 4 == 0 && g.sO % 4 == 0), "gemm_h2w: plane output needs 8-byte aligned rows");
+  BSG_REQUIRE(g.up_u == 0 || (g.up_u == 8 && !g.act_is_a && g.C && g.up_p % 4 == 0 && g.up_lout > 0 && g.act_fn == ACT_NONE && !g.R && !g.rowscale &&
+                              g.alpha == 1.f && g.sBias == 0),
+              "gemm_h2w: polyphase output: up_u=%d act_is_a=%d", g.up_u, g.act_is_a);
   if (g.zdiv <= 0) g.zdiv = g.batch;
   g.range_events = gemm_range_counter();
   // 64-row activation tiles when 128-row tiles would leave CUs without a second workgroup

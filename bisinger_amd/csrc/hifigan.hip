@@ -1157,6 +1157,10 @@ struct ConvW {
   float* wpu = nullptr;   // ConvTranspose1d with K = 2u: per-phase 2-tap weights in CO-blocks of 8 for upsample_kernel
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
+  // round 4: the split-fp16 GEMM with pre-split operands (gemm_h2w.hip) for the two dense convolutions outside the ResBlocks —
+  // ConvTranspose1d(k = 16, u = 8) as ONE 2-tap product over (co, phase) weight rows with a polyphase store, conv_pre as a 7-tap product
+  H2wWeights h2w;
+  int h2w_kp = 0;         // input channels padded to a multiple of 64 in the activation planes
 };
 
 struct bsg_hifigan {
@@ -1176,6 +1180,8 @@ struct bsg_hifigan {
   // h2_ok says whether the packed form may be used (else the fp32-MFMA pairs: never a clipped weight)
   unsigned* w_range_bad = nullptr;
   bool h2_ok = true;
+  unsigned short* planes = nullptr;       // activation planes of the gemm_h2w products (hi, then lo)
+  size_t planes_cap = 0;                  // halfs
 };
 
 extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
@@ -1185,6 +1191,9 @@ extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
     if (p) (void)hipFree(p);
   if (h->sw_tmp) (void)hipFree(h->sw_tmp);
   if (h->har) (void)hipFree(h->har);
+  if (h->planes) (void)hipFree(h->planes);
+  h2w_free(&h->pre.h2w);
+  for (ConvW& c : h->ups) h2w_free(&c.h2w);
   delete h;
 }
 
@@ -1244,6 +1253,58 @@ static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st, bool pair = false
 }
 
 // ConvTranspose1d with K == 2*u: per-phase 2-tap weights for the polyphase launch
+// tmp[tap][n = co u + r][ci] = w[ci][co][r + u (1 - tap)] (ConvTranspose1d weight [Cin][Cout][2u]): tap 0 meets x[q - 1], tap 1 x[q]
+__global__ void up_h2w_reorder_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int u) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Wn = Cout * u;
+  if (i >= 2 * Wn * Cin) return;
+  const int ci = i % Cin, n = (i / Cin) % Wn, tap = i / (Cin * Wn);
+  const int co = n / u, r = n - co * u;
+  out[i] = w[((long long)ci * Cout + co) * (2 * u) + r + u * (1 - tap)];
+}
+// tmp[tap][co][ci < CinP] = w[co][ci][tap] (Conv1d weight [Cout][Cin][K]), zero for ci >= Cin
+__global__ void conv_h2w_reorder_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int CinP, int Cout, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * Cout * CinP) return;
+  const int ci = i % CinP, co = (i / CinP) % Cout, tap = i / (CinP * Cout);
+  out[i] = ci < Cin ? w[((long long)co * Cin + ci) * K + tap] : 0.f;
+}
+static int pack_up_h2w(bsg_hifigan* h, ConvW& c, int u, hipStream_t st) {
+  if (u != 8 || c.k != 16 || c.cin % 64 || (c.cout * u) % 128) return BSG_OK;
+  float* tmp = nullptr;
+  const int n = 2 * c.cout * u * c.cin;
+  TRY(hg_alloc(h, &tmp, n));
+  hipLaunchKernelGGL(up_h2w_reorder_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, tmp, c.cin, c.cout, u);
+  BSG_LAUNCH_CHECK();
+  TRY(h2w_pack(&c.h2w, tmp, c.cout * u, c.cin, 2, (long long)c.cout * u * c.cin, c.cin, 1, h->w_range_bad, st));
+  c.h2w.ok = true;   // (subject to bsg_hifigan::h2_ok: the range counter is read once, at the end of create)
+  c.h2w_kp = c.cin;
+  return BSG_OK;
+}
+static int pack_pre_h2w(bsg_hifigan* h, ConvW& c, hipStream_t st) {
+  const int kp = (c.cin + 63) / 64 * 64;
+  if (c.cout % 128 || c.k > 17) return BSG_OK;
+  float* tmp = nullptr;
+  const int n = c.k * c.cout * kp;
+  TRY(hg_alloc(h, &tmp, n));
+  hipLaunchKernelGGL(conv_h2w_reorder_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, tmp, c.cin, kp, c.cout, c.k);
+  BSG_LAUNCH_CHECK();
+  TRY(h2w_pack(&c.h2w, tmp, c.cout, kp, c.k, (long long)c.cout * kp, kp, 1, h->w_range_bad, st));
+  c.h2w.ok = true;
+  c.h2w_kp = kp;
+  return BSG_OK;
+}
+static int ensure_planes(bsg_hifigan* h, size_t halfs, hipStream_t st) {
+  if (halfs > h->planes_cap) {
+    BSG_HIP(hipStreamSynchronize(st));
+    if (h->planes) (void)hipFree(h->planes);
+    h->planes = nullptr; h->planes_cap = 0;
+    BSG_HIP(hipMalloc((void**)&h->planes, halfs * sizeof(unsigned short)));
+    h->planes_cap = halfs;
+  }
+  return BSG_OK;
+}
+
 static int pack_convT(bsg_hifigan* h, ConvW& c, int u, hipStream_t st) {
   if (c.k != 2 * u) return BSG_OK;   // other shapes keep the gather kernel
   const int CO = c.cout >= 16 ? 16 : 8;
@@ -1330,12 +1391,14 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   h->pre.cout = C0; h->pre.cin = cfg->n_mel; h->pre.k = 7;
   if ((rc = take_conv(h, h->pre, w, C0, cfg->n_mel * 7, st)) != BSG_OK) return fail(rc);
   if ((rc = pack_conv(h, h->pre, st)) != BSG_OK) return fail(rc);
+  if ((rc = pack_pre_h2w(h, h->pre, st)) != BSG_OK) return fail(rc);
   h->ups.resize(cfg->n_ups);
   for (int i = 0; i < cfg->n_ups; ++i) {
     ConvW& c = h->ups[i];
     c.cin = C0 >> i; c.cout = C0 >> (i + 1); c.k = cfg->upsample_kernel_sizes[i];
     if ((rc = take_conv(h, c, w, c.cin, c.cout * c.k, st)) != BSG_OK) return fail(rc);   // weight [Cin][Cout][K], g over dim 0 = Cin
     if ((rc = pack_convT(h, c, cfg->upsample_rates[i], st)) != BSG_OK) return fail(rc);
+    if ((rc = pack_up_h2w(h, c, cfg->upsample_rates[i], st)) != BSG_OK) return fail(rc);
   }
   const int nrb = cfg->n_ups * cfg->n_kernels;
   h->rb1.resize((size_t)nrb * cfg->n_dil);
@@ -1397,7 +1460,23 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
   }
   float *x = h->buf[0], *ya = h->buf[1], *yb = h->buf[2], *tmp = h->buf[3], *xs = h->buf[4];
   const float slope = 0.1f;   // LRELU_SLOPE, hifigan.py:11
-  TRY(run_conv(h->pre, mel, x, B, T, 1, 1.0f, nullptr, nullptr, 1.0f, 0, st));            // conv_pre :150
+  static int h2w_env = -1;   // BSG_HG_H2W=0: conv_pre and the u = 8 transposed convolutions on the vector pipe (conv1d_kernel / upsample_kernel)
+  if (h2w_env < 0) { const char* e = getenv("BSG_HG_H2W"); h2w_env = e ? atoi(e) : 1; }
+  const bool h2w_on = h2w_env && h->h2_ok && gemm_split_enabled();
+  if (h2w_on && h->pre.h2w.ok && h2w_supports(T, h->pre.cout, h->pre.h2w_kp, h->pre.k, h->pre.h2w_kp)) {
+    // conv_pre :150 as a 7-tap product of the mel planes [T][n_mel padded to 128] with the pre-split weights; output [C0][T]
+    const ConvW& p = h->pre;
+    const long long n = (long long)B * T * p.h2w_kp;
+    TRY(ensure_planes(h, (size_t)2 * n, st));
+    TRY(h2w_split_transposed_lrelu(mel, h->planes, h->planes + n, B, p.cin, p.h2w_kp, T, T, 1.0f, st));
+    H2wArgs g{};
+    g.act = h->planes; g.act_plane = n; g.lda = p.h2w_kp; g.sAct = (long long)T * p.h2w_kp; g.wpack = p.h2w.pack; g.rows = T; g.K = p.h2w_kp;
+    g.Wn = p.cout; g.taps = p.k; g.tap_shift0 = -(p.k / 2); g.act_is_a = 0; g.C = x; g.ldc = T; g.sC = (long long)p.cout * T; g.bias = p.b;
+    g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = B;
+    TRY(launch_gemm_h2w(g, st));
+  } else {
+    TRY(run_conv(h->pre, mel, x, B, T, 1, 1.0f, nullptr, nullptr, 1.0f, 0, st));            // conv_pre :150
+  }
   int L = T;
   float* cur = x;
   for (int i = 0; i < c.n_ups; ++i) {
@@ -1408,7 +1487,18 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
     const int Lout = L * t.u;
     static int up_env = -1;
     if (up_env < 0) { const char* e = getenv("BSG_HG_UP"); up_env = e ? atoi(e) : 1; }
-    if (up.wpu && up_env && t.p * 2 == t.u && (long long)cdiv(L + 1, 256) * cdiv(up.cout, 8) * B >= 512) {   // short inputs: the phase-per-block form has u x the workgroups
+    if (h2w_on && up.h2w.ok && t.u == 8 && t.p == 4 && h2w_supports(L + 1, up.cout * 8, up.cin, 2, up.cin)) {
+      // the transposed convolution on the matrix pipe: lrelu(x) as planes [L + 1][Cin] (row L zero), ONE 2-tap product with the (co, phase) weight
+      // rows, stored phase-interleaved (H2wArgs::up_u)
+      const long long n = (long long)B * (L + 1) * up.cin;
+      TRY(ensure_planes(h, (size_t)2 * n, st));
+      TRY(h2w_split_transposed_lrelu(cur, h->planes, h->planes + n, B, up.cin, up.cin, L, L + 1, slope, st));
+      H2wArgs g{};
+      g.act = h->planes; g.act_plane = n; g.lda = up.cin; g.sAct = (long long)(L + 1) * up.cin; g.wpack = up.h2w.pack; g.rows = L + 1; g.K = up.cin;
+      g.Wn = up.cout * 8; g.taps = 2; g.tap_shift0 = -1; g.act_is_a = 0; g.C = t.y; g.ldc = Lout; g.sC = (long long)up.cout * Lout; g.bias = up.b;
+      g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = B; g.up_u = 8; g.up_p = t.p; g.up_lout = Lout;
+      TRY(launch_gemm_h2w(g, st));
+    } else if (up.wpu && up_env && t.p * 2 == t.u && (long long)cdiv(L + 1, 256) * cdiv(up.cout, 8) * B >= 512) {   // short inputs: the phase-per-block form has u x the workgroups
       // all phases of a position in one lane: contiguous stores (upsample_kernel)
       UpArgs ua{};
       ua.x = cur; ua.w = up.wpu; ua.bias = up.b; ua.y = t.y; ua.slope = slope; ua.Cin = up.cin; ua.Cout = up.cout; ua.Lin = L; ua.p = t.p;
