@@ -22,6 +22,7 @@
 
 namespace bsg {
 namespace {
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // samples per lane TT (stride 256) is a template parameter: 4 when the launch fills the chip anyway, 2 or 1 for short
 // inputs (B = 1), where 1024-sample tiles leave most CUs without a workgroup
@@ -488,6 +489,117 @@ __global__ __launch_bounds__(256) void upsample_kernel(UpArgs a) {
       for (int r = 0; r < U; ++r)
         if (o0 + r >= 0 && o0 + r < Lout) yr[o0 + r] = acc[c][r];
     }
+  }
+}
+
+// ConvTranspose1d(K = 4, stride 2, padding 1) — the last upsampling stages, 2 x (read + write) of the largest tensors: a lane produces 4
+// CONSECUTIVE output samples of CO channels (16-byte stores, a wave covers 1 KB per channel) from x[2m-1 .. 2m+2]:
+//   y[4m]   = x[2m-1] w3 + x[2m]   w1      y[4m+1] = x[2m]   w2 + x[2m+1] w0
+//   y[4m+2] = x[2m]   w3 + x[2m+1] w1      y[4m+3] = x[2m+1] w2 + x[2m+2] w0          (w_k = w[ci][co][k], x = lrelu(input), zero outside)
+// The weights are read in their own layout [Cin][Cout][4] (wave-uniform: scalar loads).  upsample_kernel<2> wrote 2 samples per lane with
+// 4-byte stores at odd offsets and staged x once per block of 8 output channels: 117 us per stage at B = 16 against 52 us of HBM time; this
+// form: 100 / 90 us (16 / 8 output channels) — the staging of a 16-channel chunk and its FMAs still alternate.
+template <int CO>
+__global__ __launch_bounds__(256) void upsample2_kernel(UpArgs a) {
+  constexpr int CIC = 16, XS = 516;      // xs[ci][j] = lrelu(x[2 m0 - 2 + j]): the lane's x[2m-1] sits at the EVEN index 2 tid + 1... see below
+  __shared__ __attribute__((aligned(16))) float xs[CIC][XS];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * 256, m = m0 + tid;   // outputs [4m, 4m + 4)
+  const int cb = blockIdx.y, b = blockIdx.z;
+  const float* __restrict__ xb = a.x + (long long)b * a.Cin * a.Lin;
+  float acc[CO][4];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float bv = a.bias[cb * CO + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[c][r] = bv;
+  }
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += CIC) {
+    __syncthreads();
+    // xs[ci][j] = x[2 m0 - 1 + j], j in [0, 514): lane tid reads j = 2 tid .. 2 tid + 3 (two aligned 8-byte reads)
+    for (int idx = tid; idx < CIC * 514; idx += 256) {
+      const int ci = idx / 514, j = idx - ci * 514;
+      const int t = 2 * m0 - 1 + j;
+      const float v = (ci0 + ci < a.Cin && t >= 0 && t < a.Lin) ? xb[(long long)(ci0 + ci) * a.Lin + t] : 0.f;
+      xs[ci][j] = fmaxf(v, v * a.slope);
+    }
+    __syncthreads();
+    const int nci = a.Cin - ci0 < CIC ? a.Cin - ci0 : CIC;
+#pragma unroll 1
+    for (int ci = 0; ci < nci; ++ci) {
+      const f32x2 xa = *reinterpret_cast<const f32x2*>(&xs[ci][2 * tid]), xb2 = *reinterpret_cast<const f32x2*>(&xs[ci][2 * tid + 2]);
+      const float xm = xa[0], x0 = xa[1], x1 = xb2[0], x2 = xb2[1];   // x[2m-1], x[2m], x[2m+1], x[2m+2]
+      const float* __restrict__ wp = a.w + ((long long)(ci0 + ci) * a.Cout + cb * CO) * 4;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) {
+        const float w0 = wp[4 * c], w1 = wp[4 * c + 1], w2 = wp[4 * c + 2], w3 = wp[4 * c + 3];
+        acc[c][0] = fmaf(x0, w1, fmaf(xm, w3, acc[c][0]));
+        acc[c][1] = fmaf(x1, w0, fmaf(x0, w2, acc[c][1]));
+        acc[c][2] = fmaf(x1, w1, fmaf(x0, w3, acc[c][2]));
+        acc[c][3] = fmaf(x2, w0, fmaf(x1, w2, acc[c][3]));
+      }
+    }
+  }
+  const int Lout = a.Lin * 2, o0 = 4 * m;
+  if (o0 >= Lout) return;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    float* __restrict__ yr = a.y + ((long long)b * a.Cout + cb * CO + c) * Lout;
+    if (o0 + 3 < Lout && (Lout & 3) == 0) {
+      *reinterpret_cast<f32x4*>(yr + o0) = f32x4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (o0 + r < Lout) yr[o0 + r] = acc[c][r];
+    }
+  }
+}
+
+// conv_post (hifigan.py:169-171): Conv1d(C -> 1, 7, padding 3) on LeakyReLU(x, 0.01), then tanh.  One output channel: the generic conv1d_kernel
+// spends 7 of its 8 output-channel lanes' FMAs on nothing.  A lane produces 4 consecutive samples from three 16-byte loads per input channel
+// (x[4m-4 .. 4m+7]; neighbours' loads overlap in L1), no LDS; weights wave-uniform.  98 -> 33 us at B = 16 (147 MB: 4.4 TB/s).
+template <int C>
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int L, float slope) {
+  const int m = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const int t0 = 4 * m;
+  if (t0 >= L) return;
+  const float* __restrict__ xb = x + (long long)b * C * L;
+  float acc[4] = {bias[0], bias[0], bias[0], bias[0]};
+  const bool inner = t0 >= 4 && t0 + 8 <= L && (L & 3) == 0;
+#pragma unroll
+  for (int ci = 0; ci < C; ++ci) {
+    float v[12];   // x[t0 - 4 + j]
+    const float* __restrict__ xr = xb + (long long)ci * L;
+    if (inner) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(xr + t0 - 4 + 4 * g);
+        v[4 * g] = q[0]; v[4 * g + 1] = q[1]; v[4 * g + 2] = q[2]; v[4 * g + 3] = q[3];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int t = t0 - 4 + j;
+        v[j] = (t >= 0 && t < L) ? xr[t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 1; j < 11; ++j) v[j] = fmaxf(v[j], v[j] * slope);   // (slope in [0, 1])
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const float wk = w[ci * 7 + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(wk, v[r + k + 1], acc[r]);   // y[t0 + r] += w[k] x[t0 + r + k - 3]
+    }
+  }
+  float* __restrict__ yr = y + (long long)b * L + t0;
+  if (t0 + 3 < L && (L & 3) == 0) {
+    *reinterpret_cast<f32x4*>(yr) = f32x4{tanhf(acc[0]), tanhf(acc[1]), tanhf(acc[2]), tanhf(acc[3])};
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (t0 + r < L) yr[r] = tanhf(acc[r]);
   }
 }
 
@@ -1498,6 +1610,14 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
       g.Wn = up.cout * 8; g.taps = 2; g.tap_shift0 = -1; g.act_is_a = 0; g.C = t.y; g.ldc = Lout; g.sC = (long long)up.cout * Lout; g.bias = up.b;
       g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = B; g.up_u = 8; g.up_p = t.p; g.up_lout = Lout;
       TRY(launch_gemm_h2w(g, st));
+    } else if (up_env && t.u == 2 && up.k == 4 && t.p == 1 && (up.cout == 16 || up.cout == 8) && (long long)cdiv(Lout, 1024) * B >= 512 &&
+               !getenv("BSG_NO_UP2")) {   // (single utterances: 125 workgroups of this form are slower than the phase-per-block form, 38 against 28 us)
+      UpArgs ua{};
+      ua.x = cur; ua.w = up.w; ua.bias = up.b; ua.y = t.y; ua.slope = slope; ua.Cin = up.cin; ua.Cout = up.cout; ua.Lin = L; ua.p = t.p;
+      const dim3 grid(cdiv(Lout, 1024), 1, B);
+      if (up.cout == 16) hipLaunchKernelGGL(upsample2_kernel<16>, grid, dim3(256), 0, st, ua);
+      else hipLaunchKernelGGL(upsample2_kernel<8>, grid, dim3(256), 0, st, ua);
+      BSG_LAUNCH_CHECK();
     } else if (up.wpu && up_env && t.p * 2 == t.u && (long long)cdiv(L + 1, 256) * cdiv(up.cout, 8) * B >= 512) {   // short inputs: the phase-per-block form has u x the workgroups
       // all phases of a position in one lane: contiguous stores (upsample_kernel)
       UpArgs ua{};
@@ -1583,7 +1703,12 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
     }
     cur = sum;
   }
-  TRY(run_conv(h->post, cur, wav, B, L, 1, 0.01f, nullptr, nullptr, 1.0f, 1, st));          // :169-171 (default slope 0.01)
+  if (h->post.cin == 8 && h->post.k == 7 && !getenv("BSG_NO_CONV_POST")) {
+    hipLaunchKernelGGL(conv_post_kernel<8>, dim3(cdiv(L, 1024), B), dim3(256), 0, st, (const float*)cur, (const float*)h->post.w, (const float*)h->post.b, wav, L, 0.01f);
+    BSG_LAUNCH_CHECK();
+  } else {
+    TRY(run_conv(h->post, cur, wav, B, L, 1, 0.01f, nullptr, nullptr, 1.0f, 1, st));          // :169-171 (default slope 0.01)
+  }
   return BSG_OK;
 }
 
