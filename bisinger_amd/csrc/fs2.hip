@@ -661,13 +661,28 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_planes_kernel(const _Fl
 // x0 = sqrt(H) * E_tok[txt]; lang_e = E_lang[lang]                      (diffsinger_midi/fs2.py:28,122)
 __global__ void embed_tokens_kernel(const long long* __restrict__ txt, const long long* __restrict__ lang,
                                     const float* __restrict__ Etok, const float* __restrict__ Elang, float* __restrict__ x0,
-                                    float* __restrict__ lang_e, long long rows, float scale) {
+                                    float* __restrict__ lang_e, long long rows, float scale, _Float16* __restrict__ x0h,
+                                    _Float16* __restrict__ x0l, unsigned* __restrict__ range_events) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   f32x4 e = reinterpret_cast<const f32x4*>(Etok + txt[row] * H)[lane];
   e *= scale;
   reinterpret_cast<f32x4*>(x0 + row * H)[lane] = e;
+  if (x0h) {   // x0 as the operand of the ESM's query projection on the pre-split GEMM: hi / lo fp16 planes of 16 x0
+    ln_f16x4 hv, lv;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = e[c] * 16.0f;
+      bad |= !(fabsf(x) < 65000.0f);
+      hv[c] = (_Float16)x;
+      lv[c] = (_Float16)(x - (float)hv[c]);
+    }
+    reinterpret_cast<ln_f16x4*>(x0h + row * H)[lane] = hv;
+    reinterpret_cast<ln_f16x4*>(x0l + row * H)[lane] = lv;
+    if (range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(range_events, 1u);
+  }
   reinterpret_cast<f32x4*>(lang_e + row * H)[lane] = reinterpret_cast<const f32x4*>(Elang + lang[row] * H)[lane];
 }
 
@@ -745,6 +760,87 @@ __global__ void esm_attention_kernel(const float* __restrict__ q, const float* _
   float* op = o + ((long long)l * N + n) * H + h * HD;
 #pragma unroll
   for (int d = 0; d < HD; ++d) op[d] = acc[d] / sum;
+}
+
+// The same for L <= 64 utterances with ONE WAVE per (position n, head): lane = query utterance l; the L keys and values of (n, head) are staged in
+// LDS once (128-byte rows, coalesced) and read back as broadcasts, instead of every thread streaming its own copy of them through L1 with
+// 64 different cache lines per load instruction (186 us at the 64-row token front of configs[3]; this form: see DESIGN.md).  Two passes as
+// above (max, then exp and sum) in the same order of operations.  ld = row stride of q / k / v; out fp32 [.][H] and / or hi / lo planes of 16 x out.
+__global__ __launch_bounds__(256) void esm_attention_wave_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, int ldq, int ldkv, float* __restrict__ o,
+                                                                 _Float16* __restrict__ oh, long long o_plane, int L, int N, int heads,
+                                                                 float scale, unsigned* __restrict__ range_events) {
+  constexpr int HD = 32;
+  __shared__ __attribute__((aligned(16))) float kv[4][2][64][HD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;          // (n, head)
+  const bool live = unit < N * heads;              // (no early return: the barrier below is the workgroup's)
+  const int n = live ? unit / heads : 0, hh = live ? unit - n * heads : 0;
+  for (int it = 0; it < (L * 8 + 63) / 64; ++it) {
+    const int j = it * 8 + (lane >> 3), d4 = (lane & 7) * 4;
+    if (live && j < L) {
+      const long long row = ((long long)j * N + n) * ldkv + hh * HD + d4;
+      *reinterpret_cast<f32x4*>(&kv[wave][0][j][d4]) = *reinterpret_cast<const f32x4*>(k + row);
+      *reinterpret_cast<f32x4*>(&kv[wave][1][j][d4]) = *reinterpret_cast<const f32x4*>(v + row);
+    }
+  }
+  __syncthreads();
+  if (!live || lane >= L) return;
+  const int l = lane;
+  float qv[HD];
+  {
+    const float* qp = q + ((long long)l * N + n) * ldq + hh * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(qp + d);
+      qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;
+    }
+  }
+  float m = -INFINITY;
+  for (int j = 0; j < L; ++j) {
+    const float* kp = kv[wave][0][j];
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(qv[d], kp[d], s);
+    m = fmaxf(m, s);
+  }
+  float acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+  float sum = 0.f;
+  for (int j = 0; j < L; ++j) {
+    const float* kp = kv[wave][0][j];
+    const float* vp = kv[wave][1][j];
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(qv[d], kp[d], s);
+    const float e = expf(s - m);
+    sum += e;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = fmaf(e, vp[d], acc[d]);
+  }
+  const long long orow = ((long long)l * N + n) * H + hh * HD;
+  bool bad = false;
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    f32x4 t;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = acc[d + c] / sum;
+    if (o) *reinterpret_cast<f32x4*>(o + orow + d) = t;
+    if (oh) {
+      ln_f16x4 hv, lv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x = t[c] * 16.0f;
+        bad |= !(fabsf(x) < 65000.0f);
+        hv[c] = (_Float16)x;
+        lv[c] = (_Float16)(x - (float)hv[c]);
+      }
+      *reinterpret_cast<ln_f16x4*>(oh + orow + d) = hv;
+      *reinterpret_cast<ln_f16x4*>(oh + o_plane + orow + d) = lv;
+    }
+  }
+  if (range_events && bad) atomicAdd(range_events, 1u);
 }
 
 // ---- encoder -> frames ---------------------------------------------------------------------------
@@ -892,6 +988,7 @@ struct bsg_fs2midi {
   std::vector<FftLayerW> enc, dec;
   std::vector<float*> dur_conv, dur_convb, dur_lnw, dur_lnb;
   float *esm_in_w, *esm_in_b, *esm_out_w, *esm_out_b, *esm_f0w, *esm_f0b, *esm_f2w, *esm_f2b, *esm_ln1w, *esm_ln1b, *esm_ln2w, *esm_ln2b;
+  H2wWeights p_esm_q, p_esm_kv, p_esm_out, p_esm_f0, p_esm_f2;   // the ESM's Linear layers as pre-split fragments (K and V projections as one product)
   float *enc_lnw, *enc_lnb, *Emidi, *Wdur, *bdur, *Eslur, *Elang, *Estyle;
   float *dec_table, *rel_table;
   // workspace
@@ -934,6 +1031,7 @@ extern "C" void bsg_fs2midi_destroy(bsg_fs2midi* h) {
   if (h->pack_bad) (void)hipFree(h->pack_bad);
   for (std::vector<FftLayerW>* v : {&h->enc, &h->dec})
     for (FftLayerW& L : *v) { h2w_free(&L.p_in); h2w_free(&L.p_out); h2w_free(&L.p_ffn1); h2w_free(&L.p_ffn2); }
+  for (H2wWeights* p : {&h->p_esm_q, &h->p_esm_kv, &h->p_esm_out, &h->p_esm_f0, &h->p_esm_f2}) h2w_free(p);
   delete h;
 }
 
@@ -999,6 +1097,11 @@ static int fs2_create_impl(bsg_fs2midi* h, const void* const* w, const float* de
   TRY(fs2_copy(h, &h->esm_ln1b, w[i++], H, st));
   TRY(fs2_copy(h, &h->esm_ln2w, w[i++], H, st));
   TRY(fs2_copy(h, &h->esm_ln2b, w[i++], H, st));
+  TRY(h2w_pack(&h->p_esm_q, h->esm_in_w, H, H, 1, 0, H, 1, h->pack_bad, st));
+  TRY(h2w_pack(&h->p_esm_kv, h->esm_in_w + (size_t)H * H, 2 * H, H, 1, 0, H, 1, h->pack_bad, st));
+  TRY(h2w_pack(&h->p_esm_out, h->esm_out_w, H, H, 1, 0, H, 1, h->pack_bad, st));
+  TRY(h2w_pack(&h->p_esm_f0, h->esm_f0w, H, H, 1, 0, H, 1, h->pack_bad, st));
+  TRY(h2w_pack(&h->p_esm_f2, h->esm_f2w, H, H, 1, 0, H, 1, h->pack_bad, st));
   TRY(load_fft_layers(h, h->enc, w + i, c.enc_layers, c.enc_ffn_kernel_size, st));
   i += 10 * c.enc_layers;
   TRY(fs2_copy(h, &h->enc_lnw, w[i++], H, st));
@@ -1243,7 +1346,36 @@ extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int6
   const float sq = sqrtf((float)H);
   float* x0 = h->w_x;      // sqrt(H) * tok
   float* lange = h->w_b;   // lang embedding LP
-  hipLaunchKernelGGL(embed_tokens_kernel, rg, rb, 0, st, (const long long*)txt, (const long long*)lang, h->Etok, h->Elang, x0, lange, rows, sq);
+  static int esm_env = -1;   // BSG_ESM_H2W=0: the ESM's Linear layers on gemm_split_kernel and the thread-per-query attention
+  if (esm_env < 0) { const char* e = getenv("BSG_ESM_H2W"); esm_env = e ? atoi(e) : 1; }
+  static int esm_gemm_env = -1;
+  if (esm_gemm_env < 0) { const char* e = getenv("BSG_GEMM_H2W"); esm_gemm_env = e ? atoi(e) : 1; }
+  const bool esm_h2w = esm_env && esm_gemm_env && h->h2w_ok && gemm_split_enabled() && B <= 64 && h2w_supports((int)rows, H, H, 1, H) &&
+                       rows * 4 * H * 2 < (1LL << 31);
+  if (esm_h2w) {
+    // ---- ESM (common_layers.py:848-860) on the pre-split GEMM: every operand is written as hi / lo planes by its producer; the K and V
+    // projections (both of LN(lang)) are ONE product of 512 weight rows; the attention runs one wave per (position, head)
+    unsigned short* ap = h->w_ap;   // [2][rows][H]
+    unsigned short* fp = h->w_fp;   // x0 planes, later the FFN's hidden planes ([2][rows][H] of its [2][rows][4H])
+    hipLaunchKernelGGL(embed_tokens_kernel, rg, rb, 0, st, (const long long*)txt, (const long long*)lang, h->Etok, h->Elang, x0, lange, rows, sq,
+                       reinterpret_cast<_Float16*>(fp), reinterpret_cast<_Float16*>(fp) + rows * H, gemm_range_counter());
+    BSG_LAUNCH_CHECK();
+    TRY(ln_planes(lange, h->esm_ln1w, h->esm_ln1b, ap, rows, 1e-5f, st));
+    float* q = h->w_qkv;
+    float* kvp = h->w_qkv + rows * H;   // [rows][2H]: K | V
+    TRY(linear_h2w(fp, h->p_esm_q, H, h->esm_in_b, q, nullptr, rows, ACT_NONE, nullptr, nullptr, st));
+    TRY(linear_h2w(ap, h->p_esm_kv, 2 * H, h->esm_in_b + H, kvp, nullptr, rows, ACT_NONE, nullptr, nullptr, st));
+    hipLaunchKernelGGL(esm_attention_wave_kernel, dim3(cdiv(Tt * 8, 4)), dim3(256), 0, st, (const float*)q, (const float*)kvp, (const float*)(kvp + H), H,
+                       2 * H, (float*)nullptr, reinterpret_cast<_Float16*>(ap), rows * H, B, Tt, 8, (float)sqrt(1.0 / 32.0), gemm_range_counter());
+    BSG_LAUNCH_CHECK();
+    float* Mo = h->w_c;
+    TRY(linear_h2w(ap, h->p_esm_out, H, h->esm_out_b, Mo, nullptr, rows, ACT_NONE, lange, nullptr, st));       // Mo = out_proj + LP
+    TRY(ln_planes(Mo, h->esm_ln2w, h->esm_ln2b, ap, rows, 1e-5f, st));
+    TRY(linear_h2w(ap, h->p_esm_f0, H, h->esm_f0b, nullptr, fp, rows, ACT_RELU, nullptr, nullptr, st));
+    TRY(linear_h2w(fp, h->p_esm_f2, H, h->esm_f2b, h->w_a, nullptr, rows, ACT_NONE, Mo, nullptr, st));          // Fo = ffn + Mo
+  } else {
+  hipLaunchKernelGGL(embed_tokens_kernel, rg, rb, 0, st, (const long long*)txt, (const long long*)lang, h->Etok, h->Elang, x0, lange, rows, sq,
+                     (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr);
   BSG_LAUNCH_CHECK();
   // ---- ESM (common_layers.py:848-860): attention over the batch axis
   float* lpn = h->w_a;
@@ -1266,6 +1398,7 @@ extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int6
   TRY(ln(Mo, h->esm_ln2w, h->esm_ln2b, h->w_a, nullptr, rows, 1e-5f, st));
   TRY(linear(h->w_a, h->esm_f0w, h->esm_f0b, h->w_b, rows, H, H, ACT_RELU, nullptr, nullptr, st));
   TRY(linear(h->w_b, h->esm_f2w, h->esm_f2b, h->w_a, rows, H, H, ACT_NONE, Mo, nullptr, st));      // Fo = ffn + Mo
+  }
   // ---- sum of embeddings, *sqrt(H) + reversed positional table, mask
   float* x = h->w_c;
   hipLaunchKernelGGL(embed_finish_kernel, rg, rb, 0, st, (const float*)x0, (const float*)h->w_a, (const long long*)txt,
