@@ -57,8 +57,10 @@ def test_hifigan_throughput_size_vs_oracle(B, tmp_path, hifigan_sd, sd_spec):
     wave, at B = 1 (single utterance) the 128-position tiles — which the goldens (T = 16, 37) and the 3 x 150 oracle case do not reach.
     Each form of the fused ResBlock pairs is compared with the CPU ORACLE (oracle/hifigan.py, pinned to the reference's goldens;
     /root/reference/train_bisinger/modules/hifigan/hifigan.py:30-67,144-173): split-fp16 on the 16-bit matrix pipe (default), fp32 MFMA
-    (BSG_HG_SPLIT=0), VALU (BSG_HG_MFMA=0) — <= 5e-5 of the waveform's scale.  One child process per form (the switches are read once
-    per process); the oracle takes ~0.5 s per 1000 frames."""
+    (BSG_HG_SPLIT=0), VALU (BSG_HG_MFMA=0) — <= 5e-5 of the waveform's scale.  Round 4: the default also runs conv_pre and the u = 8 transposed
+    convolutions on the pre-split GEMM (polyphase store), conv_post as its own kernel and — at B = 8 — the 4-samples-per-lane u = 2 stages;
+    'vector_convs' switches those four back to the round-3 kernels.  One child process per form (the switches are read once per process);
+    the oracle takes ~0.5 s per 1000 frames."""
     import json
     import os
     import subprocess
@@ -79,7 +81,8 @@ np.save(sys.argv[2], y.cpu().numpy())
 print(json.dumps({'finite': bool(torch.isfinite(y).all())}))
 ''' % ROOT
     scale = max(1.0, float(np.abs(want).max()))
-    for name, env in (('split', {}), ('fp32_mfma', {'BSG_HG_SPLIT': '0'}), ('valu', {'BSG_HG_MFMA': '0'})):
+    for name, env in (('split', {}), ('fp32_mfma', {'BSG_HG_SPLIT': '0'}), ('valu', {'BSG_HG_MFMA': '0'}),
+                      ('vector_convs', {'BSG_HG_H2W': '0', 'BSG_NO_CONV_POST': '1', 'BSG_NO_UP2': '1'})):
         f = str(tmp_path / f'{name}.npy')
         res = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'mel.npy'), f], env=dict(os.environ, **env), capture_output=True,
                              text=True, timeout=600)
