@@ -479,6 +479,12 @@ int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
   // 64-row activation tiles when 128-row tiles would leave CUs without a second workgroup
   const long long wg128 = (long long)cdiv(g.rows, 128) * (g.Wn / 128) * g.batch;
   const bool small = wg128 < 2 * 256;
+  // 32-row tiles when even 64-row tiles leave most CUs without a workgroup (a single utterance: the product is then one workgroup's serial chain
+  // of k-steps deep, and half the MFMAs per step shorten that chain)
+  static int tiny_env = -1;
+  if (tiny_env < 0) { const char* e = getenv("BSG_H2W_TINY"); tiny_env = e ? atoi(e) : 256; }   // (workgroups of 64-row tiles below which 32-row tiles are used; 0: never)
+  const bool tiny = g.act_is_a && (long long)cdiv(g.rows, 64) * (g.Wn / 128) * g.batch < tiny_env;
+  if (tiny) return g.taps == 1 ? h2w_launch<true, 1, 4>(g, st) : h2w_launch<true, 1, 2>(g, st);
   if (g.taps == 1) {   // plain products: 64-deep slices
     if (g.act_is_a) return small ? h2w_launch<true, 2, 4>(g, st) : h2w_launch<true, 4, 4>(g, st);
     return small ? h2w_launch<false, 2, 4>(g, st) : h2w_launch<false, 4, 4>(g, st);
