@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "bsg_common.h"
+#include "diffnet_res.h"
 
 namespace bsg {
 namespace {
@@ -400,8 +401,11 @@ constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80);   // flash_attn_plane
 // and key order as flash_attn_split_kernel (its comment above).
 // Measured (T = 1000, decoder layer): 118 -> 88 us at B = 16, 99 -> 63 us at B = 1 against the first planes form (the split-in-kernel form: 270 /
 // 200 us).  PMC of this kernel (profiles/r04_flash_planes_pmc.txt): matrix pipe busy 25 % of the wave cycles, vector issue 29 %, LDS 8 %,
-// s_waitcnt 18 % — the grid is B x heads x T / 32 = 1024 waves at B = 16, ONE wave per SIMD, so nothing hides the in-order dependences of a wave;
-// the next step would be to split the keys of a query tile over two workgroups (twice the waves), not more work on this loop.
+// s_waitcnt 18 % — the grid is B x heads x T / 32 = 1024 waves at B = 16, ONE wave per SIMD, so nothing hides the in-order dependences of a wave.
+// Batches that leave SIMDs empty split the KEYS of a query tile over gridDim.z = 2 or 4 workgroups (each a shorter serial chain of key blocks);
+// the last to arrive combines the un-normalised partials in the order of z: a single utterance 63 -> 27 us per decoder layer, the 8 utterances of
+// a configs[3] rank 66 -> 50 us.  (With agent-scope fences around the count the same split was SLOWER than no split — 100 against 66 us: every
+// workgroup's release is an L2 write-back; write-through stores + sc1 loads, the residual launches' hand-off form, cost nothing measurable.)
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, _Float16* __restrict__ qk, long long qk_plane,
                                                         _Float16* __restrict__ vt, long long vt_plane, int T, int Tp,
                                                         const float* __restrict__ keep, unsigned* __restrict__ kmask,
@@ -466,7 +470,8 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_planes_kernel(const _Fl
                                                                        const _Float16* __restrict__ vt, long long vt_plane,
                                                                        const unsigned* __restrict__ kmask, int T, int Tp, int heads,
                                                                        _Float16* __restrict__ out_h, long long out_plane, int ldo,
-                                                                       unsigned* __restrict__ range_events) {
+                                                                       unsigned* __restrict__ range_events, float* __restrict__ part,
+                                                                       unsigned* __restrict__ cnt) {
   constexpr int D = 128, BK = 32, KROW = 2 * D + 16, VROW = 2 * BK + 16;   // bytes per LDS row: 272 (68 dwords = 4 mod 64), 80
   constexpr int KB = 2 * BK * KROW, VB = 2 * D * VROW;                     // K hi | K lo, V^T hi | V^T lo of one key block
   constexpr int NTH = 64 * NW, NPC = 1024 / NTH;                           // 16-byte pieces of a block's K (or V^T) per thread
@@ -613,25 +618,78 @@ __global__ __launch_bounds__(64 * NW, 1) void flash_attn_planes_kernel(const _Fl
     __syncthreads();         // this block is consumed; K(i+2) and V^T(i+1) are complete
   };
   using std::integral_constant;
-  load_k(0);
+  // key split (gridDim.z = KS > 1, small batches): this workgroup takes the key blocks [kbeg, kend) of its query tile and leaves an un-normalised
+  // partial (O, m, l); the last of the KS workgroups to arrive combines them in the order of z (below)
+  const int KS = (int)gridDim.z;
+  const int nbz = (Tp / BK + KS - 1) / KS;
+  const int kbeg = (int)blockIdx.z * nbz * BK, kend = min(T, kbeg + nbz * BK);
+  load_k(kbeg);
   store_k(0);
-  load_k(BK);
+  load_k(kbeg + BK);
   store_k(1);
-  load_v(0);
+  load_v(kbeg);
   store_v(0);
-  load_k(2 * BK);
+  load_k(kbeg + 2 * BK);
   __syncthreads();
   f32x16 S0, S1;
   scores(0, S0);
   __syncthreads();   // K buffer 0 is free for K(2)
-  for (int k0 = 0; k0 < T; k0 += 2 * BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
     const unsigned km0 = kmb[k0 >> 5];   // wave-uniform
     if (km0 == 0xffffffffu) block(integral_constant<bool, false>{}, integral_constant<int, 0>{}, k0, S0, S1, km0);
     else block(integral_constant<bool, true>{}, integral_constant<int, 0>{}, k0, S0, S1, km0);
-    if (k0 + BK >= T) break;
+    if (k0 + BK >= kend) break;
     const unsigned km1 = kmb[(k0 >> 5) + 1];
     if (km1 == 0xffffffffu) block(integral_constant<bool, false>{}, integral_constant<int, 1>{}, k0 + BK, S1, S0, km1);
     else block(integral_constant<bool, true>{}, integral_constant<int, 1>{}, k0 + BK, S1, S0, km1);
+  }
+  if (KS > 1) {
+    // partial of (unit, z): O [NW][16 register quads][64 lanes][4], m [NW][64], l [NW][64] (16 bytes per lane: coalesced).  The hand-off form of
+    // the residual launches (diffnet_h2.hip): write-through (sc1) stores, drained, a barrier, then the count; the combining workgroup reads with sc1
+    // loads — no agent-scope fence (an L2 write-back per workgroup: measured 45 us per launch of 512 workgroups)
+    constexpr int PS = NW * 64 * 66;
+    const int unit = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    const rsrc_t rp = mk_rsrc(part + (long long)unit * KS * PS, (unsigned)(KS * PS * 4));
+    const int zoff = (int)blockIdx.z * PS * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 v = {O[dt][4 * g4], O[dt][4 * g4 + 1], O[dt][4 * g4 + 2], O[dt][4 * g4 + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp, ((wave * 16 + dt * 4 + g4) * 64 + lane) * 16, zoff, 16);
+      }
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), rp, (NW * 4096 + wave * 64 + lane) * 4, zoff, 16);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l), rp, (NW * 4096 + NW * 64 + wave * 64 + lane) * 4, zoff, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* arrived = reinterpret_cast<unsigned*>(fl);   // (the key buffers are dead)
+    if (tid == 0) *arrived = __hip_atomic_fetch_add(cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*arrived != (unsigned)(KS - 1)) return;
+    if (tid == 0) __hip_atomic_store(cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    float M = -INFINITY;
+    for (int z = 0; z < KS; ++z)
+      M = fmaxf(M, __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (NW * 4096 + wave * 64 + lane) * 4, z * PS * 4, 16)));
+    const float Ms = M == -INFINITY ? 0.f : M;
+    l = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+    for (int z = 0; z < KS; ++z) {   // fixed order: the result does not depend on which workgroup combines
+      const float mz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (NW * 4096 + wave * 64 + lane) * 4, z * PS * 4, 16));
+      const float lz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (NW * 4096 + NW * 64 + wave * 64 + lane) * 4, z * PS * 4, 16));
+      const float wz = __builtin_amdgcn_exp2f(mz - Ms);
+      l = fmaf(wz, lz, l);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, ((wave * 16 + dt * 4 + g4) * 64 + lane) * 16, z * PS * 4, 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) O[dt][4 * g4 + e] = fmaf(wz, v[e], O[dt][4 * g4 + e]);
+        }
+    }
   }
   bool bad = false;
   if (q_ok) {
@@ -997,6 +1055,9 @@ struct bsg_fs2midi {
   float *w_c = nullptr;
   int* w_pos = nullptr;
   unsigned short *w_ap = nullptr, *w_fp = nullptr;   // activation planes [2][rows][H] / [2][rows][4H] fp16 (operands of gemm_h2w_kernel)
+  float* w_fsk = nullptr;                            // key-split partials of flash_attn_planes_kernel (small batches) and their arrival counters
+  unsigned* w_fcnt = nullptr;
+  size_t cap_fsk = 0, cap_fcnt = 0;
   unsigned* pack_bad = nullptr;                      // device word: packed weights beyond the fp16 range (then the pre-split GEMMs are not used)
   bool h2w_ok = false;
 };
@@ -1028,6 +1089,8 @@ extern "C" void bsg_fs2midi_destroy(bsg_fs2midi* h) {
   if (h->w_pos) (void)hipFree(h->w_pos);
   if (h->w_ap) (void)hipFree(h->w_ap);
   if (h->w_fp) (void)hipFree(h->w_fp);
+  if (h->w_fsk) (void)hipFree(h->w_fsk);
+  if (h->w_fcnt) (void)hipFree(h->w_fcnt);
   if (h->pack_bad) (void)hipFree(h->pack_bad);
   for (std::vector<FftLayerW>* v : {&h->enc, &h->dec})
     for (FftLayerW& L : *v) { h2w_free(&L.p_in); h2w_free(&L.p_out); h2w_free(&L.p_ffn1); h2w_free(&L.p_ffn2); }
@@ -1261,8 +1324,28 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
         unsigned* km = reinterpret_cast<unsigned*>(vt + 2 * vplane);   // key mask words [B][Tp / 32] behind the V^T planes
         hipLaunchKernelGGL(qkv_split_kernel, dim3(Tp / 32, B), dim3(256), 0, st, (const float*)h->w_qkv, qk, rows * 2 * H, vt, vplane, T, Tp, keep, km, gemm_range_counter());
         BSG_LAUNCH_CHECK();
-        // 2 waves (64 queries) per workgroup at every size: the pipelined loop keeps two score tiles live and does not fit 4 waves x 2 workgroups
-        hipLaunchKernelGGL(flash_attn_planes_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, (const unsigned*)km, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter());
+        // 2 waves (64 queries) per workgroup at every size: the pipelined loop keeps two score tiles live and does not fit 4 waves x 2 workgroups.
+        // Small batches: the keys of a query tile over KS workgroups (a single utterance is 32 workgroups, each a serial chain of 32 key blocks)
+        static int ks_env = -1;   // BSG_FLASH_KS: 0 = auto, 1 = never split, 2 / 4 / 8 = that many splits whenever the sequence allows
+        if (ks_env < 0) { const char* e = getenv("BSG_FLASH_KS"); ks_env = e ? atoi(e) : 0; }
+        const int units = cdiv(T, 64) * B * heads, nb = Tp / 32;
+        int ks = 1;
+        if (ks_env == 0) { while (ks < 4 && units * ks * 2 <= 512 && nb / (ks * 2) >= 4) ks *= 2; }
+        else { while (ks < ks_env && nb / (ks * 2) >= 1) ks *= 2; }
+        if (ks > 1) {
+          const size_t need = (size_t)units * ks * (2 * 64 * 66);
+          if (need > h->cap_fsk || (size_t)units > h->cap_fcnt) {
+            BSG_HIP(hipStreamSynchronize(st));
+            if (h->w_fsk) (void)hipFree(h->w_fsk);
+            if (h->w_fcnt) (void)hipFree(h->w_fcnt);
+            h->w_fsk = nullptr; h->w_fcnt = nullptr; h->cap_fsk = h->cap_fcnt = 0;
+            BSG_HIP(hipMalloc((void**)&h->w_fsk, need * sizeof(float)));
+            BSG_HIP(hipMalloc((void**)&h->w_fcnt, (size_t)units * sizeof(unsigned)));
+            BSG_HIP(hipMemsetAsync(h->w_fcnt, 0, (size_t)units * sizeof(unsigned), st));   // (the kernel leaves every counter at zero)
+            h->cap_fsk = need; h->cap_fcnt = (size_t)units;
+          }
+        }
+        hipLaunchKernelGGL(flash_attn_planes_kernel<2>, dim3(cdiv(T, 64), B * heads, ks), dim3(128), FLP_LDS, st, (const _Float16*)qk, rows * 2 * H, (const _Float16*)vt, vplane, (const unsigned*)km, T, Tp, heads, reinterpret_cast<_Float16*>(ap), rows * H, H, gemm_range_counter(), h->w_fsk, h->w_fcnt);
       } else if (wg4 >= 512) hipLaunchKernelGGL(flash_attn_split_kernel<4>, dim3(cdiv(T, 128), B * heads), dim3(256), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
       else hipLaunchKernelGGL(flash_attn_split_kernel<2>, dim3(cdiv(T, 64), B * heads), dim3(128), 0, st, (const float*)h->w_qkv, keep, (float*)nullptr, T, heads, 3 * H, H, gemm_range_counter(), reinterpret_cast<_Float16*>(ap), rows * H);
       BSG_LAUNCH_CHECK();
