@@ -473,6 +473,9 @@ def secondary_captured(model, device, fence):
                 g.replay()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 3
+            xg.copy_(x0)                                     # the sampler updates x in place: the comparison replay starts from the eager run's x_T
+            g.replay()
+            torch.cuda.synchronize()
         torch.cuda.current_stream().wait_stream(side)
         return {'what': 'hipGraph capture of the 100-step sampler loop at B=16, T=1000 (sampler only: no FS2), replayed 3 times',
                 'captured_path': cap_path, 'eager_path': eager_path, 'ms_per_replay': dt * 1e3, 'ms_per_eager_call': dt_eager * 1e3,
