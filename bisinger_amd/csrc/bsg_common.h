@@ -115,6 +115,12 @@ struct H2wArgs {
   // polyphase output (act_is_a = 0 only; up_u = 0: off) — a transposed convolution with kernel 2 u, stride u as ONE 2-tap product: weight row
   // n = co * up_u + r, activation row q; C[co * ldc + q * up_u + r - up_p] for positions inside [0, up_lout); bias per co
   int up_u, up_p, up_lout;
+  // FS2 QKV projection feeding flash_attn_planes_kernel (act_is_a = 1 only; qkv_T = 0: off): weight rows 0 .. 2 qkv_H - 1 (Q | K) go to the planes
+  // `out` as usual (ldo = 2 qkv_H), weight rows >= 2 qkv_H (V) are written TRANSPOSED as planes vt[(b * qkv_H + d) * qkv_Tp + key'] (lo plane
+  // vt_plane halfs behind), b = row / qkv_T, keys of a group of 16 in MFMA-fragment order (0-3, 8-11, 4-7, 12-15), keys qkv_T .. qkv_Tp - 1 zero
+  int qkv_T, qkv_Tp, qkv_H;
+  unsigned short* vt;
+  long long vt_plane;
 };
 bool h2w_supports(int rows, int Wn, int K, int taps, int lda);
 // W(tap, n, k) at src[tap * ts + n * rs + k * ks]; allocates w->pack on first use; |16 w| >= 65000 counted into *bad_dev (device word)

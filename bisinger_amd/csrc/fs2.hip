@@ -393,7 +393,8 @@ constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80);   // flash_attn_plane
 // ---- round 4: the fused attention on PRE-SPLIT operands -------------------------------------------------------------------------------
 // flash_attn_split_kernel splits K and V while it stages every 32-key block — and transposes V with 2-byte LDS writes — once per 64 or 128
 // queries: at T = 1000 a K / V element is split 8-16 times, between two barriers and with its global loads exposed.  Here
-// qkv_split_kernel splits the QKV projection's output ONCE into fp16 planes — Q and K as [row][256] (hi, lo), V TRANSPOSED as
+// qkv_split_kernel (BSG_QKV_FUSED=0; by default the QKV product's own epilogue, H2wArgs::qkv_T — one launch less per layer) splits the QKV
+// projection's output ONCE into fp16 planes — Q and K as [row][256] (hi, lo), V TRANSPOSED as
 // [b][256 (head, d)][Tp keys] (Tp = T rounded up to 32, the padding zeroed; keys in fragment order within groups of 16) — plus one mask word per (utterance, 32-key block), and
 // flash_attn_planes_kernel stages a key block as plain 16-byte copies while the MFMAs of the blocks before it run: K two blocks ahead, V^T one,
 // one barrier per block, no vector arithmetic in the staging, the softmax in the log2 domain (v_exp_f32, the 2^10 of the P operand folded into the
@@ -406,6 +407,15 @@ constexpr int FLP_LDS = 2 * (2 * 32 * 272 + 2 * 128 * 80);   // flash_attn_plane
 // the last to arrive combines the un-normalised partials in the order of z: a single utterance 63 -> 27 us per decoder layer, the 8 utterances of
 // a configs[3] rank 66 -> 50 us.  (With agent-scope fences around the count the same split was SLOWER than no split — 100 against 66 us: every
 // workgroup's release is an L2 write-back; write-through stores + sc1 loads, the residual launches' hand-off form, cost nothing measurable.)
+// mask words of flash_attn_planes_kernel when the QKV product writes the planes itself (H2wArgs::qkv_T): one wave per (utterance, 32-key block)
+__global__ __launch_bounds__(256) void key_mask_kernel(const float* __restrict__ keep, unsigned* __restrict__ kmask, int B, int T, int Tp) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, nblk = Tp / 32;
+  if (w >= B * nblk) return;
+  const int b = w / nblk, t = (w - b * nblk) * 32 + lane;
+  const unsigned long long mk = __builtin_amdgcn_ballot_w64(lane < 32 && t < T && keep[(long long)b * T + t] != 0.f);
+  if (lane == 0) kmask[w] = (unsigned)mk;
+}
+
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* __restrict__ qkv, _Float16* __restrict__ qk, long long qk_plane,
                                                         _Float16* __restrict__ vt, long long vt_plane, int T, int Tp,
                                                         const float* __restrict__ keep, unsigned* __restrict__ kmask,
@@ -1312,18 +1322,36 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
       }
     }
     const int Tp = cdiv(T, 32) * 32;
+    static int qkv_fused = -1;   // BSG_QKV_FUSED=0: fp32 QKV tensor + qkv_split_kernel instead of the QKV product's own plane output
+    if (qkv_fused < 0) { const char* e = getenv("BSG_QKV_FUSED"); qkv_fused = e ? atoi(e) : 1; }
     for (const FftLayerW& L : layers) {
       TRY(ln_planes(x, L.ln1w, L.ln1b, ap, rows, 1e-5f, st));
-      TRY(linear_h2w(ap, L.p_in, 3 * H, nullptr, h->w_qkv, nullptr, rows, ACT_NONE, nullptr, nullptr, st, qscale, H));
       const long long wg4 = (long long)cdiv(T, 128) * B * heads;
-      if (fplanes && Tp <= 3 * T && rows >= 32) {
-        // Q | K planes [2][rows][2H] in the (not yet written) FFN planes buffer, V^T planes [2][B][H][Tp] in the fp32 FFN buffer this path does not use
-        _Float16* qk = reinterpret_cast<_Float16*>(fp);
-        _Float16* vt = reinterpret_cast<_Float16*>(h->w_ffn);
-        const long long vplane = (long long)B * H * Tp;
-        unsigned* km = reinterpret_cast<unsigned*>(vt + 2 * vplane);   // key mask words [B][Tp / 32] behind the V^T planes
-        hipLaunchKernelGGL(qkv_split_kernel, dim3(Tp / 32, B), dim3(256), 0, st, (const float*)h->w_qkv, qk, rows * 2 * H, vt, vplane, T, Tp, keep, km, gemm_range_counter());
-        BSG_LAUNCH_CHECK();
+      const bool use_planes = fplanes && Tp <= 3 * T && rows >= 32;
+      // Q | K planes [2][rows][2H] in the (not yet written) FFN planes buffer, V^T planes [2][B][H][Tp] in the fp32 FFN buffer this path does not use
+      _Float16* qk = reinterpret_cast<_Float16*>(fp);
+      _Float16* vt = reinterpret_cast<_Float16*>(h->w_ffn);
+      const long long vplane = (long long)B * H * Tp;
+      unsigned* km = reinterpret_cast<unsigned*>(vt + 2 * vplane);   // key mask words [B][Tp / 32] behind the V^T planes
+      if (use_planes && qkv_fused) {
+        // the QKV product writes the attention's planes itself (H2wArgs::qkv_T): no fp32 QKV tensor, no split launch; the mask words once per stack
+        if (&L == &layers.front()) {
+          hipLaunchKernelGGL(key_mask_kernel, dim3(cdiv(B * (Tp / 32), 4)), dim3(256), 0, st, keep, km, B, T, Tp);
+          BSG_LAUNCH_CHECK();
+        }
+        H2wArgs g{};
+        g.act = ap; g.act_plane = rows * H; g.lda = H; g.wpack = L.p_in.pack; g.rows = (int)rows; g.K = H; g.Wn = 3 * H; g.taps = 1; g.act_is_a = 1;
+        g.out = fp; g.out_plane = rows * 2 * H; g.ldo = 2 * H; g.alpha = qscale; g.alpha_ncols = H; g.act_fn = ACT_NONE; g.batch = 1;
+        g.qkv_T = T; g.qkv_Tp = Tp; g.qkv_H = H; g.vt = h->w_ffn ? reinterpret_cast<unsigned short*>(h->w_ffn) : nullptr; g.vt_plane = vplane;
+        TRY(launch_gemm_h2w(g, st));
+      } else {
+        TRY(linear_h2w(ap, L.p_in, 3 * H, nullptr, h->w_qkv, nullptr, rows, ACT_NONE, nullptr, nullptr, st, qscale, H));
+      }
+      if (use_planes) {
+        if (!qkv_fused) {
+          hipLaunchKernelGGL(qkv_split_kernel, dim3(Tp / 32, B), dim3(256), 0, st, (const float*)h->w_qkv, qk, rows * 2 * H, vt, vplane, T, Tp, keep, km, gemm_range_counter());
+          BSG_LAUNCH_CHECK();
+        }
         // 2 waves (64 queries) per workgroup at every size: the pipelined loop keeps two score tiles live and does not fit 4 waves x 2 workgroups.
         // Small batches: the keys of a query tile over KS workgroups (a single utterance is 32 workgroups, each a serial chain of 32 key blocks)
         static int ks_env = -1;   // BSG_FLASH_KS: 0 = auto, 1 = never split, 2 / 4 / 8 = that many splits whenever the sequence allows

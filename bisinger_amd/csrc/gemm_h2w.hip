@@ -335,6 +335,62 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
   bool bad = false;
   const bool vec = (g.ldc & 3) == 0 && (((uintptr_t)Cp) & 15) == 0;
   const int wrow0 = wt128 * 128;
+  if (ACT_IS_A && g.qkv_T && wrow0 >= 2 * g.qkv_H) {
+    // V tile of the QKV projection -> V^T planes (what qkv_split_kernel did in a launch of its own): item = 4 consecutive keys of one (head, d)
+    // column; lanes run along the keys (8-byte stores, contiguous within a V^T row)
+    using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+    const int T = g.qkv_T, Tp = g.qkv_Tp;
+    _Float16* __restrict__ vth = reinterpret_cast<_Float16*>(g.vt);
+    constexpr int NRG = BMA / 4;
+    auto stored = [](int t) { const int g4 = (t >> 2) & 3; return (t & ~15) + ((((g4 & 1) << 1) | (g4 >> 1)) << 2) + (t & 3); };   // fragment order inside 16 keys
+#pragma unroll 1
+    for (int it = tid; it < 128 * NRG; it += 256) {
+      const int cc = it / NRG, rg = it - cc * NRG;
+      const int row0 = arow0 + 4 * rg;
+      if (row0 >= g.rows) continue;
+      const int d = wrow0 + cc - 2 * g.qkv_H;
+      const float bv = bias ? bias[wrow0 + cc] : 0.f;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = et[(4 * rg + e) * EP + cc] * H2W_OUT + bv;
+        if (g.alpha_ncols == 0 || wrow0 + cc < g.alpha_ncols) x *= g.alpha;
+        v[e] = x * H2W_IN;
+        bad |= !(fabsf(v[e]) < 65000.0f) && row0 + e < g.rows;
+      }
+      const int b0 = row0 / T, t0 = row0 - b0 * T;
+      if ((T & 3) == 0 && row0 + 3 < g.rows) {   // the 4 keys belong to one utterance and stay consecutive in the stored order
+        f16x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hv[e] = (_Float16)v[e]; lv[e] = (_Float16)(v[e] - (float)hv[e]); }
+        _Float16* dst = vth + ((long long)b0 * g.qkv_H + d) * Tp;
+        *reinterpret_cast<f16x4*>(dst + stored(t0)) = hv;
+        *reinterpret_cast<f16x4*>(dst + g.vt_plane + stored(t0)) = lv;
+        if (t0 + 4 == T) {   // the utterance's last keys: zero the padding T .. Tp - 1
+          const f16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          for (int t = T; t < Tp; t += 4) {
+            *reinterpret_cast<f16x4*>(dst + stored(t)) = z;
+            *reinterpret_cast<f16x4*>(dst + g.vt_plane + stored(t)) = z;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = row0 + e;
+          if (row >= g.rows) break;
+          const int b = row / T, t = row - b * T;
+          _Float16* dst = vth + ((long long)b * g.qkv_H + d) * Tp;
+          const _Float16 h = (_Float16)v[e];
+          dst[stored(t)] = h;
+          dst[g.vt_plane + stored(t)] = (_Float16)(v[e] - (float)h);
+          if (t + 1 == T)
+            for (int tz = T; tz < Tp; ++tz) { dst[stored(tz)] = (_Float16)0.f; dst[g.vt_plane + stored(tz)] = (_Float16)0.f; }
+        }
+      }
+    }
+    if (g.range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(g.range_events, 1u);
+    return;
+  }
 #pragma unroll 1
   for (int it = tid; it < ER * EC / 4; it += 256) {
     const int er = it / (EC / 4), ec = (it - er * (EC / 4)) * 4;
@@ -474,6 +530,9 @@ int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
   BSG_REQUIRE(g.up_u == 0 || (g.up_u == 8 && !g.act_is_a && g.C && g.up_p % 4 == 0 && g.up_lout > 0 && g.act_fn == ACT_NONE && !g.R && !g.rowscale &&
                               g.alpha == 1.f && g.sBias == 0),
               "gemm_h2w: polyphase output: up_u=%d act_is_a=%d", g.up_u, g.act_is_a);
+  BSG_REQUIRE(g.qkv_T == 0 || (g.act_is_a && g.out && g.vt && g.batch == 1 && g.qkv_H % 128 == 0 && g.Wn == 3 * g.qkv_H && g.ldo == 2 * g.qkv_H &&
+                               g.qkv_Tp % 32 == 0 && g.qkv_Tp >= g.qkv_T && g.rows % g.qkv_T == 0 && !g.C && g.act_fn == ACT_NONE && !g.R && !g.rowscale),
+              "gemm_h2w: QKV output: T=%d Tp=%d H=%d Wn=%d", g.qkv_T, g.qkv_Tp, g.qkv_H, g.Wn);
   if (g.zdiv <= 0) g.zdiv = g.batch;
   g.range_events = gemm_range_counter();
   // 64-row activation tiles when 128-row tiles would leave CUs without a second workgroup
