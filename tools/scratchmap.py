@@ -3,7 +3,7 @@
 matrix instructions (M<n>), scratch loads (L<n>), scratch stores (S<n>) and barriers (|) with the branch targets, so that one can see
 whether a spill lands inside a matrix loop (a block that branches to itself with M48) or at a phase boundary.
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o /tmp/h2.s bisinger_amd/csrc/diffnet_h2.hip
-    python tools/scratchmap.py /tmp/h2.s [ILb0ELb1ELi2ELb1E ...]      (template arguments as mangled: FAIR, TAIL, NCT, PERSIST)"""
+    python tools/scratchmap.py /tmp/h2.s [ILb1ELb1ELi2E ...]      (template arguments as mangled: FAIR, TAIL, NCT)"""
 import re,sys
 lines=open(sys.argv[1]).read().split('\n')
 starts=[(i,l.split(':')[0]) for i,l in enumerate(lines) if re.match(r'^_ZN3bsg.*residual_stack_h2_kernel.*:',l)]
