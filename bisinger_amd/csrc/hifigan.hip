@@ -789,51 +789,62 @@ __global__ void pack_conv_h2_kernel(const float* __restrict__ w, _Float16* __res
 }
 
 // acc[rt][nb] += W * img for one conv: img = LDS planes [rows][rowb] (lo plane at + plane), this wave's positions start at row n0; tap k
-// reads row p + k * dil
+// reads row p + k * dil.
+// The weight fragments stream from L2 through a RING of D k-steps (round 4).  Until round 3 they were requested ONE k-step ahead: a k-step is
+// 12 (C = 64) or 6 (C = 32) MFMAs = 384 / 192 matrix clocks, an L2 round trip is ~1 000, so every k-step ended waiting for its weights (the
+// pairs ran at 13-32 % of the matrix pipe).  D = 4 k-steps for 64 channels (1 536 clocks ahead), 8 for 32; the loop over taps and channel slices
+// is fully unrolled so that the ring slots are compile-time registers.
 template <int K, int C, int NB>
 __device__ __forceinline__ void conv_h2(f32x16 (&acc)[C / 32][NB], const _Float16* __restrict__ wpk, const char* img, int rowb, int plane,
                                         int n0, int dil, int lane) {
-  constexpr int RT = C / 32, KS = C / 16;
+  constexpr int RT = C / 32, KS = C / 16, NS = K * KS;
+  constexpr int D0 = RT == 2 ? 4 : 8, D = D0 < NS ? D0 : NS;
   const int l31 = lane & 31, lh = lane >> 5;
   const hf16x8* __restrict__ wp = reinterpret_cast<const hf16x8*>(wpk) + lane;
   const char* bp = img + (n0 + l31) * rowb + lh * 16;
-  hf16x8 A[2][RT][2];
+  hf16x8 A[D][RT][2];
+  auto lda = [&](int i, int slot) {   // k-step i = tap i / KS, channel slice i % KS
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    A[0][rt][0] = wp[((rt * K) * KS) * 128];
-    A[0][rt][1] = wp[((rt * K) * KS) * 128 + 64];
-  }
-#pragma unroll 1
-  for (int k = 0; k < K; ++k) {
-    const char* bk = bp + k * dil * rowb;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      // weights of the next k-step (the first of the next tap after the last of this one; a harmless repeat at the very end)
-      const int kn = ks + 1 < KS ? k : (k + 1 < K ? k + 1 : k), sn = ks + 1 < KS ? ks + 1 : (k + 1 < K ? 0 : ks);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        A[(ks + 1) & 1][rt][0] = wp[((rt * K + kn) * KS + sn) * 128];
-        A[(ks + 1) & 1][rt][1] = wp[((rt * K + kn) * KS + sn) * 128 + 64];
-      }
-      hf16x8 bh[NB], bl[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        bh[nb] = *reinterpret_cast<const hf16x8*>(bk + 32 * nb * rowb + ks * 32);
-        bl[nb] = *reinterpret_cast<const hf16x8*>(bk + 32 * nb * rowb + ks * 32 + plane);
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][rt][0], bh[nb], acc[rt][nb], 0, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][rt][0], bl[nb], acc[rt][nb], 0, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ks & 1][rt][1], bh[nb], acc[rt][nb], 0, 0, 0);
+    for (int rt = 0; rt < RT; ++rt) {
+      A[slot][rt][0] = wp[((rt * K + i / KS) * KS + i % KS) * 128];
+      A[slot][rt][1] = wp[((rt * K + i / KS) * KS + i % KS) * 128 + 64];
     }
+  };
+#pragma unroll
+  for (int i = 0; i < D; ++i) lda(i, i);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int k = i / KS, ks = i % KS;
+    const char* bk = bp + k * dil * rowb;
+    hf16x8 bh[NB], bl[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      bh[nb] = *reinterpret_cast<const hf16x8*>(bk + 32 * nb * rowb + ks * 32);
+      bl[nb] = *reinterpret_cast<const hf16x8*>(bk + 32 * nb * rowb + ks * 32 + plane);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i % D][rt][0], bh[nb], acc[rt][nb], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i % D][rt][0], bl[nb], acc[rt][nb], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i % D][rt][1], bh[nb], acc[rt][nb], 0, 0, 0);
+    if (i + D < NS) lda(i + D, i % D);   // the slot is free: refill it D k-steps ahead
+    // pin the issue order (the scheduler otherwise sinks the refills towards their use to save registers, which is the round-3 form again):
+    // the B fragments' LDS reads, then the MFMAs with the ring's refills among the first of them
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);
+#pragma unroll
+    for (int q = 0; q < 2 * RT; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * RT * NB - 2 * RT, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -861,19 +872,31 @@ __global__ __launch_bounds__(256) void resblock_pair_h2_kernel(PairArgs a) {
     }
   };
   // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
-  for (int idx = tid; idx < (C / 4) * span; idx += 256) {
-    const int cq = idx / span, jx = idx - cq * span;
-    const int t = t0 - H2 - h1 + jx;
-    float v[4];
+  // (4 items' loads are requested before the first of them is split and written: the trip count depends on the dilation, so the compiler
+  // leaves the loop rolled, and a rolled loop pays one memory round trip per item — ~10 per thread)
+  for (int idx0 = tid; idx0 < (C / 4) * span; idx0 += 4 * 256) {
+    float v[4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = (t >= 0 && t < a.L) ? xb[(long long)(4 * cq + e) * a.L + t] : 0.f;
-      v[e] = fmaxf(x, x * slope);
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + 256 * u;
+      const int cq = idx / span, jx = idx - cq * span;
+      const int t = t0 - H2 - h1 + jx;
+      const bool ok = idx < (C / 4) * span && t >= 0 && t < a.L;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[u][e] = ok ? xb[(long long)(4 * cq + e) * a.L + t] : 0.f;
     }
-    hf16x4 hi, lo;
-    split4(v, hi, lo);
-    *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
-    *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + 256 * u;
+      if (idx >= (C / 4) * span) break;
+      const int cq = idx / span, jx = idx - cq * span;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[u][e] = fmaxf(v[u][e], v[u][e] * slope);
+      hf16x4 hi, lo;
+      split4(v[u], hi, lo);
+      *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
+      *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+    }
   }
   const int n0 = 32 * NB * wave;
   f32x16 acc[RT][NB];
@@ -1077,19 +1100,30 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
     }
   };
   // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
-  for (int idx = tid; idx < (C / 4) * span; idx += 256) {
-    const int cq = idx / span, jx = idx - cq * span;
-    const int t = t0 - H2 - h1 + jx;
-    float v[4];
+  // (the loads of 4 items are requested before the first of them is split and written: see resblock_pair_h2_kernel)
+  for (int idx0 = tid; idx0 < (C / 4) * span; idx0 += 4 * 256) {
+    float v[4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = (t >= 0 && t < a.L) ? xb[(long long)(4 * cq + e) * a.L + t] : 0.f;
-      v[e] = fmaxf(x, x * slope);
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + 256 * u;
+      const int cq = idx / span, jx = idx - cq * span;
+      const int t = t0 - H2 - h1 + jx;
+      const bool ok = idx < (C / 4) * span && t >= 0 && t < a.L;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[u][e] = ok ? xb[(long long)(4 * cq + e) * a.L + t] : 0.f;
     }
-    hf16x4 hi, lo;
-    split4(v, hi, lo);
-    *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
-    *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = idx0 + 256 * u;
+      if (idx >= (C / 4) * span) break;
+      const int cq = idx / span, jx = idx - cq * span;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[u][e] = fmaxf(v[u][e], v[u][e] * slope);
+      hf16x4 hi, lo;
+      split4(v[u], hi, lo);
+      *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
+      *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+    }
   }
   const int n0 = 32 * NB * wave;
   const bool rows_ok = 4 * kb < C;   // C = 8: accumulator rows 8..15 do not exist
