@@ -180,10 +180,18 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(PairArgs a) {
   // ---- A: conv1 (dilation d) at u = t0 - H2 + tid + 256 j ---------------------------------------------------------------
   for (int ci0 = 0; ci0 < C; ci0 += CI) {
     __syncthreads();
-    for (int idx = tid; idx < CI * span; idx += 256) {
-      const int ci = idx / span, jx = idx - ci * span;
-      const int t = t0 - H2 - h1 + jx;
-      lds[idx] = (t >= 0 && t < a.L) ? xb[(long long)(ci0 + ci) * a.L + t] : 0.f;
+    for (int idx0 = tid; idx0 < CI * span; idx0 += 4 * 256) {   // (4 loads in flight per thread: the trip count is not a constant, the loop stays rolled)
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + 256 * u;
+        const int ci = idx / span, jx = idx - ci * span;
+        const int t = t0 - H2 - h1 + jx;
+        v[u] = (idx < CI * span && t >= 0 && t < a.L) ? xb[(long long)(ci0 + ci) * a.L + t] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (idx0 + 256 * u < CI * span) lds[idx0 + 256 * u] = v[u];
     }
     __syncthreads();
 #pragma unroll 1
