@@ -880,6 +880,23 @@ __global__ __launch_bounds__(256) void resblock_pair_h2_kernel(PairArgs a) {
     }
   };
   // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
+  // the residual's x values in accumulator layout, requested first (see resblock_pair_h16_kernel): the staging loop then finds their lines in
+  // L2, and the epilogue does not fetch the tile's x from HBM a second time.  Only where the 32 registers do not cost a resident wave: C = 32
+  // with K = 3 (117 -> 93 us); with the 8-slot weight ring of K = 7 / 11 the kernel drops from 3 to 2 waves per SIMD and runs 8 % SLOWER
+  // (191 / 150 against 177 / 137 us), and C = 64 would need 64 registers
+  constexpr bool XRES = C == 32 && K == 3;
+  float xres[XRES ? NB : 1][XRES ? RT : 1][16];
+  if constexpr (XRES) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int pcol = 32 * NB * wave + 32 * nb + l31, t = t0 + pcol;
+      const bool ok = pcol < POUT && t < a.L;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xres[nb][rt][r] = ok ? xb[(long long)(32 * rt + 4 * lh + (r & 3) + 8 * (r >> 2)) * a.L + t] : 0.f;
+    }
+  }
   // (4 items' loads are requested before the first of them is split and written: the trip count depends on the dilation, so the compiler
   // leaves the loop rolled, and a rolled loop pays one memory round trip per item — ~10 per thread)
   for (int idx0 = tid; idx0 < (C / 4) * span; idx0 += 4 * 256) {
@@ -971,7 +988,10 @@ __global__ __launch_bounds__(256) void resblock_pair_h2_kernel(PairArgs a) {
       const long long i0 = ((long long)b * C + 32 * rt + 4 * lh) * a.L + t;
       float xr[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xr[r] = a.x[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L];
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (XRES) xr[r] = xres[nb][rt][r];
+        else xr[r] = a.x[i0 + (long long)((r & 3) + 8 * (r >> 2)) * a.L];
+      }
       if (has_acc) {
         float ar[16];
 #pragma unroll
@@ -1108,6 +1128,19 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
     }
   };
   // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
+  // the residual's x values in ACCUMULATOR layout (16 registers), requested first: the staging loop below then finds their lines in L2 instead
+  // of the epilogue fetching the tile's x from HBM a second time, ~100 us after it was staged (PMC: 2.7 x the tensor fetched per pair)
+  float xres[2 * NB][4];
+  {
+    const bool rows_ok_ = 4 * (lane >> 4) < C;
+#pragma unroll
+    for (int ct = 0; ct < 2 * NB; ++ct) {
+      const int pcol = 32 * NB * wave + 16 * ct + (lane & 15), t = t0 + pcol;
+      const bool ok = rows_ok_ && pcol < POUT && t < a.L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[ct][r] = ok ? xb[(long long)(4 * (lane >> 4) + r) * a.L + t] : 0.f;
+    }
+  }
   // (the loads of 4 items are requested before the first of them is split and written: see resblock_pair_h2_kernel)
   for (int idx0 = tid; idx0 < (C / 4) * span; idx0 += 4 * 256) {
     float v[4][4];
@@ -1188,7 +1221,7 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
     const long long i0 = ((long long)b * C + 4 * kb) * a.L + t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = acc[ct][r] * ACC_INV + a.x[i0 + (long long)r * a.L];
+      float v = acc[ct][r] * ACC_INV + xres[ct][r];
       if (has_acc) v = a.acc_in[i0 + (long long)r * a.L] + v;
       if (has_div) v = v / a.out_div;
       a.y[i0 + (long long)r * a.L] = v;
