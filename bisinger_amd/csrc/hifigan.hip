@@ -1254,13 +1254,23 @@ int launch_pair_h16(const PairArgs& a, int K, int C, int B, hipStream_t st) {
     if (K == 7) return launch_pair_h16_kc<7, 16>(a, B, st);
     if (K == 11) return launch_pair_h16_kc<11, 16>(a, B, st);
   }
+  if (C == 8) {
+    if (K == 3) return launch_pair_h16_kc<3, 8>(a, B, st);
+    if (K == 7) return launch_pair_h16_kc<7, 8>(a, B, st);
+    if (K == 11) return launch_pair_h16_kc<11, 8>(a, B, st);
+  }
   set_error("hifigan: no 16-row split-fp16 pair kernel for K=%d, C=%d", K, C);
   return BSG_EINVAL;
 }
-// (the kernel is written for C = 8 too — 4 taps x 8 channels per k-step, half of the MFMA's rows unused — but measured SLOWER there than the VALU
-// pairs it would replace: 220 / 208 / 150 us against 199 / 153 / 96 us for K = 11 / 7 / 3 at B=16, T=1000; for C = 16: 180 / 161 / 118 against
-// 355 / 223 / 126 us.  Only the 16-channel form is instantiated.)
-bool pair_h16_supported(int K, int C) { return (K == 3 || K == 7 || K == 11) && C == 16; }
+// (C = 8 — 4 taps x 8 channels per k-step, half of the MFMA's rows unused — measured SLOWER in round 3 than the VALU pairs it would replace: 220 / 208
+// / 150 us against 199 / 153 / 96 us for K = 11 / 7 / 3 at B=16, T=1000; for C = 16: 180 / 161 / 118 against 355 / 223 / 126 us.  With round 4's
+// staging and residual prefetch: 176 / 160 / 120 us — ahead for K = 11 only, which is what the default takes.)
+// BSG_HG_H16_C8: 8-channel pairs on the 16-row matrix form — default 11 = only K = 11 (176 against 195 us; K = 7 / 3 are faster on the vector
+// pipe: 146 / 93 against 160 / 120 us), 0 = never, 1 = every K
+static int h16_c8() { static int v = -1; if (v < 0) { const char* e = getenv("BSG_HG_H16_C8"); v = e ? atoi(e) : 11; } return v; }
+bool pair_h16_supported(int K, int C) {
+  return (K == 3 || K == 7 || K == 11) && (C == 16 || (C == 8 && (h16_c8() == 1 || (h16_c8() == 11 && K == 11))));
+}
 
 
 template <int K, int C, int NB>
