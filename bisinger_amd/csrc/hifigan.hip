@@ -525,11 +525,20 @@ __global__ __launch_bounds__(256) void upsample2_kernel(UpArgs a) {
   for (int ci0 = 0; ci0 < a.Cin; ci0 += CIC) {
     __syncthreads();
     // xs[ci][j] = x[2 m0 - 1 + j], j in [0, 514): lane tid reads j = 2 tid .. 2 tid + 3 (two aligned 8-byte reads)
-    for (int idx = tid; idx < CIC * 514; idx += 256) {
-      const int ci = idx / 514, j = idx - ci * 514;
-      const int t = 2 * m0 - 1 + j;
-      const float v = (ci0 + ci < a.Cin && t >= 0 && t < a.Lin) ? xb[(long long)(ci0 + ci) * a.Lin + t] : 0.f;
-      xs[ci][j] = fmaxf(v, v * a.slope);
+    for (int idx0 = tid; idx0 < CIC * 514; idx0 += 8 * 256) {   // 8 loads in flight per thread (a rolled load -> store loop pays one round trip per item)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + 256 * u;
+        const int ci = idx / 514, j = idx - ci * 514;
+        const int t = 2 * m0 - 1 + j;
+        v[u] = (idx < CIC * 514 && ci0 + ci < a.Cin && t >= 0 && t < a.Lin) ? xb[(long long)(ci0 + ci) * a.Lin + t] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = idx0 + 256 * u;
+        if (idx < CIC * 514) xs[idx / 514][idx % 514] = fmaxf(v[u], v[u] * a.slope);
+      }
     }
     __syncthreads();
     const int nci = a.Cin - ci0 < CIC ? a.Cin - ci0 : CIC;
