@@ -68,15 +68,18 @@ __global__ __launch_bounds__(256) void conv1d_kernel(ConvArgs a) {
 
   for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CHUNK) {
     __syncthreads();
-    for (int idx = tid; idx < CI_CHUNK * span; idx += 256) {
-      const int ci = idx / span, j = idx - ci * span;
-      const int t = t0 - a.pad + j;
-      float v = 0.f;
-      if (ci0 + ci < a.Cin && t >= 0 && t < a.L) {
-        v = xb[(long long)(ci0 + ci) * a.L + t];
-        v = v > 0.f ? v : v * a.in_slope;
+    for (int idx0 = tid; idx0 < CI_CHUNK * span; idx0 += 4 * 256) {   // 4 loads in flight per thread (the rolled load -> store loop paid a round trip per item)
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + 256 * u;
+        const int ci = idx / span, j = idx - ci * span;
+        const int t = t0 - a.pad + j;
+        v[u] = (idx < CI_CHUNK * span && ci0 + ci < a.Cin && t >= 0 && t < a.L) ? xb[(long long)(ci0 + ci) * a.L + t] : 0.f;
       }
-      xs[idx] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (idx0 + 256 * u < CI_CHUNK * span) xs[idx0 + 256 * u] = v[u] > 0.f ? v[u] : v[u] * a.in_slope;
     }
     __syncthreads();
     const int nci = (a.Cin - ci0) < CI_CHUNK ? (a.Cin - ci0) : CI_CHUNK;
