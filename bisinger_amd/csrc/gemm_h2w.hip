@@ -26,7 +26,8 @@ using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 constexpr float H2W_IN = 16.0f, H2W_OUT = 1.0f / 256.0f;
 constexpr int H2W_BK = 32;          // k extent of a slice in the packed weights' step order (two MFMA steps of 16 per tap)
 // LDS bytes per activation row and slice: 32 (or 64) fp16 + 16 pad = 80 / 144 B = 20 / 36 dwords: the 16 rows of a b128 lane group cover the 64 banks once
-constexpr int H2W_NS = 4;           // weight ring, in k-steps of 16
+// weight ring, in k-steps of 16: template argument NS = 4 for 128-row activation tiles (12 MFMAs per k-step: 1 536 matrix clocks ahead, an L2 round
+// trip is ~1 000), 8 for 64-row tiles (6 per k-step), 16 for 32-row tiles (3 per k-step) — where it divides the number of k-steps
 constexpr int H2W_MAXTAPS = 17;
 
 // out[((step * 2 + plane) * WT + wt) * 512 + lane * 8 + j] = plane ? lo : hi of 16 x W(tap, n = 32 wt + (lane & 31), k = 32 slice + 16 kk + 8 (lane >> 5) + j)
@@ -120,11 +121,11 @@ __global__ __launch_bounds__(256) void h2w_split_transposed_kernel(const float* 
 // KK = MFMA steps of 16 per slice and tap: 2 (32-deep slices) for convolutions, whose slices are long (2 x taps steps); 4 (64-deep slices)
 // for plain products (taps = 1): with 32-deep slices the staging loads of a slice were requested 768 matrix cycles before they are
 // written to LDS — about the L2 latency, so every slice ended in a stall — and a barrier stood behind every 24 MFMAs.
-template <bool ACT_IS_A, int MI, int KK>
+template <bool ACT_IS_A, int MI, int KK, int H2W_NS>
 __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
   constexpr int BMA = 32 * MI;
   constexpr int BK = 16 * KK, H2W_ROWB = 2 * BK + 16, PPR = 2 * KK;   // pieces of 16 bytes per row and plane
-  constexpr int NPH = ((BMA + (KK == 4 ? 0 : H2W_MAXTAPS - 1)) * PPR + 255) / 256;   // 16-byte pieces per thread, plane and slice
+  constexpr int NPH = ((BMA + (KK >= 4 ? 0 : H2W_MAXTAPS - 1)) * PPR + 255) / 256;   // 16-byte pieces per thread, plane and slice
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
 }
 #undef BSG_MFMA_W
 
-template <bool ACT_IS_A, int MI, int KK>
+template <bool ACT_IS_A, int MI, int KK, int NS>
 int h2w_launch(const H2wArgs& g, hipStream_t st) {
   constexpr int BMA = 32 * MI;
   // the two stages; the epilogue's fp32 image of the workgroup tile aliases them (pitch = contiguous extent + 4 floats)
@@ -453,11 +454,11 @@ int h2w_launch(const H2wArgs& g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     constexpr size_t smax = (size_t)2 * 2 * (BMA + H2W_MAXTAPS - 1) * (32 * KK + 16);
-    BSG_HIP(hipFuncSetAttribute((const void*)gemm_h2w_kernel<ACT_IS_A, MI, KK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    BSG_HIP(hipFuncSetAttribute((const void*)gemm_h2w_kernel<ACT_IS_A, MI, KK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(smax > epi ? smax : epi)));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_h2w_kernel<ACT_IS_A, MI, KK>), dim3(nwg), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_h2w_kernel<ACT_IS_A, MI, KK, NS>), dim3(nwg), dim3(256), lds, st, g);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
@@ -543,13 +544,24 @@ int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
   static int tiny_env = -1;
   if (tiny_env < 0) { const char* e = getenv("BSG_H2W_TINY"); tiny_env = e ? atoi(e) : 256; }   // (workgroups of 64-row tiles below which 32-row tiles are used; 0: never)
   const bool tiny = g.act_is_a && (long long)cdiv(g.rows, 64) * (g.Wn / 128) * g.batch < tiny_env;
-  if (tiny) return g.taps == 1 ? h2w_launch<true, 1, 4>(g, st) : h2w_launch<true, 1, 2>(g, st);
-  if (g.taps == 1) {   // plain products: 64-deep slices
-    if (g.act_is_a) return small ? h2w_launch<true, 2, 4>(g, st) : h2w_launch<true, 4, 4>(g, st);
-    return small ? h2w_launch<false, 2, 4>(g, st) : h2w_launch<false, 4, 4>(g, st);
+  static int ring_env = -1;   // BSG_H2W_RING=4: the 4-step weight ring at every tile size (rounds 4's first form)
+  if (ring_env < 0) { const char* e = getenv("BSG_H2W_RING"); ring_env = e ? atoi(e) : 16; }
+  const int steps = g.K / 16 * g.taps;
+  const bool r16 = ring_env >= 16 && steps % 16 == 0, r8 = ring_env >= 8 && steps % 8 == 0;
+  if (tiny) {
+    // plain products of a handful of workgroups: 256-deep slices (K = 256: the whole contraction staged once, no barrier inside the k-loop)
+    static int deep_env = -1;
+    if (deep_env < 0) { const char* e = getenv("BSG_H2W_DEEP"); deep_env = e ? atoi(e) : 1; }
+    if (g.taps == 1 && deep_env && g.K % 256 == 0 && ring_env >= 16) return h2w_launch<true, 1, 16, 16>(g, st);
+    if (g.taps == 1) return r16 ? h2w_launch<true, 1, 4, 16>(g, st) : r8 ? h2w_launch<true, 1, 4, 8>(g, st) : h2w_launch<true, 1, 4, 4>(g, st);
+    return r16 ? h2w_launch<true, 1, 2, 16>(g, st) : r8 ? h2w_launch<true, 1, 2, 8>(g, st) : h2w_launch<true, 1, 2, 4>(g, st);
   }
-  if (g.act_is_a) return small ? h2w_launch<true, 2, 2>(g, st) : h2w_launch<true, 4, 2>(g, st);
-  return small ? h2w_launch<false, 2, 2>(g, st) : h2w_launch<false, 4, 2>(g, st);
+  if (g.taps == 1) {   // plain products: 64-deep slices
+    if (g.act_is_a) return !small ? h2w_launch<true, 4, 4, 4>(g, st) : r8 ? h2w_launch<true, 2, 4, 8>(g, st) : h2w_launch<true, 2, 4, 4>(g, st);
+    return !small ? h2w_launch<false, 4, 4, 4>(g, st) : r8 ? h2w_launch<false, 2, 4, 8>(g, st) : h2w_launch<false, 2, 4, 4>(g, st);
+  }
+  if (g.act_is_a) return !small ? h2w_launch<true, 4, 2, 4>(g, st) : r8 ? h2w_launch<true, 2, 2, 8>(g, st) : h2w_launch<true, 2, 2, 4>(g, st);
+  return !small ? h2w_launch<false, 4, 2, 4>(g, st) : r8 ? h2w_launch<false, 2, 2, 8>(g, st) : h2w_launch<false, 2, 2, 4>(g, st);
 }
 
 }  // namespace bsg
