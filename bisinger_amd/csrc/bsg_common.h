@@ -121,6 +121,7 @@ struct H2wArgs {
   int qkv_T, qkv_Tp, qkv_H;
   unsigned short* vt;
   long long vt_plane;
+  int no_direct;               // set by launch_gemm_h2w (BSG_H2W_DIRECT=0): the [feature][frame] output through the LDS image even where the accumulators could be stored directly
 };
 bool h2w_supports(int rows, int Wn, int K, int taps, int lda);
 // W(tap, n, k) at src[tap * ts + n * rs + k * ks]; allocates w->pack on first use; |16 w| >= 65000 counted into *bad_dev (device word)

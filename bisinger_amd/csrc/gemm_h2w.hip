@@ -290,6 +290,27 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
   _Float16* __restrict__ oh = g.out ? reinterpret_cast<_Float16*>(g.out) + (long long)z * g.sO : nullptr;
   constexpr int ER = ACT_IS_A ? BMA : 128, EC = ACT_IS_A ? 128 : BMA, EP = EC + 4;   // image rows x columns (columns = the output's contiguous axis), pitch
   float* et = reinterpret_cast<float*>(lds);
+  if (!ACT_IS_A && !g.up_u && !Rp && !RS && g.act_fn == ACT_NONE && !g.no_direct) {
+    // [feature][frame] output with nothing but bias / alpha in the epilogue (the conditioner hoist: 655 MB of fp32 per pass at B = 16): straight from
+    // the accumulators — a register is 32 consecutive frames of one feature row per lane half (two 128-byte runs per store) — without the LDS
+    // image, its two barriers and the rolled loop
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[wt128 * 128 + wave * 32 + acc_row(r, lh)] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int arow = arow0 + mi * 32 + l31;
+      if (arow >= g.rows) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int wrow = wt128 * 128 + wave * 32 + acc_row(r, lh);
+        float v = c[mi][r] * H2W_OUT + bv[r];
+        if (g.alpha_ncols == 0 || wrow < g.alpha_ncols) v *= g.alpha;
+        Cp[(long long)wrow * g.ldc + arow] = v;
+      }
+    }
+    return;
+  }
   __syncthreads();   // every wave is done reading the stages
   if (!ACT_IS_A && g.up_u) {
     // polyphase output (H2wArgs::up_u = 8): the image as [activation row q][weight row n = 8 co + r] (pitch 132), so that the 4 phases r0 .. r0 + 3
@@ -536,6 +557,11 @@ int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
               "gemm_h2w: QKV output: T=%d Tp=%d H=%d Wn=%d", g.qkv_T, g.qkv_Tp, g.qkv_H, g.Wn);
   if (g.zdiv <= 0) g.zdiv = g.batch;
   g.range_events = gemm_range_counter();
+  {
+    static int direct_env = -1;
+    if (direct_env < 0) { const char* e = getenv("BSG_H2W_DIRECT"); direct_env = e ? atoi(e) : 1; }
+    g.no_direct = direct_env ? 0 : 1;
+  }
   // 64-row activation tiles when 128-row tiles would leave CUs without a second workgroup
   const long long wg128 = (long long)cdiv(g.rows, 128) * (g.Wn / 128) * g.batch;
   const bool small = wg128 < 2 * 256;
