@@ -197,15 +197,24 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT
 // Small split-fp16 GEMM of the fused step tail: one row tile of 32 x NC column tiles of 32, N_KS k-steps of 16, fully unrolled; A fragments
 // (hi at sa + ks*ksb, lo at + plb) in a ring of up to 8 k-steps, B fragments from `ldb(ks, Bf)`: Bf[2 nc] = hi, Bf[2 nc + 1] = lo of column
 // tile nc.
-template <int NC, int N_KS, typename LDB>
-__device__ __forceinline__ void tail_gemm_h2(f32x16 (&c)[NC], rsrc_t rs, int vfrag, int sa, int ksb, int plb, LDB ldb) {
-  constexpr int R = N_KS < 8 ? N_KS : 8;
-  f16x8 Ar[R][2];
+template <int N_KS>
+struct TailRing {
+  static constexpr int R = N_KS < 8 ? N_KS : 8;
+  f16x8 a[R][2];
+};
+// the first R k-steps' fragments: can be requested long before the GEMM runs (step_tail_h2_kernel asks for all three projections' first
+// fragments while the skip sum is still on its way from HBM: each GEMM used to start with a ring fill of its own, an exposed L2 round trip)
+template <int N_KS>
+__device__ __forceinline__ void tail_ring_fill(TailRing<N_KS>& q, rsrc_t rs, int vfrag, int sa, int ksb, int plb) {
 #pragma unroll
-  for (int k = 0; k < R; ++k) {
-    Ar[k][0] = lda8(rs, vfrag, sa + k * ksb);
-    Ar[k][1] = lda8(rs, vfrag, sa + k * ksb + plb);
+  for (int k = 0; k < TailRing<N_KS>::R; ++k) {
+    q.a[k][0] = lda8(rs, vfrag, sa + k * ksb);
+    q.a[k][1] = lda8(rs, vfrag, sa + k * ksb + plb);
   }
+}
+template <int NC, int N_KS, typename LDB>
+__device__ __forceinline__ void tail_gemm_h2_run(f32x16 (&c)[NC], TailRing<N_KS>& q, rsrc_t rs, int vfrag, int sa, int ksb, int plb, LDB ldb) {
+  constexpr int R = TailRing<N_KS>::R;
   f16x8 Bf[2][2 * NC];
   ldb(0, Bf[0]);
 #pragma unroll
@@ -213,16 +222,22 @@ __device__ __forceinline__ void tail_gemm_h2(f32x16 (&c)[NC], rsrc_t rs, int vfr
     if (ks + 1 < N_KS) ldb(ks + 1, Bf[(ks + 1) & 1]);
     const f16x8(&Bc)[2 * NC] = Bf[ks & 1];
 #pragma unroll
-    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], Ar[ks % R][0], Bc[2 * nc]);
+    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], q.a[ks % R][0], Bc[2 * nc]);
 #pragma unroll
-    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], Ar[ks % R][0], Bc[2 * nc + 1]);
+    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], q.a[ks % R][0], Bc[2 * nc + 1]);
 #pragma unroll
-    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], Ar[ks % R][1], Bc[2 * nc]);
+    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], q.a[ks % R][1], Bc[2 * nc]);
     if (ks + R < N_KS) {
-      Ar[ks % R][0] = lda8(rs, vfrag, sa + (ks + R) * ksb);
-      Ar[ks % R][1] = lda8(rs, vfrag, sa + (ks + R) * ksb + plb);
+      q.a[ks % R][0] = lda8(rs, vfrag, sa + (ks + R) * ksb);
+      q.a[ks % R][1] = lda8(rs, vfrag, sa + (ks + R) * ksb + plb);
     }
   }
+}
+template <int NC, int N_KS, typename LDB>
+__device__ __forceinline__ void tail_gemm_h2(f32x16 (&c)[NC], rsrc_t rs, int vfrag, int sa, int ksb, int plb, LDB ldb) {
+  TailRing<N_KS> q;
+  tail_ring_fill<N_KS>(q, rs, vfrag, sa, ksb, plb);
+  tail_gemm_h2_run<NC, N_KS>(c, q, rs, vfrag, sa, ksb, plb, ldb);
 }
 
 // TAIL: the tail of the sampler step runs on the tile while it is still on chip (the fp32 launch pair it replaces: this kernel without
@@ -792,6 +807,15 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
     if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
   };
   auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+  // the first weight fragments of the skip projection (all waves) and of the output projection (waves 0..2), requested before anything else:
+  // they arrive while the skip sum is on its way and the noise is generated (each projection used to fill its ring behind its barrier)
+  const rsrc_t rs_ws = mk_rsrc(a.ws_s, 2 * C * C * 2);
+  const rsrc_t rs_wo = mk_rsrc(a.wo_s, 2 * 96 * C * 2);
+  const rsrc_t rs_wi = mk_rsrc(a.wi_s, 2 * C * 96 * 2);
+  TailRing<16> ring_s, ring_o;
+  TailRing<6> ring_i;
+  tail_ring_fill<16>(ring_s, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024);
+  if (wave < 3) tail_ring_fill<16>(ring_o, rs_wo, vfrag, wave * 1024, 2 * 3 * 1024, 3 * 1024);
   // ---- s (skip sum / sqrt(L), fp32 rows) -> hi / lo image rows: 32 chunks of 8 channels x 32 frames, lanes = consecutive frames.  The
   // loads are requested first; the noise below is generated while they are on their way from HBM ------------------------------------
   float sv[2][8];
@@ -847,14 +871,14 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
   };
   // ---- h = relu(W_skip s + b) -> zs (hi / lo)                                                                          (net.py:126-128) ----
   {
-    const rsrc_t rs_ws = mk_rsrc(a.ws_s, 2 * C * C * 2);
     const rsrc_t rs_bs = mk_rsrc(a.b_skip, C * 4);
     const float sc = tsc[0], inv = tsc[1];
     f32x16 hc[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hc[0][r] = ldf(rs_bs, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
     __syncthreads();   // (T1) s complete
-    tail_gemm_h2<1, 16>(hc, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x);
+    tail_gemm_h2_run<1, 16>(hc, ring_s, rs_ws, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x);
+    if (a.do_head) tail_ring_fill<6>(ring_i, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024);   // (the skip projection's ring is free)
     unsigned worst = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) worst = max(worst, absbits(hc[0][r] * inv));
@@ -872,7 +896,6 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
   // ---- eps = W_out h + b and the sampler update, fp32, on the 3 row tiles that cover the M mel bins: waves 0..2     (net.py:129) --------------
   if (wave < 3) {
     const int rt = wave;
-    const rsrc_t rs_wo = mk_rsrc(a.wo_s, 2 * 96 * C * 2);
     const rsrc_t rs_bf = mk_rsrc(a.b_fin, 96 * 4);
     const rsrc_t rs_xx = mk_rsrc(a.x + (long long)b * M * T, (unsigned)M * T * 4);
     const rsrc_t rs_n = mk_rsrc(a.noise ? a.noise + (long long)b * M * T : a.x, a.noise ? (unsigned)M * T * 4 : 0u);
@@ -906,7 +929,7 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
       Bf[0] = *reinterpret_cast<const f16x8*>(zb + ks * 32);
       Bf[1] = *reinterpret_cast<const f16x8*>(zb + ks * 32 + ZP);
     };
-    tail_gemm_h2<1, 16>(e, rs_wo, vfrag, rt * 1024, 2 * 3 * 1024, 3 * 1024, ldb_h);
+    tail_gemm_h2_run<1, 16>(e, ring_o, rs_wo, vfrag, rt * 1024, 2 * 3 * 1024, 3 * 1024, ldb_h);
     const rsrc_t rs_en = mk_rsrc(a.plms_hist ? a.e_new + (long long)b * M * T : a.x, a.plms_hist ? (unsigned)M * T * 4 : 0u);
     float o[16];
 #pragma unroll
@@ -947,14 +970,13 @@ __global__ __launch_bounds__(512, 1) void step_tail_h2_kernel(TailArgs a) {
   if (!a.do_head) return;
   // ---- next evaluation's input projection: xa = relu(W_in x + b), K = 96 (in_dims zero-padded)                     (net.py:116-118) ----------
   {
-    const rsrc_t rs_wi = mk_rsrc(a.wi_s, 2 * C * 96 * 2);
     const rsrc_t rs_bi = mk_rsrc(a.b_in, C * 4);
     const float sc = tsc[4], inv = tsc[5];
     f32x16 hc[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) hc[0][r] = ldf(rs_bi, lh * 16, (32 * wave + acc_row0(r)) * 4) * sc;
     __syncthreads();   // (T3) the updated x tile is complete
-    tail_gemm_h2<1, 6>(hc, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x);
+    tail_gemm_h2_run<1, 6>(hc, ring_i, rs_wi, vfrag, wave * 1024, 2 * 8 * 1024, 8 * 1024, ldb_x);
     const rsrc_t rs_xa = mk_rsrc(a.xa_next + (long long)b * C * T, plane);
     if (col_ok) {
 #pragma unroll
