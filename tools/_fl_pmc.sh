@@ -5,7 +5,7 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  PN=1 timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $O/s$i -o s$i -- python3 tools/prof_rank.py > $O/s$i.log 2>&1 || echo "pmc $set failed"
+  PN=1 timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $O/s$i -o s$i -- python3 ${PROG:-tools/prof_rank.py} > $O/s$i.log 2>&1 || echo "pmc $set failed"
 done <<SETS
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
