@@ -1079,6 +1079,8 @@ struct bsg_diffnet {
   bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
   bool stack_is_h2 = false;            // ... the split-fp16 stack launch (diffnet_h2.hip)
   bool h2_off = false;                 // bsg_diffnet_set_h2(h, 0): this handle multiplies on the fp32 matrix pipe only
+  int occ_stack_h2q[3] = {-1, -1, -1}; // the same for residual_stack_q_kernel (16-row matrix tiles, diffnet_h2q.hip)
+  bool stack_q = false;                // the stack launch of the current shape runs on 16-row matrix tiles
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
   int stack_nct = 2;                   // column tiles of 32 frames per workgroup the last stack_rows() chose for the split-fp16 launch
   int stack_parts = 0;                 // ... a part form (diffnet_h2.hip residual_part_h2_kernel): workgroups per tile (4 / 2), else 0
@@ -1659,9 +1661,18 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
           }
         }
       }
-      if (h->occ_stack_h2[nct] < 0) h->occ_stack_h2[nct] = stack_h2_occupancy(nct) >= 1 ? 1 : 0;
+      // 16-row matrix tiles (residual_stack_q_kernel, diffnet_h2q.hip; round 5): the same launch with every product a v_mfma_f32_16x16x32_f16 —
+      // the same matrix cycles, but the chip holds a higher clock under that shape.  BSG_H2_Q=0: the 32-row form (residual_stack_h2_kernel)
+      static int env_q = -1;
+      if (env_q < 0) { const char* e = getenv("BSG_H2_Q"); env_q = e ? atoi(e) : 1; }
+      h->stack_q = false;
+      if (env_q && h->apack1q && h->apack2q) {
+        if (h->occ_stack_h2q[nct] < 0) h->occ_stack_h2q[nct] = stack_h2q_occupancy(nct) >= 1 ? 1 : 0;
+        h->stack_q = h->occ_stack_h2q[nct] >= 1;
+      }
+      if (!h->stack_q && h->occ_stack_h2[nct] < 0) h->occ_stack_h2[nct] = stack_h2_occupancy(nct) >= 1 ? 1 : 0;
       const int tpr = cdiv(T, 32 * nct);
-      if (h->occ_stack_h2[nct] >= 1 && tpr <= h->num_cus) {
+      if ((h->stack_q || h->occ_stack_h2[nct] >= 1) && tpr <= h->num_cus) {
         int rows = h->num_cus / tpr;
         if (rows > B) rows = B;
         h->stack_is_h2 = true;
@@ -1731,6 +1742,12 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (stamps) { const char* e = getenv("BSG_STAMP_MODE"); p.stamp_mode = e ? atoi(e) : 0; }
+    {
+      static int skew_tile = -1, skew_row = -1;   // BSG_H2_SKEW_TILE / BSG_H2_SKEW_ROW: start skews in units of 10 ns
+      if (skew_tile < 0) { const char* e = getenv("BSG_H2_SKEW_TILE"); skew_tile = e ? atoi(e) : 0; }
+      if (skew_row < 0) { const char* e = getenv("BSG_H2_SKEW_ROW"); skew_row = e ? atoi(e) : 0; }
+      p.skew_tile = skew_tile; p.skew_row = skew_row;
+    }
     if (h2 && h->stack_parts) {
       BSG_REQUIRE(!tail && nb == B, "part launch: whole batch, no fused tail");
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
@@ -1758,6 +1775,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       TRY(launch_residual_part_h2(p, st, h->stack_parts, nct));
     } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
+      p.apack1q = h->apack1q; p.apack2q = h->apack2q;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
         TailArgs a = *tail;
         const size_t mo = (size_t)r0 * h->M * T;
@@ -1767,9 +1785,9 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
         if (a.h1) a.h1 += mo;
         if (a.h2) a.h2 += mo;
         if (a.h3) a.h3 += mo;
-        TRY(launch_residual_stack_h2(p, &a, st, nct));
+        TRY(h->stack_q ? launch_residual_stack_h2q(p, &a, st, nct) : launch_residual_stack_h2(p, &a, st, nct));
       } else {
-        TRY(launch_residual_stack_h2(p, nullptr, st, nct));
+        TRY(h->stack_q ? launch_residual_stack_h2q(p, nullptr, st, nct) : launch_residual_stack_h2(p, nullptr, st, nct));
       }
     } else if (f43) {
       p.apackw43 = h->apackw43;
@@ -1780,7 +1798,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     }
   }
   BSG_REQUIRE(!tail || h2, "stack launch: a fused tail needs the split-fp16 form");
-  h->last_path = h2 ? (h->stack_parts == 2 ? "stack_h2_pair64" : h->stack_parts ? (h->stack_nct == 2 ? "stack_h2_quad64" : "stack_h2_quad") : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
+  h->last_path = h2 ? (h->stack_parts == 2 ? "stack_h2_pair64" : h->stack_parts ? (h->stack_nct == 2 ? "stack_h2_quad64" : "stack_h2_quad") : h->stack_q ? (tail ? "stack_h2q_tail" : "stack_h2q") : tail ? "stack_h2_tail" : "stack_h2") : "stack_f43";
   return BSG_OK;
 }
 

@@ -28,29 +28,13 @@
 // idle); TAIL appends the sampler step's tail on the tile (skip / output / input projections, DDPM or PLMS update).
 // NOTE for whoever edits the kernel: the NCT = 2 form needs all 256 VGPRs and its register allocation has no slack — check the spill
 // count after every change (tests/test_build_resources.py; ~10-17 spilled registers outside the matrix loops are the good state).
-#include "diffnet_res.h"
-#include "diffnet_tail.h"
+#include "diffnet_h2_shared.h"
 #include <type_traits>
 
 namespace bsg {
 
 namespace {
 
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-
-// NCT = column tiles of 32 frames per workgroup: 2 (64-frame tiles, the form described above) or 1 (32-frame tiles: twice the tiles for
-// batches that would leave CUs without one — half the matrix work per tile against the same weight stream)
-constexpr int ROWB = 2 * C + 16;          // LDS image row: 256 fp16 + 16 B pad = 528 B (132 dwords = 4 mod 64)
-constexpr int h2_xp(int nct) { return (32 * nct + 2 * HALO) * ROWB; }   // bytes per plane of the image: 42,240 (NCT = 2)
-constexpr int h2_zp(int nct) { return 32 * nct * ROWB; }                // bytes per plane of z: 33,792 (NCT = 2)
-constexpr int NSH = 4;                    // weight ring (k-steps).  A ring of 8 for the 32-frame form (it has the registers) measured 5-7 % SLOWER at
-                                          // B = 1, 4, 8 (profiles/r03_ab_ring.log): the L2 latency of the weight stream is already covered
-constexpr int PLB = 16 * 1024;            // bytes per plane of a k-step slab (16 row tiles x 1 KB)
-constexpr int KSB2 = 2 * PLB;             // bytes per k-step: hi slab, lo slab
-constexpr float ZSCALE = 1024.0f;         // z in (-1, 1) is split as z x 2^10
-constexpr size_t h2_lds(int nct) { return (size_t)2 * h2_xp(nct) + 2 * h2_zp(nct) + 3 * C * sizeof(float); }
 
 // scale table, per layer: [0] s1 (GEMM1 weights x s1), [1] 1 / s1, [2] s2 x 2^10 (GEMM2 weights x s2, z x 2^10), [3] its reciprocal
 __global__ void h2_absmax_kernel(const float* __restrict__ src, long long n, unsigned* __restrict__ out) {
@@ -99,18 +83,6 @@ __global__ void pack_a_frag_h2_kernel(const float* __restrict__ src, _Float16* _
   out[base + (long long)RT * 512] = lo;
 }
 
-__device__ __forceinline__ f16x8 lda8(rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-// hi / lo split of two values into two packed dwords
-struct HiLo { unsigned hi, lo; };
-__device__ __forceinline__ HiLo split2(float a, float b) {
-  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-  return HiLo{__builtin_bit_cast(unsigned, f16x2{ha, hb}),
-              __builtin_bit_cast(unsigned, f16x2{(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)})};
-}
-
-#define BSG_MFMA_H(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, ACC, 0, 0, 0)
 
 // i-th executed k-step -> k-step index: GEMM1 (ROT = 16, 48 k-steps, tap-major) starts with the CENTRE tap, whose B operand is the
 // tile's own 64 frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
@@ -194,51 +166,6 @@ __device__ __forceinline__ void mfma_pipe_h2(f32x16 (&c0)[NCT], f32x16 (&c1)[NCT
   }
 }
 
-// Small split-fp16 GEMM of the fused step tail: one row tile of 32 x NC column tiles of 32, N_KS k-steps of 16, fully unrolled; A fragments
-// (hi at sa + ks*ksb, lo at + plb) in a ring of up to 8 k-steps, B fragments from `ldb(ks, Bf)`: Bf[2 nc] = hi, Bf[2 nc + 1] = lo of column
-// tile nc.
-template <int N_KS>
-struct TailRing {
-  static constexpr int R = N_KS < 8 ? N_KS : 8;
-  f16x8 a[R][2];
-};
-// the first R k-steps' fragments: can be requested long before the GEMM runs (step_tail_h2_kernel asks for all three projections' first
-// fragments while the skip sum is still on its way from HBM: each GEMM used to start with a ring fill of its own, an exposed L2 round trip)
-template <int N_KS>
-__device__ __forceinline__ void tail_ring_fill(TailRing<N_KS>& q, rsrc_t rs, int vfrag, int sa, int ksb, int plb) {
-#pragma unroll
-  for (int k = 0; k < TailRing<N_KS>::R; ++k) {
-    q.a[k][0] = lda8(rs, vfrag, sa + k * ksb);
-    q.a[k][1] = lda8(rs, vfrag, sa + k * ksb + plb);
-  }
-}
-template <int NC, int N_KS, typename LDB>
-__device__ __forceinline__ void tail_gemm_h2_run(f32x16 (&c)[NC], TailRing<N_KS>& q, rsrc_t rs, int vfrag, int sa, int ksb, int plb, LDB ldb) {
-  constexpr int R = TailRing<N_KS>::R;
-  f16x8 Bf[2][2 * NC];
-  ldb(0, Bf[0]);
-#pragma unroll
-  for (int ks = 0; ks < N_KS; ++ks) {
-    if (ks + 1 < N_KS) ldb(ks + 1, Bf[(ks + 1) & 1]);
-    const f16x8(&Bc)[2 * NC] = Bf[ks & 1];
-#pragma unroll
-    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], q.a[ks % R][0], Bc[2 * nc]);
-#pragma unroll
-    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], q.a[ks % R][0], Bc[2 * nc + 1]);
-#pragma unroll
-    for (int nc = 0; nc < NC; ++nc) BSG_MFMA_H(c[nc], q.a[ks % R][1], Bc[2 * nc]);
-    if (ks + R < N_KS) {
-      q.a[ks % R][0] = lda8(rs, vfrag, sa + (ks + R) * ksb);
-      q.a[ks % R][1] = lda8(rs, vfrag, sa + (ks + R) * ksb + plb);
-    }
-  }
-}
-template <int NC, int N_KS, typename LDB>
-__device__ __forceinline__ void tail_gemm_h2(f32x16 (&c)[NC], rsrc_t rs, int vfrag, int sa, int ksb, int plb, LDB ldb) {
-  TailRing<N_KS> q;
-  tail_ring_fill<N_KS>(q, rs, vfrag, sa, ksb, plb);
-  tail_gemm_h2_run<NC, N_KS>(c, q, rs, vfrag, sa, ksb, plb, ldb);
-}
 
 // TAIL: the tail of the sampler step runs on the tile while it is still on chip (the fp32 launch pair it replaces: this kernel without
 // TAIL + step_tail_kernel, diffnet.hip; net.py:126-129, shallow_diffusion_tts.py:149-201): skip projection + ReLU, output projection,
@@ -379,7 +306,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 
 #define STK_STAMP(i)                                                                                              \
   do {                                                                                                            \
-    if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + l) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    if (p.stamps && tid == 0) {                                                                                   \
+      unsigned long long sv_ = __builtin_amdgcn_s_memrealtime();                                                  \
+      if (p.stamp_mode >= 2) sv_ = (sv_ & 0xffffffffull) | ((unsigned long long)__builtin_amdgcn_s_memtime() << 32); /* + shader cycles */ \
+      p.stamps[((long long)tile_id * L + l) * 8 + (i)] = sv_;                                                     \
+    }                                                                                                             \
   } while (0)
   if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -1608,7 +1539,6 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
 }
 #undef BSG_MFMA_Q
 
-#undef BSG_MFMA_H
 
 }  // namespace
 

@@ -1,0 +1,525 @@
+// fp32 DiffNet residual stack on the 16-bit matrix pipe, on 16-ROW MATRIX TILES: residual_stack_h2_kernel (diffnet_h2.hip) with every
+// product issued as v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16.
+//
+// Same contract, tensors, LDS images, hand-off protocol, split (hi + lo fp16 per fp32 operand; lo hi + hi hi + hi lo per product), scales, range
+// guard and fused step tail as that launch — reference semantics /root/reference/train_bisinger/usr/diff/net.py:66-78,107-130, with TAIL also
+// net.py:126-129 and usr/diff/shallow_diffusion_tts.py:149-201 — and the same matrix cycles per layer (a 16x16x32 MFMA is 16 clocks for half the
+// FLOP of a 32-clock 32x32x16).  What differs is what the chip holds its clock at under it (MI355X_MICROARCH.md "DVFS give-back" item 7: the
+// clock a dense MFMA loop sustains depends on the MFMA shape): per matrix cycle the 16-row shape reads and writes 0.25 accumulator registers
+// per lane where the 32-row shape moves 0.5, and tools/gemm_shape_ab.hip — this launch's GEMM1 loop alone, both shapes, the same output tile
+// per wave, weights streamed from L2, operand fragments from LDS, random hi / lo planes — holds 1.57-1.60 GHz with it against 1.37-1.39 GHz:
+// 26.4-27.4 us per GEMM1 of a 64-frame tile on all 256 CUs against 28.8-29.7 us (profiles/r05_gemm_shape_ab.txt).
+//
+// Layout.  A wave owns 32 channels, as before, as 2 + 2 row tiles of 16 (gate + filter rows of GEMM1, residual + skip rows of GEMM2) over
+// NQ = 2 NCT column tiles of 16 frames: lane l holds A[row l & 15][k = 8 (l >> 4) + j], B[k][column l & 15] and, of a 16 x 16 result, column
+// l & 15, rows 4 (l >> 4) + r.  So a lane's 4 registers of a tile are 4 CONSECUTIVE channels of one frame — the 8-byte pieces of the
+// channels-last LDS images as before — and element (ct, rt, i) of x / the skip sum / an accumulator is channel 32 w + 16 rt + 4 (l >> 4) + i of
+// frame 16 ct + (l & 15).  Weights: the 16-row fragments the part forms stream (pack_a_frag_q_kernel, diffnet_h2.hip): per 32-deep k-step a hi
+// and a lo slab of 32 row tiles x 1 KB.  A k-step is 48 MFMAs per wave on 8 weight fragments (ring of 2 k-steps = 64 registers, as the 4 x 16
+// deep of the 32-row form) and, per column tile, 2 operand fragments from LDS, read two column tiles ahead into four buffers (32 registers, as there).
+#include "diffnet_h2_shared.h"
+#include <type_traits>
+
+namespace bsg {
+
+namespace {
+
+constexpr int QPLB = 32 * 1024;            // bytes per plane of a k-step slab: 32 row tiles of 16 x 1 KB
+constexpr int QKSB = 2 * QPLB;             // bytes per k-step (32 deep): hi slab, lo slab
+using f32x4q = __attribute__((ext_vector_type(4))) float;
+#define BSG_MFMA_Q(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0)
+
+// i-th executed k-step -> k-step index: GEMM1 (ROT = 8: 24 k-steps of 32, tap-major) starts with the CENTRE tap, whose B operand is the tile's
+// own frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
+template <int ROT>
+__device__ __forceinline__ int kmapq(int i) {
+  if (ROT == 0) return i;
+  return i < ROT ? i + ROT : (i < 2 * ROT ? i - ROT : i);
+}
+
+// k-step pipeline over 4 row tiles (c[0], c[1]: gate / residual; c[2], c[3]: filter / skip) x NQ column tiles of 16 frames.  Per column tile 12
+// MFMAs — lo hi, hi hi, hi lo for each of the 4 row tiles; an accumulator is revisited every 4th MFMA — on the k-step's 8 weight fragments
+// A[s][2 rt] = hi, A[s][2 rt + 1] = lo and the tile's two operand fragments; the fragments of the column tile after the next are read from LDS
+// inside the first MFMA group.  The ring slot is refilled during the LAST column tile of its k-step (lo fragments behind the first group, hi fragments
+// behind the last), two k-steps = 96 MFMAs ahead.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0: never): the hand-off
+// with the neighbours sits there, under the centre tap's MFMAs.  FAIRB: the two waves of a SIMD take turns at issue priority.
+template <int ROT, bool FAIRB, int NQ, typename LDB, typename MID>
+__device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8], rsrc_t rs, int vfrag, const int (&sa)[4], int n_ks, LDB ldb,
+                                            MID mid, int half, bool diag_l1) {
+  static_assert(NQ == 2 || NQ == 4, "four operand buffers, indexed by the item's position in a pass of two k-steps");
+  // operand fragments: item (k-step, column tile) -> buffer (item index in the pass) & 3, read from LDS TWO column tiles = 24 MFMAs ahead (one
+  // tile ahead, its latency — 8 waves' 16-byte reads of 528-byte rows — showed between the column tiles: GEMM2 8.05 us against 6.14 for the 32-row form)
+  f16x8 B[4][2];
+  const int last = n_ks - 1;
+  auto item_ks = [&](int ks, int s, int ct) { const int k = ks + s + ct / NQ; return kmapq<ROT>(k <= last ? k : last); };
+  ldb(kmapq<ROT>(0), 0, B[0]);
+  ldb(kmapq<ROT>(0), 1, B[1]);
+#pragma unroll 1
+  for (int ks = 0; ks < n_ks; ks += 2) {
+    if (FAIRB) {
+      const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
+      if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    if (ROT > 0 && ks == ROT) {
+      mid();
+      ldb(kmapq<ROT>(ks), 0, B[0]);   // the B operands of the next two column tiles were read before the halo rows arrived: read them again
+      ldb(kmapq<ROT>(ks), 1, B[1]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kr = diag_l1 ? 0 : kmapq<ROT>(ks + s + 2 <= last ? ks + s + 2 : last) * QKSB;   // (diagnostic: every reload from ONE L1-resident k-step — wrong results)
+#pragma unroll
+      for (int ct = 0; ct < NQ; ++ct) {
+        const int item = s * NQ + ct;
+        ldb(item_ks(ks, s, ct + 2), (ct + 2) % NQ, B[(item + 2) & 3]);
+        const f16x8(&Bc)[2] = B[item & 3];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt + 1], Bc[0]);   // lo hi
+        if (ct == NQ - 1) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8(rs, vfrag, sa[rt] + kr + QPLB);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[0]);       // hi hi
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[1]);       // hi lo
+        if (ct == NQ - 1) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8(rs, vfrag, sa[rt] + kr);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (ct == NQ - 1) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <bool FAIRB, bool TAIL, int NCT>
+__global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, TailArgs a) {
+  constexpr int NT = 32 * NCT, NQ = 2 * NCT, XP = h2_xp(NCT), ZP = h2_zp(NCT);   // frames / column tiles of 16 per workgroup; bytes per plane
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* xs = lds_raw;                  // [2 planes][NT + 16 frames][528 B]: hi / lo of x + d_l, frames t0-8 .. t0+NT+7
+  char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation
+  float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]: d_{l+1} per channel, fetched a layer ahead
+  float* btab = dtab + C;                                              // [512]: output-projection bias of the current layer
+
+  const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
+  const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (tile_id >= n_tiles) return;
+  p.fbase = stack_epoch_take(p);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, q4 = lane >> 4;
+  const int tpr = p.tiles_per_row, L = p.L, T = p.T;
+  const int b = tile_id / tpr, j = tile_id - b * tpr;
+  const int t0 = j * NT;
+  const int tb = p.t_dev ? (int)p.t_dev[b] : p.t_uniform;
+  const bool has_left = j > 0, has_right = j + 1 < tpr;
+
+  const unsigned plane = (unsigned)C * T * 4;
+  const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
+  const int rowT = T * 4, vfrag = lane * 16;
+  int vcol[NQ], vst[NQ];
+  bool col_ok[NQ];
+#pragma unroll
+  for (int ct = 0; ct < NQ; ++ct) {
+    const int col = t0 + 16 * ct + n16;
+    col_ok[ct] = col < T;
+    vcol[ct] = (q4 * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
+    vst[ct] = (q4 * 4 * T + col) * 4;
+  }
+  // row tiles (of 16) inside a plane of a k-step slab: gate / residual rows 2w, 2w + 1; filter / skip rows 16 + 2w, 17 + 2w
+  const int sa[4] = {(2 * wave) * 1024, (2 * wave + 1) * 1024, (16 + 2 * wave) * 1024, (17 + 2 * wave) * 1024};
+  const int cw = 32 * wave + 4 * q4;   // the lane's first channel; + 16 rt + i
+
+  float xr[NQ][2][4];     // x: element (ct, rt, i) = channel cw + 16 rt + i of frame 16 ct + n16
+  float sk[NQ][2][4];     // running skip sum (fp32), same layout
+  f32x4q y[4][NQ];        // accumulators: y[rt] gate / residual rows, y[2 + rt] filter / skip rows; GEMM1's start from the conditioner term x s1
+  int range_flag = 0;     // see residual_stack_h2_kernel: a split value beyond 60000 (or not finite) raises the launch's status word 1
+  auto range_check = [&](unsigned worst) {
+    if (__builtin_amdgcn_ballot_w64(worst >= 0x476A6000u) != 0ull) range_flag = 1;   // 60000.0f
+  };
+  auto absbits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+
+  // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 32 NCT dword loads per lane, 64 B contiguous per 16 lanes,
+  // requested straight into the accumulators a phase before they are used
+  auto cond_request = [&](int l) {
+    const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int so = (32 * wave + 16 * rt + i) * rowT;
+#pragma unroll
+        for (int ct = 0; ct < NQ; ++ct) {
+          y[rt][ct][i] = ldf(rs_ct, vcol[ct], so);
+          y[2 + rt][ct][i] = ldf(rs_ct, vcol[ct], so + C * rowT);
+        }
+      }
+  };
+  // image core (frames t0 .. t0+NT-1, this wave's 32 channels) = hi / lo of x + d_l, zero beyond T (the conv pads x + d)
+  auto write_core = [&]() {   // d of the layer being prepared is in dtab (written a phase earlier, behind a barrier)
+    f32x4 dv[2];
+    unsigned worst = 0;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) dv[rt] = *reinterpret_cast<const f32x4*>(dtab + cw + 16 * rt);
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const float v0 = xr[ct][rt][0] + dv[rt][0], v1 = xr[ct][rt][1] + dv[rt][1];
+        const float v2 = xr[ct][rt][2] + dv[rt][2], v3 = xr[ct][rt][3] + dv[rt][3];
+        worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
+        const HiLo s0 = split2(v0, v1);
+        const HiLo s1_ = split2(v2, v3);
+        u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
+        if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+        char* dst = xs + (HALO + 16 * ct + n16) * ROWB + (cw + 16 * rt) * 2;
+        *reinterpret_cast<u32x2*>(dst) = wh;
+        *reinterpret_cast<u32x2*>(dst + XP) = wl;
+      }
+    range_check(worst);
+  };
+
+  // ---- layer 0: x from HBM (the whole input exists, halo included) ------------------------------------------------------
+#pragma unroll
+  for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xr[ct][rt][i] = ldf(rs_x, vcol[ct], (32 * wave + 16 * rt + i) * rowT);
+        sk[ct][rt][i] = 0.f;
+      }
+  {
+    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
+    const int hf = tid & 15, hc = tid >> 4;   // 16 halo frames x 32 chunks of 8 channels
+    const int th = hf < 8 ? t0 - HALO + hf : t0 + NT - 8 + hf;
+    const int hrow = hf < 8 ? hf : NT + hf;
+    const bool hok = th >= 0 && th < T;
+    float hv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
+    range_check(max(max(max(absbits(hv[0]), absbits(hv[1])), max(absbits(hv[2]), absbits(hv[3]))),
+                    max(max(absbits(hv[4]), absbits(hv[5])), max(absbits(hv[6]), absbits(hv[7])))));
+    const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
+    u32x4 wh = u32x4{h0.hi, h1.hi, h2.hi, h3.hi}, wl = u32x4{h0.lo, h1.lo, h2.lo, h3.lo};
+    if (!hok) { wh = u32x4{0u, 0u, 0u, 0u}; wl = u32x4{0u, 0u, 0u, 0u}; }
+    *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = wh;
+    *reinterpret_cast<u32x4*>(xs + XP + hrow * ROWB + hc * 16) = wl;
+  }
+  if (tid < C) dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
+  btab[tid] = p.bias_out[tid];
+  cond_request(0);
+  __syncthreads();
+  write_core();
+  // weight ring, shared by both GEMMs.  GEMM1's first k-steps (it starts with the centre tap: kmapq) are requested a phase ahead — right
+  // behind the previous layer's GEMM2 — so that the L2 latency of the weight stream is never on the layer's critical path
+  f16x8 A[2][8];
+  auto prefetch_a1 = [&](int l) {
+    const rsrc_t rs = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int kr = kmapq<8>(k) * QKSB;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        A[k][2 * rt] = lda8(rs, vfrag, sa[rt] + kr);
+        A[k][2 * rt + 1] = lda8(rs, vfrag, sa[rt] + kr + QPLB);
+      }
+    }
+  };
+  prefetch_a1(0);
+
+#define STK_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (p.stamps && lane == 0 && (wave == 0 || p.stamp_mode >= 4)) {                                              \
+      unsigned long long sv_ = __builtin_amdgcn_s_memrealtime();                                                  \
+      if (p.stamp_mode >= 2) sv_ = (sv_ & 0xffffffffull) | ((unsigned long long)__builtin_amdgcn_s_memtime() << 32); /* + shader cycles */ \
+      /* modes 4, 5: every wave stamps, [tile][layer][wave][8] */                                                 \
+      p.stamps[p.stamp_mode >= 4 ? (((long long)tile_id * L + l) * 8 + wave) * 8 + (i) : ((long long)tile_id * L + l) * 8 + (i)] = sv_; \
+    }                                                                                                             \
+  } while (0)
+  {
+    // start skew (StackArgs::skew_tile / skew_row): the odd tiles of a row and the odd rows start later.  Neighbours stay within the slack of the
+    // hand-off (a tile waits for its neighbours' edges only behind its centre tap), so the skew survives the layers
+    const int skew = (j & 1) * p.skew_tile + (b & 1) * p.skew_row;
+    if (skew > 0) {
+      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)skew;
+      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (p.stamps && tid == 0 && p.stamp_mode < 4) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
+  if (p.clk && tile_id == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int dil = 1 << (l % p.cycle);
+    const rsrc_t rs_a1 = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
+    const rsrc_t rs_a2 = mk_rsrc(p.apack2q + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
+    const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
+    const float dnext = (tid < C && l + 1 < L) ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;   // lands during GEMM1
+    const float bnext = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
+    // GEMM1 accumulates (conditioner term + W x) x s1: the requested term is scaled on arrival (its first use)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NQ; ++ct) y[rt][ct] *= s1;
+    if (l == 0) __syncthreads();   // layer 0: the staged image (core + halo rows); later layers: barrier (C) below covers the core rows
+    STK_STAMP(0);
+    // ---- GEMM1: 24 k-steps of 32.  The centre tap (8 k-steps) reads the tile's own frames only, so it runs while the neighbours' edges of
+    // this layer are still in flight; the wait for them, and the copy of the halo rows, sit behind it (mid) ------------------------------
+    {
+      const char* xb = xs + (HALO + n16) * ROWB + q4 * 16;
+      auto ldb = [&](int ks, int ct, f16x8 (&Bf)[2]) {
+        const int tap = ks >> 3, kc = ks & 7;
+        const char* q = xb + ((tap - 1) * dil + 16 * ct) * ROWB + kc * 64;
+        Bf[0] = *reinterpret_cast<const f16x8*>(q);
+        Bf[1] = *reinterpret_cast<const f16x8*>(q + XP);
+      };
+      auto mid = [&]() {
+        if (l == 0) return;   // layer 0 staged its halo rows from HBM
+        if (wave == 0) {
+          // lane 0 polls the left neighbour's flag, lane 1 the right one's — both loads in flight together (one L2 round trip, not two)
+          const unsigned want = p.fbase + (unsigned)l;
+          const bool mine = lane == 0 ? has_left : (lane == 1 ? has_right : false);
+          const unsigned* fl = p.flags + (lane == 0 ? tile_id - 1 : tile_id + 1);
+          bool pend = mine;
+          if (p.inject) {
+            if (pend) atomicAdd(p.status, 1u);
+          } else {
+            unsigned spins = 0;
+            while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+              if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
+              if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+              __builtin_amdgcn_s_sleep(2);
+              // ~ seconds: never reached unless a workgroup is not resident.  Once ANY wait of this handle has given up (status != 0: the host
+              // repeats the call without hand-offs anyway) the others stop waiting within a thousand polls instead of seconds each
+              if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (pend) atomicAdd(p.status, 1u);
+                break;
+              }
+            }
+          }
+        }
+        __syncthreads();   // (D) the polling wave has seen both flags
+        if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(1);
+        {
+          // halo rows of this layer, both planes: rows 0..7 = the left neighbour's last 8 frames, rows NT+8..NT+15 = the right neighbour's
+          // first 8.  Write-through (sc1) stores, drained before the flag, one workgroup per CU, and EVERY load of the handed-off
+          // bytes an sc1 buffer load to registers: the hand-off form that needs no agent-scope acquire (MI355X_MICROARCH.md)
+          const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+          const bool have = side == 0 ? has_left : has_right;
+          u32x4 vh = u32x4{0u, 0u, 0u, 0u}, vl = u32x4{0u, 0u, 0u, 0u};
+          if (have) {
+            const unsigned short* src = reinterpret_cast<const unsigned short*>(p.hx) +
+                                        ((long long)(l & 1) * n_tiles + (side == 0 ? tile_id - 1 : tile_id + 1)) * (4 * 8 * C);
+            const rsrc_t rs_h = mk_rsrc(src, 4 * 8 * C * 2);
+            const int o = (((side == 0 ? 8 : 0) + f) * C + c16 * 8) * 2;   // the neighbour's side 1 (its last frames) for our left halo
+            vh = __builtin_amdgcn_raw_buffer_load_b128(rs_h, o, 0, 16);                 // sc1
+            vl = __builtin_amdgcn_raw_buffer_load_b128(rs_h, o + 2 * 8 * C * 2, 0, 16);   // lo plane
+          }
+          char* dst = xs + ((side ? HALO + NT : 0) + f) * ROWB + c16 * 16;
+          *reinterpret_cast<u32x4*>(dst) = vh;
+          *reinterpret_cast<u32x4*>(dst + XP) = vl;
+        }
+        __syncthreads();   // (A) halo rows in place
+        if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(2);
+      };
+      mfma_pipe_q<8, FAIRB, NQ>(y, A, rs_a1, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6);
+      if (FAIRB) __builtin_amdgcn_s_setprio(0);
+    }
+    STK_STAMP(3);
+    // ---- gate -> zs (hi / lo of 2^10 z); GEMM2's first weights fly meanwhile ------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        A[k][2 * rt] = lda8(rs_a2, vfrag, sa[rt] + k * QKSB);
+        A[k][2 * rt + 1] = lda8(rs_a2, vfrag, sa[rt] + k * QKSB + QPLB);
+      }
+    if (tid < C) dtab[tid] = dnext;   // read by write_core() behind barrier (B)
+    const float rs2 = inv2 * 0.70710678118654752440f;
+    const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x2 z01 = gate2_scaled(f32x2{y[rt][ct][0], y[rt][ct][1]}, f32x2{y[2 + rt][ct][0], y[2 + rt][ct][1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
+        const f32x2 z23 = gate2_scaled(f32x2{y[rt][ct][2], y[rt][ct][3]}, f32x2{y[2 + rt][ct][2], y[2 + rt][ct][3]}, gcg, gcf, glim, ZSCALE);
+        const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
+        char* dst = zs + (16 * ct + n16) * ROWB + (cw + 16 * rt) * 2;
+        *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+        *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
+      }
+    }
+    // residual rows start from (x + b_out) x s2', skip rows from b_out x s2' (the accumulators of GEMM1 are free now)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 br = *reinterpret_cast<const f32x4*>(btab + cw + 16 * rt), bs = *reinterpret_cast<const f32x4*>(btab + C + cw + 16 * rt);
+#pragma unroll
+      for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          y[rt][ct][i] = (xr[ct][rt][i] + br[i]) * s2;
+          y[2 + rt][ct][i] = bs[i] * s2;
+        }
+    }
+    __syncthreads();   // (B) zs complete; every wave is done reading xs and this layer's biases
+    btab[tid] = bnext;
+    STK_STAMP(4);
+    // ---- GEMM2: 8 k-steps of 32; y[0..1] = residual rows, y[2..3] = skip rows ----------------------------------------------
+    {
+      const char* zb = zs + n16 * ROWB + q4 * 16;
+      auto ldb = [&](int ks, int ct, f16x8 (&Bf)[2]) {
+        const char* q = zb + 16 * ct * ROWB + ks * 64;
+        Bf[0] = *reinterpret_cast<const f16x8*>(q);
+        Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
+      };
+      mfma_pipe_q<0, FAIRB, NQ>(y, A, rs_a2, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6);
+      if (FAIRB) __builtin_amdgcn_s_setprio(0);
+    }
+    if (l + 1 < L) prefetch_a1(l + 1);
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xr[ct][rt][i] = y[rt][ct][i] * rs2;          // (x + residual) / sqrt(2), net.py:78: un-scaling and 1 / sqrt(2) in one factor
+          sk[ct][rt][i] += y[2 + rt][ct][i] * inv2;
+        }
+    STK_STAMP(5);
+    if (l + 1 == L) break;
+
+    // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
+    // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
+    cond_request(l + 1);
+    if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(1);   // diagnostics: the image phase's inner boundaries instead of GEMM1's
+    write_core();
+    if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(2);
+    __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
+    STK_STAMP(6);
+    {
+      // publish the first and the last 8 frames of both planes: [plane][side][8 frames][256 ch] fp16 = 16 KB, write-through
+      unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (4 * 8 * C);
+      const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
+      const char* srcp = xs + (HALO + (side ? NT - 8 : 0) + f) * ROWB + c16 * 16;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(srcp);
+      const u32x4 vl = *reinterpret_cast<const u32x4*>(srcp + XP);
+      if (!(p.inject && (tile_id & 1))) {
+        const rsrc_t rs_hx = mk_rsrc(hx_t, 4 * 8 * C * 2);
+        const int o = ((side * 8 + f) * C + c16 * 8) * 2;
+        __builtin_amdgcn_raw_buffer_store_b128(vh, rs_hx, o, 0, 16);                   // sc1
+        __builtin_amdgcn_raw_buffer_store_b128(vl, rs_hx, o + 2 * 8 * C * 2, 0, 16);   // lo plane
+      }
+    }
+    // every storing wave drains its write-through stores before the flag goes up.  vmcnt counts in order: the conditioner loads of this
+    // wave are older than its edge stores, so this also waits for them (they have had the image phase to land)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (C)
+    if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    STK_STAMP(7);
+  }
+#undef STK_STAMP
+  if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
+  if (p.stamps && tid == 0 && p.stamp_mode < 4) p.stamps[((long long)tile_id * L + L - 1) * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock: end of the last layer ...
+  if (p.clk && tile_id == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
+  if constexpr (!TAIL) {
+    if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);   // word 1: range events (word 0: hand-off give-ups)
+    // ---- the skip sum / sqrt(L) (net.py:126), fp32 [C][T] rows: what the step tail (diffnet.hip step_tail_kernel) reads -------------
+    const rsrc_t rs_sk = mk_rsrc(p.skip + (long long)b * C * T, plane);
+    const float rdiv = 1.0f / sqrtf((float)L);
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct)
+      if (col_ok[ct]) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) stf(sk[ct][rt][i] * rdiv, rs_sk, vst[ct], (32 * wave + 16 * rt + i) * rowT);
+      }
+  } else {
+    // ================= fused step tail: s = skip sum / sqrt(L) -> hi / lo image rows (the conv image is dead: every wave is behind barrier
+    // (B) of the last layer), then the tail of residual_stack_h2_kernel on 32-row tiles (h2_fused_tail, diffnet_h2_shared.h) ================
+    {
+      const float rdiv = 1.0f / sqrtf((float)L);
+      unsigned worst = 0;
+#pragma unroll
+      for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) worst = max(worst, absbits(sk[ct][rt][i]));   // |s| <= |skip sum|
+      range_check(worst);
+#pragma unroll
+      for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const HiLo s0 = split2(sk[ct][rt][0] * rdiv, sk[ct][rt][1] * rdiv), s1_ = split2(sk[ct][rt][2] * rdiv, sk[ct][rt][3] * rdiv);
+          char* dst = xs + (HALO + 16 * ct + n16) * ROWB + (cw + 16 * rt) * 2;
+          *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
+          *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
+        }
+    }
+    h2_fused_tail<NCT>(a, p.status, xs, zs, b, t0, T, L, tid, wave, range_flag);
+  }
+}
+#undef BSG_MFMA_Q
+
+}  // namespace
+
+template <int NCT>
+static int h2q_occupancy() {
+  int o = 0;
+  const int lds = (int)h2_lds(NCT);
+  if (hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT>, 512, h2_lds(NCT)) != hipSuccess)
+    return 0;
+  return o;
+}
+// resident workgroups per CU (0 on error) of the form with `nct` units of 32 frames per workgroup (1 or 2)
+int stack_h2q_occupancy(int nct) { return nct == 1 ? h2q_occupancy<1>() : h2q_occupancy<2>(); }
+
+template <int NCT>
+static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
+  const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
+  const TailArgs a = tail ? *tail : TailArgs{};
+  const size_t lds = h2_lds(NCT);
+  static int fair = -1;   // BSG_H2Q_FAIR=0: no time-sliced issue priority between the two waves of a SIMD
+  if (fair < 0) { const char* e = getenv("BSG_H2Q_FAIR"); fair = e ? atoi(e) : 1; }
+  if (!fair) {
+    static bool attr = false;
+    if (!attr) {
+      BSG_HIP(hipFuncSetAttribute((const void*)residual_stack_q_kernel<false, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      BSG_HIP(hipFuncSetAttribute((const void*)residual_stack_q_kernel<false, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    if (tail) hipLaunchKernelGGL((residual_stack_q_kernel<false, true, NCT>), grid, block, lds, st, p, a);
+    else hipLaunchKernelGGL((residual_stack_q_kernel<false, false, NCT>), grid, block, lds, st, p, a);
+  } else if (tail) hipLaunchKernelGGL((residual_stack_q_kernel<true, true, NCT>), grid, block, lds, st, p, a);
+  else hipLaunchKernelGGL((residual_stack_q_kernel<true, false, NCT>), grid, block, lds, st, p, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+
+// the arguments of launch_residual_stack_h2 (diffnet_h2.hip); p.apack1q / p.apack2q must hold the 16-row weight fragments
+int launch_residual_stack_h2q(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct) {
+  BSG_REQUIRE(p.apack1q && p.apack2q, "16-row stack launch: the 16-row weight fragments are missing");
+  return nct == 1 ? h2q_launch<1>(p, tail, st) : h2q_launch<2>(p, tail, st);
+}
+
+}  // namespace bsg

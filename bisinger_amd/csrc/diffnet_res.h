@@ -68,6 +68,9 @@ struct StackArgs {
   int pflag_words;        // the same for `pflags` (part forms)
   int stamp_mode;         // diagnostics (BSG_STAMP_MODE, part forms): 1 = stamp slots 1 / 2 mark the gate phase's inner boundaries instead of GEMM1's
   int inject;             // fault injection: consumers do not wait
+  // start skew of the one-workgroup-per-tile stack launches, in ticks of s_memrealtime (10 ns): odd tiles of a row / odd rows start that much
+  // later, so that the conditioner bursts of an XCD's 32 workgroups (4 MB per layer through ONE XCD's share of the HBM path) do not coincide
+  int skew_tile, skew_row;
   // part forms of the split-fp16 launch (residual_part_h2_kernel, small batches): exchange of the P channel parts of a tile
   unsigned short* zx;     // [n_tiles][P parts][2 planes][tile frames][C/P] fp16: gated activation parts
   unsigned short* ix;     // [2 parities][n_tiles][P parts][2 planes][tile frames][C/P] fp16: image parts (core frames; neighbours read the edges)
@@ -104,6 +107,7 @@ int stack_bf16_occupancy();   // resident workgroups per CU of residual_stack_bf
 // fp32 stack launch on the 16-bit matrix pipe: operands split exactly into hi + lo fp16 terms (diffnet_h2.hip); 64-frame tiles, one
 // workgroup per CU; grid = p.n_tiles rounded up to 8
 int stack_h2_occupancy(int nct);   // nct = column tiles of 32 frames per workgroup (1 or 2)
+int stack_h2q_occupancy(int nct);  // the 16-row-tile form of the same launch (diffnet_h2q.hip)
 // part forms on 16-row matrix tiles: `parts` workgroups (on as many CUs of one XCD) per tile of 32 nct frames, each C / parts channels:
 // (4, 1) quad of a 32-frame tile, (4, 2) quad of a 64-frame tile, (2, 2) pair of a 64-frame tile (8 waves); p.n_tiles tiles -> grid of 8 parts ceil(n_tiles / 8) workgroups, all resident
 int launch_residual_part_h2(const StackArgs& p, hipStream_t st, int parts, int nct);

@@ -108,6 +108,8 @@ __device__ __forceinline__ float philox_normal1(unsigned long long seed, unsigne
 
 // split-fp16 stack launch (diffnet_h2.hip), optionally with the step tail in the same launch
 int launch_residual_stack_h2(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct);
+// the same launch on 16-row matrix tiles (diffnet_h2q.hip): p.apack1q / p.apack2q hold its weight fragments
+int launch_residual_stack_h2q(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct);
 // the step tail behind a pair / quad launch, on the 16-bit matrix pipe (diffnet_h2.hip step_tail_h2_kernel)
 int launch_step_tail_h2(const TailArgs& a, hipStream_t st);
 int h2_tail_pack(const float* ws, const float* wo96, const float* wi96, unsigned short* out_ws, unsigned short* out_wo, unsigned short* out_wi,

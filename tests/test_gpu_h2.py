@@ -54,7 +54,8 @@ print(json.dumps({'path': net.last_path(), 'timeouts': net.handoff_timeouts()}))
 
 FORMS = {
     'split_fp16': ({'BSG_H2': '2'}, 'stack_h2'),                                  # at these sizes: a part form (four workgroups per tile)
-    'split_fp16_1wg': ({'BSG_H2': '2', 'BSG_H2_PART': '0'}, 'stack_h2'),          # one workgroup per tile
+    'split_fp16_1wg': ({'BSG_H2': '2', 'BSG_H2_PART': '0', 'BSG_H2_Q': '0'}, 'stack_h2'),   # one workgroup per tile, 32-row matrix tiles (diffnet_h2.hip)
+    'split_fp16_1wg_q': ({'BSG_H2': '2', 'BSG_H2_PART': '0', 'BSG_H2_Q': '1'}, 'stack_h2q'),   # one workgroup per tile, 16-row matrix tiles (diffnet_h2q.hip: round 5's default)
     'fp32_direct': ({'BSG_H2': '0', 'BSG_WINO': '0', 'BSG_SPLIT': '0'}, 'layer'),
     'fp32_wino23': ({'BSG_H2': '0', 'BSG_WINO': '1', 'BSG_SPLIT': '0'}, 'layer'),
     'fp32_wino43': ({'BSG_H2': '0', 'BSG_WINO': '2', 'BSG_STACK43': '2'}, 'stack_f43'),
@@ -87,7 +88,7 @@ def test_split_fp16_is_fp32_grade(B, T, wscale, stress, tmp_path):
         ref32 = odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.').double().numpy()
     err = {'cpu_fp32': (float(np.abs(ref32 - ref64).max()), float(np.sqrt(((ref32 - ref64) ** 2).mean())))}
     code = CHILD % (ROOT, B, T, wscale, stress)
-    forms = FORMS if not stress else {k: FORMS[k] for k in ('split_fp16', 'split_fp16_1wg', 'fp32_direct', 'fp32_wino23')}
+    forms = FORMS if not stress else {k: FORMS[k] for k in ('split_fp16', 'split_fp16_1wg', 'split_fp16_1wg_q', 'fp32_direct', 'fp32_wino23')}
     for name, (env, path) in forms.items():
         f = str(tmp_path / f'{name}.npy')
         out = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
@@ -109,7 +110,8 @@ def test_split_fp16_is_fp32_grade(B, T, wscale, stress, tmp_path):
     assert err['split_fp16'][0] <= max(2e-5 * max(1.0, rms_eps), max(e[0] for e in fp32_forms) if stress else 0.0)
     assert err['split_fp16'][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9
     assert err['split_fp16'][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9
-    assert err['split_fp16_1wg'][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9 and err['split_fp16_1wg'][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9
+    for k in ('split_fp16_1wg', 'split_fp16_1wg_q'):
+        assert err[k][1] <= 1.5 * max(e[1] for e in fp32_forms) + 1e-9 and err[k][0] <= 2.0 * max(e[0] for e in fp32_forms) + 1e-9, k
 
 
 GEMM_CHILD = r'''

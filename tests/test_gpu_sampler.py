@@ -134,7 +134,8 @@ def test_fused_plms_tail_matches_separate_kernels(model, monkeypatch):
 
 F23 = {'BSG_WINO': '1', 'BSG_H2': '0'}
 F43 = {'BSG_WINO': '2', 'BSG_H2': '0'}
-H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
+H2 = {'BSG_WINO': '2', 'BSG_H2': '1', 'BSG_H2_Q': '0'}    # 32-row matrix tiles (residual_stack_h2_kernel)
+HQ = dict(H2, BSG_H2_Q='1')                                # 16-row matrix tiles (residual_stack_q_kernel, diffnet_h2q.hip: round 5's default)
 
 
 @pytest.mark.parametrize('B,T,base,stack,path,tol', [
@@ -178,6 +179,18 @@ H2 = {'BSG_WINO': '2', 'BSG_H2': '1'}
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_QUAD='0', BSG_H2_QUAD64='0'), 'stack_h2_pair64', 1e-5),
     (3, 77, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),   # the same with 64-frame tiles
     (2, 31, F23, dict(H2, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2', 1e-5),
+    # the same launch on 16-row matrix tiles (diffnet_h2q.hip): another MFMA shape, the same products in another accumulation order
+    (16, 1000, F23, HQ, 'stack_h2q', 1e-5),                                # 64-frame tiles: 256 workgroups
+    (32, 997, F23, HQ, 'stack_h2q', 1e-5),                                 # two launch groups, T % 4 != 0, partial last tile
+    (8, 1000, F23, dict(HQ, BSG_H2_PAIR64='0'), 'stack_h2q', 1e-5),        # 32-frame tiles
+    (16, 1000, F23, dict(HQ, BSG_H2_NCT='1'), 'stack_h2q', 1e-5),          # forced 32-frame tiles: two launch groups of 8 rows
+    (3, 77, F23, dict(HQ, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2q', 1e-5),   # forced for a few tiles (32-frame), partial tile
+    (5, 333, F23, dict(HQ, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2q', 1e-5),
+    (2, 31, F23, dict(HQ, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2q', 1e-5),   # T < one tile
+    (1, 1, F23, dict(HQ, BSG_H2='2', BSG_H2_PART='0'), 'stack_h2q', 1e-5),
+    (3, 77, F23, dict(HQ, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2q', 1e-5),    # the same with 64-frame tiles
+    (2, 31, F23, dict(HQ, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2q', 1e-5),
+    (3, 65, F23, dict(HQ, BSG_H2='2', BSG_H2_NCT='2'), 'stack_h2q', 1e-5),    # one frame into the second tile
 ])
 def test_stack_launch_matches_per_layer_launches(B, T, base, stack, path, tol, tmp_path):
     """The on-chip stack launches (all 20 layers in one launch, x on chip, neighbour tiles exchanging 8-frame edges every

@@ -28,7 +28,7 @@ for _ in range(3):
     net(x, t, cond)          # binds, fills xa, warms up
 torch.cuda.synchronize()
 F43 = net.last_path() == 'stack_f43'
-H2 = net.last_path() == 'stack_h2'   # split-fp16 form: same stamp slots as the bf16 stack launch
+H2 = net.last_path() in ('stack_h2', 'stack_h2q')   # split-fp16 form: same stamp slots as the bf16 stack launch
 PAIR = net.last_path() in ('stack_h2_quad', 'stack_h2_quad64', 'stack_h2_pair64')   # part forms: four workgroups per tile (stamps of part 0)
 NTILE = 64 if DT == 'bf16' or F43 or H2 else 32
 if PAIR:
@@ -40,9 +40,22 @@ tiles, L = B * ((T + NTILE - 1) // NTILE), 20
 st = torch.zeros(tiles * L * 8, dtype=torch.int64, device=dev)
 for rep in range(3):
     st.zero_()
+    # the stamped launch right behind ~1.5 s of back-to-back launches of the same form: the clock the chip holds under the launch needs seconds
+    # to settle (MI355X_MICROARCH.md 'DVFS give-back' item 6), and a launch stamped from idle runs at another one
+    for _ in range(int(os.environ.get('STAMP_WARM', '500'))):
+        net(x, t, cond)
     _lib.check(_lib.load().bsg_diffnet_debug_stack_stamps(net._h, 50, B, T, _lib.ptr(st), _lib.stream_ptr()), 'stamps')
     torch.cuda.synchronize()
-s = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64) / 100.0      # us
+CYC = os.environ.get('BSG_STAMP_MODE') in ('2', '3') and H2
+M3 = os.environ.get('BSG_STAMP_MODE') == '3' and net.last_path() == 'stack_h2q'   # slots 1 / 2 = conditioner loads issued / image rows written      # stamps carry the shader-cycle counter in their upper half: phases in cycles too
+raw_all = st.cpu().numpy().reshape(tiles, L, 8)
+if CYC:
+    cy = ((raw_all >> 32) & 0xffffffff).astype(np.float64)
+    raw_real = (raw_all & 0xffffffff).astype(np.float64)
+    raw_real[:, L - 1, 6:] = 0
+    s = raw_real / 100.0
+else:
+    s = raw_all.astype(np.float64) / 100.0      # us
 names = ['GEMM1 (A->1)', 'gate+z+barrier (1->2)', 'GEMM2 residual (2->3)' if DT != 'bf16' else 'GEMM2 (2->3)',
          'publish+GEMM2 skip (3->4)' if DT != 'bf16' else 'core image + barrier C1 (3->4)', 'drain+barrier C (4->5)',
          'flag wait (5->6)', 'acquire+barrier D (6->7)', 'halo load+barrier A (7->0 next)']
@@ -59,17 +72,27 @@ if PAIR:   # 0 conditioner term arrived (loop top), 1 flags seen, 2 image comple
 if F43 or H2:
     raw = st.cpu().numpy().reshape(tiles, L, 8).astype(np.float64)
     cyc = raw[:, L - 1, 7] - raw[:, L - 1, 6]
-    us = (raw[:, L - 1, 5] - raw[:, 0, 0]) / 100.0
+    us = (raw[:, L - 1, 5] - raw[:, 0, 0]) / 100.0 if not CYC else (raw_real[:, L - 1, 5] - raw_real[:, 0, 0]) / 100.0
     print(f'shader clock held over the launch: {np.median(cyc / us):.0f} MHz (s_memtime cycles / s_memrealtime span, median over tiles)')
     tpr_ = (T + NTILE - 1) // NTILE
     print('  per-row shader clock (MHz):', ' '.join(f'{v:.0f}' for v in (cyc / us).reshape(B, tpr_).mean(1)))
 inner = s[:, 1:L - 1]                                                          # layers with all 8 stamps and a successor
-d = [inner[:, :, i + 1] - inner[:, :, i] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
+ORDER = [0, 3, 4, 5, 1, 2, 6, 7] if M3 else list(range(8))
+if M3:
+    names = ['GEMM1 (0->3)', 'gate+z+barrier (3->4)', 'GEMM2 + x/skip update (4->5)', 'conditioner loads issued (5->1)', 'image rows written (1->2)',
+             'barrier C1 (2->6)', 'publish + drain + barrier C (6->7)', 'loop top (7->0 next)']
+d = [inner[:, :, ORDER[i + 1]] - inner[:, :, ORDER[i]] for i in range(7)] + [s[:, 2:L, 0] - inner[:, :, 7]]
 period = s[:, 2:L, 0] - s[:, 1:L - 1, 0]
 print(f'path {net.last_path()}  B={B} T={T}: {tiles} tiles; layer period {period.mean():.1f} us (min {period.min():.1f}, max {period.max():.1f}); '
       f'kernel span {(s[:, L - 1, 4].max() - s[:, 0, 0].min()):.0f} us')
-for n, v in zip(names, d):
-    print(f'  {n:34s} mean {v.mean():7.2f} us   p10 {np.percentile(v, 10):7.2f}   p90 {np.percentile(v, 90):7.2f}')
+if CYC:
+    ci = cy[:, 1:L - 1]
+    dc = [(ci[:, :, ORDER[i + 1]] - ci[:, :, ORDER[i]]) % 2.0 ** 32 for i in range(7)] + [(cy[:, 2:L, 0] - ci[:, :, 7]) % 2.0 ** 32]
+    pc = (cy[:, 2:L, 0] - cy[:, 1:L - 1, 0]) % 2.0 ** 32
+    print(f'  layer period in shader cycles: {pc.mean():.0f}  ({pc.mean() / period.mean():.0f} MHz over the inner layers; MFMA cycles per SIMD and layer: 49152)')
+for k, (n, v) in enumerate(zip(names, d)):
+    extra = f'   {dc[k].mean():8.0f} cycles  {dc[k].mean() / v.mean():6.0f} MHz' if CYC else ''
+    print(f'  {n:34s} mean {v.mean():7.2f} us   p10 {np.percentile(v, 10):7.2f}   p90 {np.percentile(v, 90):7.2f}{extra}')
 a10 = s[:, 10, 0] - s[:, 10, 0].min()
 print(f'  start of layer 10 over tiles: spread {a10.max():.1f} us, std {a10.std():.1f}; first half of the grid {a10[:tiles // 2].mean():.1f}, '
       f'second half {a10[tiles // 2:].mean():.1f}')
