@@ -306,13 +306,14 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
 
 #define STK_STAMP(i)                                                                                              \
   do {                                                                                                            \
-    if (p.stamps && tid == 0) {                                                                                   \
+    if (p.stamps && lane == 0 && (wave == 0 || p.stamp_mode >= 4)) {                                              \
       unsigned long long sv_ = __builtin_amdgcn_s_memrealtime();                                                  \
       if (p.stamp_mode >= 2) sv_ = (sv_ & 0xffffffffull) | ((unsigned long long)__builtin_amdgcn_s_memtime() << 32); /* + shader cycles */ \
-      p.stamps[((long long)tile_id * L + l) * 8 + (i)] = sv_;                                                     \
+      /* modes >= 4: every wave stamps, [tile][layer][wave][8] (tools/wave_stamps.py) */                           \
+      p.stamps[p.stamp_mode >= 4 ? (((long long)tile_id * L + l) * 8 + wave) * 8 + (i) : ((long long)tile_id * L + l) * 8 + (i)] = sv_; \
     }                                                                                                             \
   } while (0)
-  if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
+  if (p.stamps && tid == 0 && p.stamp_mode < 4) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll 1
   for (int l = 0; l < L; ++l) {
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           }
         }
         __syncthreads();   // (D) the polling wave has seen both flags
-        STK_STAMP(1);
+        if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(1);
         {
           // halo rows of this layer, both planes: rows 0..7 = the left neighbour's last 8 frames, rows 72..79 = the right neighbour's
           // first 8.  Write-through (sc1) stores, drained before the flag, one workgroup per CU, and EVERY load of the handed-off
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           *reinterpret_cast<u32x4*>(dst + XP) = vl;
         }
         __syncthreads();   // (A) halo rows in place
-        STK_STAMP(2);
+        if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(2);
       };
       mfma_pipe_h2<16, FAIRB, NCT>(yg, yf, A, rs_a1, vfrag, sa_g, sa_f, 48, ldb, mid, wave >> 2);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
@@ -479,7 +480,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
     // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
     // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
     cond_request(l + 1);
+    if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(1);   // diagnostics: the image phase's inner boundaries instead of GEMM1's
     write_core();
+    if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(2);
     __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
     STK_STAMP(6);
     {
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
   }
 #undef STK_STAMP
   if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
-  if (p.stamps && tid == 0) p.stamps[((long long)tile_id * L + L - 1) * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock: end of the last layer ...
+  if (p.stamps && tid == 0 && p.stamp_mode < 4) p.stamps[((long long)tile_id * L + L - 1) * 8 + 7] = __builtin_amdgcn_s_memtime();   // shader clock: end of the last layer ...
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[2] = __builtin_amdgcn_s_memtime(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
   if constexpr (!TAIL) {
     if (range_flag && lane == 0) atomicAdd(p.status + 1, 1u);   // word 1: range events (word 0: hand-off give-ups)

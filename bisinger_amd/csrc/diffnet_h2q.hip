@@ -14,7 +14,11 @@
 // NQ = 2 NCT column tiles of 16 frames: lane l holds A[row l & 15][k = 8 (l >> 4) + j], B[k][column l & 15] and, of a 16 x 16 result, column
 // l & 15, rows 4 (l >> 4) + r.  So a lane's 4 registers of a tile are 4 CONSECUTIVE channels of one frame — the 8-byte pieces of the
 // channels-last LDS images as before — and element (ct, rt, i) of x / the skip sum / an accumulator is channel 32 w + 16 rt + 4 (l >> 4) + i of
-// frame 16 ct + (l & 15).  Weights: the 16-row fragments the part forms stream (pack_a_frag_q_kernel, diffnet_h2.hip): per 32-deep k-step a hi
+// frame 16 ct + (l & 15).  (The 16-lane groups of ds_read_b128 — {0-3, 12-15, 20-27}, ... — meet one 2-way bank conflict each on 528-byte rows.
+// Two conflict-free layouts were built and measured, profiles/r05_q_layouts.txt: rows two apart per lane (frame 2 n + ..) made the global loads of
+// x and the conditioner term strided dwords, 15k cycles to issue instead of 2.6k; a permutation of a tile's 16 frames plus units g, g + 1 of a
+// fragment half a bank row apart kept those loads contiguous and changed nothing measurable: a conflict costs one LDS cycle in five.)
+// Weights: the 16-row fragments the part forms stream (pack_a_frag_q_kernel, diffnet_h2.hip): per 32-deep k-step a hi
 // and a lo slab of 32 row tiles x 1 KB.  A k-step is 48 MFMAs per wave on 8 weight fragments (ring of 2 k-steps = 64 registers, as the 4 x 16
 // deep of the 32-row form) and, per column tile, 2 operand fragments from LDS, read two column tiles ahead into four buffers (32 registers, as there).
 #include "diffnet_h2_shared.h"
@@ -28,6 +32,13 @@ constexpr int QPLB = 32 * 1024;            // bytes per plane of a k-step slab: 
 constexpr int QKSB = 2 * QPLB;             // bytes per k-step (32 deep): hi slab, lo slab
 using f32x4q = __attribute__((ext_vector_type(4))) float;
 #define BSG_MFMA_Q(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0)
+
+// weight-stream loads with a cache-policy experiment (DIAG 8..12: aux = sc0, nt, sc1, sc0 sc1, sc0 nt)
+template <int DIAG>
+__device__ __forceinline__ f16x8 lda8q(rsrc_t r, int voff, int soff) {
+  constexpr int AUX = DIAG == 8 ? 1 : DIAG == 9 ? 2 : DIAG == 10 ? 16 : DIAG == 11 ? 17 : DIAG == 12 ? 3 : 0;
+  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
 
 // i-th executed k-step -> k-step index: GEMM1 (ROT = 8: 24 k-steps of 32, tap-major) starts with the CENTRE tap, whose B operand is the tile's
 // own frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
@@ -43,9 +54,9 @@ __device__ __forceinline__ int kmapq(int i) {
 // inside the first MFMA group.  The ring slot is refilled during the LAST column tile of its k-step (lo fragments behind the first group, hi fragments
 // behind the last), two k-steps = 96 MFMAs ahead.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0: never): the hand-off
 // with the neighbours sits there, under the centre tap's MFMAs.  FAIRB: the two waves of a SIMD take turns at issue priority.
-template <int ROT, bool FAIRB, int NQ, typename LDB, typename MID>
+template <int ROT, bool FAIRB, int NQ, int DIAG, typename LDB, typename MID, typename STAMP>
 __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8], rsrc_t rs, int vfrag, const int (&sa)[4], int n_ks, LDB ldb,
-                                            MID mid, int half, bool diag_l1) {
+                                            MID mid, int half, bool diag_l1, STAMP stamp, volatile unsigned* prog, int wave, unsigned& passes) {
   static_assert(NQ == 2 || NQ == 4, "four operand buffers, indexed by the item's position in a pass of two k-steps");
   // operand fragments: item (k-step, column tile) -> buffer (item index in the pass) & 3, read from LDS TWO column tiles = 24 MFMAs ahead (one
   // tile ahead, its latency — 8 waves' 16-byte reads of 528-byte rows — showed between the column tiles: GEMM2 8.05 us against 6.14 for the 32-row form)
@@ -56,7 +67,25 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
   ldb(kmapq<ROT>(0), 1, B[1]);
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += 2) {
-    if (FAIRB) {
+    if (DIAG == 3) stamp(ks >> 1);   // (diagnostic instantiation: one stamp per pass of two k-steps)
+    if (DIAG == 4) {   // what a stamp costs a wave, without its store: two scalar time reads and the wait for them
+      unsigned long long t_a, t_b;
+      asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a), "=s"(t_b)::"memory");
+    }
+    if (DIAG == 5) __builtin_amdgcn_s_sleep(4);
+    if (DIAG == 6) __builtin_amdgcn_s_sleep(12);
+    if (DIAG == 15) {
+      // progress feedback between the two waves of a SIMD (w, w ^ 4): each publishes the number of passes it has begun; the one that is ahead
+      // drops its issue priority, the one that is behind raises it (arbitration is by priority, then by age: without it waves 0..3 finish a
+      // GEMM thousands of cycles before their partners and then wait at the barrier)
+      ++passes;
+      prog[wave] = passes;
+      const unsigned other = prog[wave ^ 4];
+      if (passes > other) __builtin_amdgcn_s_setprio(0);
+      else if (passes < other) __builtin_amdgcn_s_setprio(3);
+      else if (half) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(1);
+    } else if (FAIRB) {
       const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
       if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
@@ -72,27 +101,29 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
 #pragma unroll
       for (int ct = 0; ct < NQ; ++ct) {
         const int item = s * NQ + ct;
-        ldb(item_ks(ks, s, ct + 2), (ct + 2) % NQ, B[(item + 2) & 3]);
+        if (DIAG != 2) ldb(item_ks(ks, s, ct + 2), (ct + 2) % NQ, B[(item + 2) & 3]);   // (DIAG: timing experiments, wrong results: 1 = no weight reloads, 2 = no operand reads either)
         const f16x8(&Bc)[2] = B[item & 3];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt + 1], Bc[0]);   // lo hi
-        if (ct == NQ - 1) {
+        if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8(rs, vfrag, sa[rt] + kr + QPLB);
+          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8q<DIAG>(rs, vfrag, sa[rt] + kr + QPLB);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[0]);       // hi hi
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[1]);       // hi lo
-        if (ct == NQ - 1) {
+        if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8(rs, vfrag, sa[rt] + kr);
+          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8q<DIAG>(rs, vfrag, sa[rt] + kr);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (ct == NQ - 1) {
+        if (DIAG != 2) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -100,7 +131,7 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
           __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        } else {
+        } else if (DIAG != 2) {
           __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -109,7 +140,7 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
   }
 }
 
-template <bool FAIRB, bool TAIL, int NCT>
+template <bool FAIRB, bool TAIL, int NCT, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, TailArgs a) {
   constexpr int NT = 32 * NCT, NQ = 2 * NCT, XP = h2_xp(NCT), ZP = h2_zp(NCT);   // frames / column tiles of 16 per workgroup; bytes per plane
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -117,6 +148,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation
   float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]: d_{l+1} per channel, fetched a layer ahead
   float* btab = dtab + C;                                              // [512]: output-projection bias of the current layer
+  volatile unsigned* prog = reinterpret_cast<volatile unsigned*>(btab + 2 * C);   // [8] (+ 8 pad): passes begun, per wave (progress feedback, DIAG 15)
+  unsigned passes = 0;
 
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -125,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, q4 = lane >> 4;
+  auto fo = [](int ct) { return 16 * ct; };   // frame of column tile ct, column n16: fo(ct) + n16
   const int tpr = p.tiles_per_row, L = p.L, T = p.T;
   const int b = tile_id / tpr, j = tile_id - b * tpr;
   const int t0 = j * NT;
@@ -138,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   bool col_ok[NQ];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct) {
-    const int col = t0 + 16 * ct + n16;
+    const int col = t0 + n16 + fo(ct);
     col_ok[ct] = col < T;
     vcol[ct] = (q4 * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
     vst[ct] = (q4 * 4 * T + col) * 4;
@@ -189,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         const HiLo s1_ = split2(v2, v3);
         u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
         if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
-        char* dst = xs + (HALO + 16 * ct + n16) * ROWB + (cw + 16 * rt) * 2;
+        char* dst = xs + (HALO + n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
         *reinterpret_cast<u32x2*>(dst) = wh;
         *reinterpret_cast<u32x2*>(dst + XP) = wl;
       }
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     *reinterpret_cast<u32x4*>(xs + XP + hrow * ROWB + hc * 16) = wl;
   }
   if (tid < C) dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
+  if (tid < 16) prog[tid] = 0u;
   btab[tid] = p.bias_out[tid];
   cond_request(0);
   __syncthreads();
@@ -251,7 +286,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
       unsigned long long sv_ = __builtin_amdgcn_s_memrealtime();                                                  \
       if (p.stamp_mode >= 2) sv_ = (sv_ & 0xffffffffull) | ((unsigned long long)__builtin_amdgcn_s_memtime() << 32); /* + shader cycles */ \
       /* modes 4, 5: every wave stamps, [tile][layer][wave][8] */                                                 \
-      p.stamps[p.stamp_mode >= 4 ? (((long long)tile_id * L + l) * 8 + wave) * 8 + (i) : ((long long)tile_id * L + l) * 8 + (i)] = sv_; \
+      p.stamps[DIAG == 3 ? (((long long)tile_id * L + l) * 8 + wave) * 32 + (i)                                    \
+               : p.stamp_mode >= 4 ? (((long long)tile_id * L + l) * 8 + wave) * 8 + (i) : ((long long)tile_id * L + l) * 8 + (i)] = sv_; \
     }                                                                                                             \
   } while (0)
   {
@@ -286,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
       const char* xb = xs + (HALO + n16) * ROWB + q4 * 16;
       auto ldb = [&](int ks, int ct, f16x8 (&Bf)[2]) {
         const int tap = ks >> 3, kc = ks & 7;
-        const char* q = xb + ((tap - 1) * dil + 16 * ct) * ROWB + kc * 64;
+        const char* q = xb + ((tap - 1) * dil + fo(ct)) * ROWB + kc * 64;
         Bf[0] = *reinterpret_cast<const f16x8*>(q);
         Bf[1] = *reinterpret_cast<const f16x8*>(q + XP);
       };
@@ -339,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         __syncthreads();   // (A) halo rows in place
         if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(2);
       };
-      mfma_pipe_q<8, FAIRB, NQ>(y, A, rs_a1, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6);
+      mfma_pipe_q<8, FAIRB, NQ, DIAG>(y, A, rs_a1, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); }, prog, wave, passes);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -361,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         const f32x2 z01 = gate2_scaled(f32x2{y[rt][ct][0], y[rt][ct][1]}, f32x2{y[2 + rt][ct][0], y[2 + rt][ct][1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
         const f32x2 z23 = gate2_scaled(f32x2{y[rt][ct][2], y[rt][ct][3]}, f32x2{y[2 + rt][ct][2], y[2 + rt][ct][3]}, gcg, gcf, glim, ZSCALE);
         const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
-        char* dst = zs + (16 * ct + n16) * ROWB + (cw + 16 * rt) * 2;
+        char* dst = zs + (n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
         *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
         *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
       }
@@ -385,14 +421,16 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     {
       const char* zb = zs + n16 * ROWB + q4 * 16;
       auto ldb = [&](int ks, int ct, f16x8 (&Bf)[2]) {
-        const char* q = zb + 16 * ct * ROWB + ks * 64;
+        const char* q = zb + fo(ct) * ROWB + ks * 64;
         Bf[0] = *reinterpret_cast<const f16x8*>(q);
         Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
       };
-      mfma_pipe_q<0, FAIRB, NQ>(y, A, rs_a2, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6);
+      mfma_pipe_q<0, FAIRB, NQ, DIAG>(y, A, rs_a2, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); }, prog, wave, passes);
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
+    if (DIAG == 3) STK_STAMP(12);
     if (l + 1 < L) prefetch_a1(l + 1);
+    if (DIAG == 3) STK_STAMP(13);
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
@@ -407,12 +445,15 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 
     // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
     // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
-    cond_request(l + 1);
+    // DIAG 13 / 14 (timing experiments, same results): the request behind barrier (C1) / behind the flag, so that it does not share the
+    // CU's memory pipeline with the partner wave's weight stream while that wave is still in GEMM2
+    if (DIAG != 13 && DIAG != 14) cond_request(l + 1);
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(1);   // diagnostics: the image phase's inner boundaries instead of GEMM1's
     write_core();
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(2);
     __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
     STK_STAMP(6);
+    if (DIAG == 13) cond_request(l + 1);
     {
       // publish the first and the last 8 frames of both planes: [plane][side][8 frames][256 ch] fp16 = 16 KB, write-through
       unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (4 * 8 * C);
@@ -433,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     __syncthreads();   // (C)
     if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STK_STAMP(7);
+    if (DIAG == 14) cond_request(l + 1);
   }
 #undef STK_STAMP
   if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
@@ -469,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
           const HiLo s0 = split2(sk[ct][rt][0] * rdiv, sk[ct][rt][1] * rdiv), s1_ = split2(sk[ct][rt][2] * rdiv, sk[ct][rt][3] * rdiv);
-          char* dst = xs + (HALO + 16 * ct + n16) * ROWB + (cw + 16 * rt) * 2;
+          char* dst = xs + (HALO + n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
           *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
           *reinterpret_cast<u32x2*>(dst + XP) = u32x2{s0.lo, s1_.lo};
         }
@@ -484,10 +526,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 template <int NCT>
 static int h2q_occupancy() {
   int o = 0;
-  const int lds = (int)h2_lds(NCT);
+  const int lds = (int)h2_lds(NCT) + 64;
   if (hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
       hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT>, 512, h2_lds(NCT)) != hipSuccess)
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT>, 512, h2_lds(NCT) + 64) != hipSuccess)
     return 0;
   return o;
 }
@@ -498,7 +540,35 @@ template <int NCT>
 static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
   const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
   const TailArgs a = tail ? *tail : TailArgs{};
-  const size_t lds = h2_lds(NCT);
+  const size_t lds = h2_lds(NCT) + 64;   // + the progress words
+  static int diag = -1;   // BSG_H2Q_DIAG=1..6: timing experiments on the launches of 64-frame tiles (1 / 2: wrong results; 3: a stamp per pass; 4..6: pass-top stalls)
+  if (diag < 0) { const char* e = getenv("BSG_H2Q_DIAG"); diag = e ? atoi(e) : 0; }
+  if constexpr (NCT == 2) {
+    if (diag) {
+      auto go = [&](auto kt, auto kn) {
+        (void)hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)kn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (tail) hipLaunchKernelGGL(kt, grid, block, lds, st, p, a);
+        else hipLaunchKernelGGL(kn, grid, block, lds, st, p, a);
+      };
+      if (diag == 1) go(residual_stack_q_kernel<true, true, 2, 1>, residual_stack_q_kernel<true, false, 2, 1>);
+      else if (diag == 2) go(residual_stack_q_kernel<true, true, 2, 2>, residual_stack_q_kernel<true, false, 2, 2>);
+      else if (diag == 3) go(residual_stack_q_kernel<true, true, 2, 3>, residual_stack_q_kernel<true, false, 2, 3>);
+      else if (diag == 4) go(residual_stack_q_kernel<true, true, 2, 4>, residual_stack_q_kernel<true, false, 2, 4>);
+      else if (diag == 5) go(residual_stack_q_kernel<true, true, 2, 5>, residual_stack_q_kernel<true, false, 2, 5>);
+      else if (diag == 6) go(residual_stack_q_kernel<true, true, 2, 6>, residual_stack_q_kernel<true, false, 2, 6>);
+      else if (diag == 8) go(residual_stack_q_kernel<true, true, 2, 8>, residual_stack_q_kernel<true, false, 2, 8>);
+      else if (diag == 9) go(residual_stack_q_kernel<true, true, 2, 9>, residual_stack_q_kernel<true, false, 2, 9>);
+      else if (diag == 10) go(residual_stack_q_kernel<true, true, 2, 10>, residual_stack_q_kernel<true, false, 2, 10>);
+      else if (diag == 11) go(residual_stack_q_kernel<true, true, 2, 11>, residual_stack_q_kernel<true, false, 2, 11>);
+      else if (diag == 12) go(residual_stack_q_kernel<true, true, 2, 12>, residual_stack_q_kernel<true, false, 2, 12>);
+      else if (diag == 13) go(residual_stack_q_kernel<true, true, 2, 13>, residual_stack_q_kernel<true, false, 2, 13>);
+      else if (diag == 14) go(residual_stack_q_kernel<true, true, 2, 14>, residual_stack_q_kernel<true, false, 2, 14>);
+      else go(residual_stack_q_kernel<true, true, 2, 15>, residual_stack_q_kernel<true, false, 2, 15>);
+      BSG_LAUNCH_CHECK();
+      return BSG_OK;
+    }
+  }
   static int fair = -1;   // BSG_H2Q_FAIR=0: no time-sliced issue priority between the two waves of a SIMD
   if (fair < 0) { const char* e = getenv("BSG_H2Q_FAIR"); fair = e ? atoi(e) : 1; }
   if (!fair) {

@@ -25,16 +25,19 @@ t = torch.full((B,), 50, device=dev, dtype=torch.long)
 for _ in range(3):
     net(x, t, cond)
 torch.cuda.synchronize()
-assert net.last_path() == 'stack_h2q', net.last_path()
+assert net.last_path() in ('stack_h2q', 'stack_h2'), net.last_path()
+print('path', net.last_path())
 tiles, L = B * ((T + 63) // 64), 20
-st = torch.zeros(tiles * L * 8 * 8, dtype=torch.int64, device=dev)
+D3 = os.environ.get('BSG_H2Q_DIAG') == '3'     # 32 slots per wave: + a stamp per pass of the GEMM loops
+NS = 32 if D3 else 8
+st = torch.zeros(tiles * L * 8 * NS, dtype=torch.int64, device=dev)
 for rep in range(2):
     st.zero_()
     for _ in range(int(os.environ.get('STAMP_WARM', '500'))):
         net(x, t, cond)
     _lib.check(_lib.load().bsg_diffnet_debug_stack_stamps(net._h, 50, B, T, _lib.ptr(st), _lib.stream_ptr()), 'stamps')
     torch.cuda.synchronize()
-raw = st.cpu().numpy().reshape(tiles, L, 8, 8)          # [tile][layer][wave][slot]
+raw = st.cpu().numpy().reshape(tiles, L, 8, NS)          # [tile][layer][wave][slot]
 us = (raw & 0xffffffff).astype(np.float64) / 100.0
 cy = ((raw >> 32) & 0xffffffff).astype(np.float64)
 # slots: 0 layer start (behind the s1 scaling), 3 GEMM1 done, 4 barrier B passed, 5 GEMM2 + update done, 1 conditioner loads issued, 2 image rows written,
@@ -59,3 +62,25 @@ for name, a, unit in (('us', us, 'us'), ('cycles', cy, 'cyc')):
     print(f'  barrier C1 released - barrier B release                 {(rC1 - rB)[:, inner].mean():.2f}')
     print('  flag stored (slot 7, wave 0) - barrier C1 release       ', f'{(a[:, :, 0, 7] - rC1)[:, inner].mean():.2f}')
     print(f'  next layer start (last wave) - barrier C1 release       {(nxt - rC1)[:, inner].mean():.2f}')
+
+if D3:
+    rB = cy[:, :, :, 4].min(2)
+    t0 = cy[:, :, :, 0].max(2)
+    f = lambda v: ' '.join(f'{x:7.0f}' for x in v)
+    print('---- GEMM loops, pass by pass (cycles; a pass = two k-steps = 96 MFMAs = 1536 matrix cycles per wave)')
+    for it in range(12):
+        print(f'  GEMM1 pass {it:2d} starts - layer start  ', f(rel(cy, 16 + it, t0)))
+    print('  GEMM1 done                         ', f(rel(cy, 3, t0)))
+    for it in range(4):
+        print(f'  GEMM2 pass {it} starts - barrier B     ', f(rel(cy, 8 + it, rB)))
+    print('  GEMM2 loop done                    ', f(rel(cy, 12, rB)))
+    print('  next GEMM1 fragments requested     ', f(rel(cy, 13, rB)))
+    print('  x / skip updated (slot 5)          ', f(rel(cy, 5, rB)))
+if os.environ.get('PER_ROW'):
+    tpr = (T + 63) // 64
+    rC1 = cy[:, :, :, 6].min(2)
+    w = (cy[:, :, 0, 7] - rC1)[:, inner].reshape(B, tpr, -1).mean((1, 2))
+    print('  per-row flag stored - barrier C1 release (cycles):', ' '.join(f'{v:.0f}' for v in w))
+    st10 = us[:, 10, :, 0].max(1).reshape(B, tpr)
+    print('  per-row start of layer 10 (us, rel.):', ' '.join(f'{v:.1f}' for v in (st10.mean(1) - st10.min())))
+    print('  even / odd tiles of row 0, start of layer 10 (us):', ' '.join(f'{v:.1f}' for v in (st10[0] - st10.min())))
