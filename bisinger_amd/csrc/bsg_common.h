@@ -96,6 +96,7 @@ struct H2wArgs {
   float* C;
   int ldc;
   long long sC;                // per batch index z
+  float* Cq;                   // optional (act_is_a = 0, direct store only): the same output once more in CHANNEL-QUAD order [Wn / 4][rows][4] (+ z x sC)
   unsigned short* out;         // optional (act_is_a only): the result as hi / lo planes [rows][ldo] for the next GEMM, lo `out_plane` halfs behind
   long long out_plane;
   int ldo;

@@ -1056,6 +1056,9 @@ struct bsg_diffnet {
   int B = 0, T = 0;
   size_t cap_bt = 0;
   float* condterm = nullptr;  // [L][B][2C][T]
+  float* condterm_q = nullptr;   // the same in channel-quad order [L][B][2C/4][T][4]: what the 16-row stack launch loads (16 bytes per lane)
+  size_t cap_cond_q = 0;         // frames it holds
+  bool cond_q_valid = false;     // written by the last prepare
   float* xa = nullptr;        // [B][C][T]
   float* xb = nullptr;
   float* skip = nullptr;
@@ -1137,6 +1140,7 @@ extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->apack1h) (void)hipFree(h->apack1h);
   if (h->condterm_h) (void)hipFree(h->condterm_h);
+  if (h->condterm_q) (void)hipFree(h->condterm_q);
   if (h->skip_h) (void)hipFree(h->skip_h);
   if (h->apack2h) (void)hipFree(h->apack2h);
   if (h->tail_h) (void)hipFree(h->tail_h);
@@ -1425,6 +1429,7 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     BSG_HIP(hipMalloc((void**)&h->skip_h, (size_t)C * bt * sizeof(unsigned short)));
     h->cap_bt_h = bt;
   }
+  h->cond_q_valid = false;
   static int env_h2w = -1;   // BSG_GEMM_H2W=0: gemm_split_kernel (operands split while staged) instead of the pre-split GEMM
   if (env_h2w < 0) { const char* e = getenv("BSG_GEMM_H2W"); env_h2w = e ? atoi(e) : 1; }
   const bool h2w = env_h2w && h->cond_h2w_ok && gemm_split_enabled() && h2w_supports(T, 2 * C, C, 1, C) && (long long)h->L * B <= 65535;
@@ -1441,7 +1446,22 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
       h->cap_cond_planes = bt;
     }
     TRY(h2w_split_transposed(cond, h->cond_planes, h->cond_planes + bt * C, B, C, T, st));
+    // the 16-row stack launch (diffnet_h2q.hip) loads the term as channel quads: the same epilogue stores it once more in that order
+    // (BSG_H2_Q=0 / BSG_COND_QUAD=0: not)
+    static int env_cq = -1;
+    if (env_cq < 0) { const char* e = getenv("BSG_COND_QUAD"); const char* q = getenv("BSG_H2_Q"); env_cq = (e ? atoi(e) : 1) && (q ? atoi(q) : 1); }
+    const bool want_q = env_cq && h->compute == BSG_COMPUTE_F32 && h->apack1q && !h->h2_off && !h->split_off;
+    if (want_q && bt > h->cap_cond_q) {
+      BSG_HIP(hipStreamSynchronize(st));
+      if (h->condterm_q) (void)hipFree(h->condterm_q);
+      h->condterm_q = nullptr;
+      h->cap_cond_q = 0;
+      BSG_HIP(hipMalloc((void**)&h->condterm_q, (size_t)h->L * 2 * C * bt * sizeof(float)));
+      h->cap_cond_q = bt;
+    }
+    h->cond_q_valid = want_q;
     H2wArgs g{};
+    g.Cq = want_q ? h->condterm_q : nullptr;
     g.act = h->cond_planes; g.act_plane = (long long)bt * C; g.lda = C; g.sAct = (long long)T * C; g.wpack = h->wcond_pack;
     g.sW = (long long)2 * 2 * C * C; g.zdiv = B; g.rows = T; g.K = C; g.Wn = 2 * C; g.taps = 1; g.act_is_a = 0; g.C = h->condterm; g.ldc = T;
     g.sC = (long long)2 * C * T; g.bias = h->b_cond; g.sBias = 2 * C; g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = h->L * B;
@@ -1742,12 +1762,6 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (stamps) { const char* e = getenv("BSG_STAMP_MODE"); p.stamp_mode = e ? atoi(e) : 0; }
-    {
-      static int skew_tile = -1, skew_row = -1;   // BSG_H2_SKEW_TILE / BSG_H2_SKEW_ROW: start skews in units of 10 ns
-      if (skew_tile < 0) { const char* e = getenv("BSG_H2_SKEW_TILE"); skew_tile = e ? atoi(e) : 0; }
-      if (skew_row < 0) { const char* e = getenv("BSG_H2_SKEW_ROW"); skew_row = e ? atoi(e) : 0; }
-      p.skew_tile = skew_tile; p.skew_row = skew_row;
-    }
     if (h2 && h->stack_parts) {
       BSG_REQUIRE(!tail && nb == B, "part launch: whole batch, no fused tail");
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
@@ -1776,6 +1790,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;
       p.apack1q = h->apack1q; p.apack2q = h->apack2q;
+      p.condterm_q = h->stack_q && h->cond_q_valid ? h->condterm_q + row * 2 * C * T : nullptr;
       if (tail) {   // the step tail in the same launch: its tensors start at this launch group's first row
         TailArgs a = *tail;
         const size_t mo = (size_t)r0 * h->M * T;

@@ -33,13 +33,6 @@ constexpr int QKSB = 2 * QPLB;             // bytes per k-step (32 deep): hi sla
 using f32x4q = __attribute__((ext_vector_type(4))) float;
 #define BSG_MFMA_Q(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0)
 
-// weight-stream loads with a cache-policy experiment (DIAG 8..12: aux = sc0, nt, sc1, sc0 sc1, sc0 nt)
-template <int DIAG>
-__device__ __forceinline__ f16x8 lda8q(rsrc_t r, int voff, int soff) {
-  constexpr int AUX = DIAG == 8 ? 1 : DIAG == 9 ? 2 : DIAG == 10 ? 16 : DIAG == 11 ? 17 : DIAG == 12 ? 3 : 0;
-  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
-}
-
 // i-th executed k-step -> k-step index: GEMM1 (ROT = 8: 24 k-steps of 32, tap-major) starts with the CENTRE tap, whose B operand is the tile's
 // own frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
 template <int ROT>
@@ -54,9 +47,9 @@ __device__ __forceinline__ int kmapq(int i) {
 // inside the first MFMA group.  The ring slot is refilled during the LAST column tile of its k-step (lo fragments behind the first group, hi fragments
 // behind the last), two k-steps = 96 MFMAs ahead.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0: never): the hand-off
 // with the neighbours sits there, under the centre tap's MFMAs.  FAIRB: the two waves of a SIMD take turns at issue priority.
-template <int ROT, bool FAIRB, int NQ, int DIAG, typename LDB, typename MID, typename STAMP>
-__device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8], rsrc_t rs, int vfrag, const int (&sa)[4], int n_ks, LDB ldb,
-                                            MID mid, int half, bool diag_l1, STAMP stamp, volatile unsigned* prog, int wave, unsigned& passes) {
+template <int ROT, int NEXT_ROT, bool FAIRB, int NQ, int DIAG, typename LDB, typename MID, typename STAMP>
+__device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8], rsrc_t rs, rsrc_t rs_next, int vfrag, const int (&sa)[4], int n_ks, LDB ldb,
+                                            MID mid, int half, bool diag_l1, STAMP stamp) {
   static_assert(NQ == 2 || NQ == 4, "four operand buffers, indexed by the item's position in a pass of two k-steps");
   // operand fragments: item (k-step, column tile) -> buffer (item index in the pass) & 3, read from LDS TWO column tiles = 24 MFMAs ahead (one
   // tile ahead, its latency — 8 waves' 16-byte reads of 528-byte rows — showed between the column tiles: GEMM2 8.05 us against 6.14 for the 32-row form)
@@ -68,24 +61,7 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
 #pragma unroll 1
   for (int ks = 0; ks < n_ks; ks += 2) {
     if (DIAG == 3) stamp(ks >> 1);   // (diagnostic instantiation: one stamp per pass of two k-steps)
-    if (DIAG == 4) {   // what a stamp costs a wave, without its store: two scalar time reads and the wait for them
-      unsigned long long t_a, t_b;
-      asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a), "=s"(t_b)::"memory");
-    }
-    if (DIAG == 5) __builtin_amdgcn_s_sleep(4);
-    if (DIAG == 6) __builtin_amdgcn_s_sleep(12);
-    if (DIAG == 15) {
-      // progress feedback between the two waves of a SIMD (w, w ^ 4): each publishes the number of passes it has begun; the one that is ahead
-      // drops its issue priority, the one that is behind raises it (arbitration is by priority, then by age: without it waves 0..3 finish a
-      // GEMM thousands of cycles before their partners and then wait at the barrier)
-      ++passes;
-      prog[wave] = passes;
-      const unsigned other = prog[wave ^ 4];
-      if (passes > other) __builtin_amdgcn_s_setprio(0);
-      else if (passes < other) __builtin_amdgcn_s_setprio(3);
-      else if (half) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(1);
-    } else if (FAIRB) {
+    if (FAIRB) {
       const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
       if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
@@ -97,7 +73,12 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int kr = diag_l1 ? 0 : kmapq<ROT>(ks + s + 2 <= last ? ks + s + 2 : last) * QKSB;   // (diagnostic: every reload from ONE L1-resident k-step — wrong results)
+      // the ring runs THROUGH the GEMMs: the reloads of a GEMM's last two k-steps fetch the first two of the GEMM that follows (`rs_next`, in
+      // that GEMM's order) — clamped to the last k-step instead, they re-read it twice (12 % more weight bytes per layer), and every GEMM
+      // began with a burst of 16 fragment requests of its own
+      const bool over = ks + s + 2 > last;
+      const int kr = diag_l1 ? 0 : (over ? kmapq<NEXT_ROT>(ks + s + 2 - n_ks) : kmapq<ROT>(ks + s + 2)) * QKSB;   // (diag_l1: every reload from ONE L1-resident k-step — wrong results)
+      const rsrc_t rsr = over ? rs_next : rs;
 #pragma unroll
       for (int ct = 0; ct < NQ; ++ct) {
         const int item = s * NQ + ct;
@@ -107,7 +88,7 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
         for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt + 1], Bc[0]);   // lo hi
         if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8q<DIAG>(rs, vfrag, sa[rt] + kr + QPLB);
+          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8(rsr, vfrag, sa[rt] + kr + QPLB);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[0]);       // hi hi
@@ -115,7 +96,7 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
         for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[1]);       // hi lo
         if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8q<DIAG>(rs, vfrag, sa[rt] + kr);
+          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8(rsr, vfrag, sa[rt] + kr);
         }
         if (DIAG != 2) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -148,8 +129,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation
   float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]: d_{l+1} per channel, fetched a layer ahead
   float* btab = dtab + C;                                              // [512]: output-projection bias of the current layer
-  volatile unsigned* prog = reinterpret_cast<volatile unsigned*>(btab + 2 * C);   // [8] (+ 8 pad): passes begun, per wave (progress feedback, DIAG 15)
-  unsigned passes = 0;
 
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -168,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   const unsigned plane = (unsigned)C * T * 4;
   const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
   const int rowT = T * 4, vfrag = lane * 16;
-  int vcol[NQ], vst[NQ];
+  int vcol[NQ], vst[NQ], vquad[NQ];
   bool col_ok[NQ];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct) {
@@ -176,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     col_ok[ct] = col < T;
     vcol[ct] = (q4 * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
     vst[ct] = (q4 * 4 * T + col) * 4;
+    vquad[ct] = (q4 * T + (col_ok[ct] ? col : T - 1)) * 16;   // channel-quad order: quad q4 of the wave's row tile, frame col
   }
   // row tiles (of 16) inside a plane of a k-step slab: gate / residual rows 2w, 2w + 1; filter / skip rows 16 + 2w, 17 + 2w
   const int sa[4] = {(2 * wave) * 1024, (2 * wave + 1) * 1024, (16 + 2 * wave) * 1024, (17 + 2 * wave) * 1024};
@@ -193,6 +173,22 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 32 NCT dword loads per lane, 64 B contiguous per 16 lanes,
   // requested straight into the accumulators a phase before they are used
   auto cond_request = [&](int l) {
+    if (p.condterm_q) {
+      // channel-quad order [2C/4][T][4]: the 4 registers of an accumulator tile are ONE 16-byte load, 256 B contiguous per 16 lanes: 8 NCT
+      // requests per lane instead of 32 NCT (as dwords every 128-byte line of the term was looked up by two requests of 64 B, and the
+      // requests alone kept the trailing wave 2.6k cycles)
+      const rsrc_t rs_cq = mk_rsrc(p.condterm_q + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int so = (8 * wave + 4 * rt) * T * 16;
+#pragma unroll
+        for (int ct = 0; ct < NQ; ++ct) {
+          y[rt][ct] = ldf4(rs_cq, vquad[ct], so);
+          y[2 + rt][ct] = ldf4(rs_cq, vquad[ct], so + (C / 4) * T * 16);
+        }
+      }
+      return;
+    }
     const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -258,13 +254,12 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     *reinterpret_cast<u32x4*>(xs + XP + hrow * ROWB + hc * 16) = wl;
   }
   if (tid < C) dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
-  if (tid < 16) prog[tid] = 0u;
   btab[tid] = p.bias_out[tid];
   cond_request(0);
   __syncthreads();
   write_core();
-  // weight ring, shared by both GEMMs.  GEMM1's first k-steps (it starts with the centre tap: kmapq) are requested a phase ahead — right
-  // behind the previous layer's GEMM2 — so that the L2 latency of the weight stream is never on the layer's critical path
+  // weight ring, shared by both GEMMs and running through them (mfma_pipe_q); layer 0's first two k-steps (GEMM1 starts with the centre
+  // tap: kmapq) are requested here
   f16x8 A[2][8];
   auto prefetch_a1 = [&](int l) {
     const rsrc_t rs = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
@@ -290,15 +285,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
                : p.stamp_mode >= 4 ? (((long long)tile_id * L + l) * 8 + wave) * 8 + (i) : ((long long)tile_id * L + l) * 8 + (i)] = sv_; \
     }                                                                                                             \
   } while (0)
-  {
-    // start skew (StackArgs::skew_tile / skew_row): the odd tiles of a row and the odd rows start later.  Neighbours stay within the slack of the
-    // hand-off (a tile waits for its neighbours' edges only behind its centre tap), so the skew survives the layers
-    const int skew = (j & 1) * p.skew_tile + (b & 1) * p.skew_row;
-    if (skew > 0) {
-      const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)skew;
-      while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
-  }
   if (p.stamps && tid == 0 && p.stamp_mode < 4) p.stamps[((long long)tile_id * L + L - 1) * 8 + 6] = __builtin_amdgcn_s_memtime();   // ... and start of the first (tools/stack_stamps.py)
   if (p.clk && tile_id == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll 1
@@ -306,6 +292,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     const int dil = 1 << (l % p.cycle);
     const rsrc_t rs_a1 = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
     const rsrc_t rs_a2 = mk_rsrc(p.apack2q + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
+    const rsrc_t rs_a1n = mk_rsrc(p.apack1q + (long long)(l + 1 < L ? l + 1 : 0) * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);   // the next layer's GEMM1
     const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
     const float dnext = (tid < C && l + 1 < L) ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;   // lands during GEMM1
     const float bnext = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
@@ -375,18 +362,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         __syncthreads();   // (A) halo rows in place
         if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(2);
       };
-      mfma_pipe_q<8, FAIRB, NQ, DIAG>(y, A, rs_a1, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); }, prog, wave, passes);
+      mfma_pipe_q<8, 0, FAIRB, NQ, DIAG>(y, A, rs_a1, rs_a2, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); });
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
-    // ---- gate -> zs (hi / lo of 2^10 z); GEMM2's first weights fly meanwhile ------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        A[k][2 * rt] = lda8(rs_a2, vfrag, sa[rt] + k * QKSB);
-        A[k][2 * rt + 1] = lda8(rs_a2, vfrag, sa[rt] + k * QKSB + QPLB);
-      }
+    // ---- gate -> zs (hi / lo of 2^10 z); GEMM2's first weights are on their way since GEMM1's last two k-steps -------------------------
     if (tid < C) dtab[tid] = dnext;   // read by write_core() behind barrier (B)
     const float rs2 = inv2 * 0.70710678118654752440f;
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
@@ -425,12 +405,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         Bf[0] = *reinterpret_cast<const f16x8*>(q);
         Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
       };
-      mfma_pipe_q<0, FAIRB, NQ, DIAG>(y, A, rs_a2, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); }, prog, wave, passes);
+      mfma_pipe_q<0, 8, FAIRB, NQ, DIAG>(y, A, rs_a2, rs_a1n, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); });
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (DIAG == 3) STK_STAMP(12);
-    if (l + 1 < L) prefetch_a1(l + 1);
-    if (DIAG == 3) STK_STAMP(13);
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
@@ -445,15 +423,15 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 
     // ---- next layer: its conditioner term (128 KB per tile, the only HBM stream) is requested into the free accumulators NOW, so
     // that it lands under the image / publish phase; then the image, the edges for the neighbours, the flag ------------------------
-    // DIAG 13 / 14 (timing experiments, same results): the request behind barrier (C1) / behind the flag, so that it does not share the
-    // CU's memory pipeline with the partner wave's weight stream while that wave is still in GEMM2
-    if (DIAG != 13 && DIAG != 14) cond_request(l + 1);
+    // (Requested behind barrier (C1) or behind the flag instead — so that it does not share the CU's memory pipeline with the partner wave's
+    // weight stream while that wave is still in GEMM2 — the trailing wave's GEMM2 is 5k cycles shorter and the wait for the term as much
+    // longer: a CU takes ~12k cycles for its 128 KB wherever they are requested, profiles/r05_q_not_kept.txt)
+    cond_request(l + 1);
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(1);   // diagnostics: the image phase's inner boundaries instead of GEMM1's
     write_core();
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(2);
     __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
     STK_STAMP(6);
-    if (DIAG == 13) cond_request(l + 1);
     {
       // publish the first and the last 8 frames of both planes: [plane][side][8 frames][256 ch] fp16 = 16 KB, write-through
       unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (4 * 8 * C);
@@ -474,7 +452,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     __syncthreads();   // (C)
     if (tid == 0) __hip_atomic_store(p.flags + tile_id, p.fbase + (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STK_STAMP(7);
-    if (DIAG == 14) cond_request(l + 1);
   }
 #undef STK_STAMP
   if (tid == 0) stack_epoch_done(p, p.fbase, n_tiles);
@@ -526,10 +503,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 template <int NCT>
 static int h2q_occupancy() {
   int o = 0;
-  const int lds = (int)h2_lds(NCT) + 64;
+  const int lds = (int)h2_lds(NCT);
   if (hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
       hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT>, 512, h2_lds(NCT) + 64) != hipSuccess)
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT>, 512, h2_lds(NCT)) != hipSuccess)
     return 0;
   return o;
 }
@@ -540,8 +517,8 @@ template <int NCT>
 static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
   const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
   const TailArgs a = tail ? *tail : TailArgs{};
-  const size_t lds = h2_lds(NCT) + 64;   // + the progress words
-  static int diag = -1;   // BSG_H2Q_DIAG=1..6: timing experiments on the launches of 64-frame tiles (1 / 2: wrong results; 3: a stamp per pass; 4..6: pass-top stalls)
+  const size_t lds = h2_lds(NCT);
+  static int diag = -1;   // BSG_H2Q_DIAG=1 / 2 / 3: timing experiments on the launches of 64-frame tiles (1: no weight reloads, 2: no operand reads either — wrong results; 3: a stamp per pass)
   if (diag < 0) { const char* e = getenv("BSG_H2Q_DIAG"); diag = e ? atoi(e) : 0; }
   if constexpr (NCT == 2) {
     if (diag) {
@@ -553,18 +530,7 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
       };
       if (diag == 1) go(residual_stack_q_kernel<true, true, 2, 1>, residual_stack_q_kernel<true, false, 2, 1>);
       else if (diag == 2) go(residual_stack_q_kernel<true, true, 2, 2>, residual_stack_q_kernel<true, false, 2, 2>);
-      else if (diag == 3) go(residual_stack_q_kernel<true, true, 2, 3>, residual_stack_q_kernel<true, false, 2, 3>);
-      else if (diag == 4) go(residual_stack_q_kernel<true, true, 2, 4>, residual_stack_q_kernel<true, false, 2, 4>);
-      else if (diag == 5) go(residual_stack_q_kernel<true, true, 2, 5>, residual_stack_q_kernel<true, false, 2, 5>);
-      else if (diag == 6) go(residual_stack_q_kernel<true, true, 2, 6>, residual_stack_q_kernel<true, false, 2, 6>);
-      else if (diag == 8) go(residual_stack_q_kernel<true, true, 2, 8>, residual_stack_q_kernel<true, false, 2, 8>);
-      else if (diag == 9) go(residual_stack_q_kernel<true, true, 2, 9>, residual_stack_q_kernel<true, false, 2, 9>);
-      else if (diag == 10) go(residual_stack_q_kernel<true, true, 2, 10>, residual_stack_q_kernel<true, false, 2, 10>);
-      else if (diag == 11) go(residual_stack_q_kernel<true, true, 2, 11>, residual_stack_q_kernel<true, false, 2, 11>);
-      else if (diag == 12) go(residual_stack_q_kernel<true, true, 2, 12>, residual_stack_q_kernel<true, false, 2, 12>);
-      else if (diag == 13) go(residual_stack_q_kernel<true, true, 2, 13>, residual_stack_q_kernel<true, false, 2, 13>);
-      else if (diag == 14) go(residual_stack_q_kernel<true, true, 2, 14>, residual_stack_q_kernel<true, false, 2, 14>);
-      else go(residual_stack_q_kernel<true, true, 2, 15>, residual_stack_q_kernel<true, false, 2, 15>);
+      else go(residual_stack_q_kernel<true, true, 2, 3>, residual_stack_q_kernel<true, false, 2, 3>);
       BSG_LAUNCH_CHECK();
       return BSG_OK;
     }

@@ -39,6 +39,7 @@ struct StackArgs {
   float* skip;            // [B][C][T] output: skip sum / sqrt(L)
   unsigned short* skip_h; // bf16 form: the same as bf16 channel quads [B][C/4][T][4]
   const float* condterm;  // layer 0, this launch's rows: [B][2C][T]; + l * ct_stride for layer l
+  const float* condterm_q; // 16-row stack launch: the same in channel-quad order [B][2C/4][T][4] (null: `condterm`); + l * ct_stride
   const float* dproj;     // [S][L][C]
   const long long* t_dev; // [B] or null
   const float* apackw;    // layer 0; + l * aw_stride
@@ -68,9 +69,6 @@ struct StackArgs {
   int pflag_words;        // the same for `pflags` (part forms)
   int stamp_mode;         // diagnostics (BSG_STAMP_MODE, part forms): 1 = stamp slots 1 / 2 mark the gate phase's inner boundaries instead of GEMM1's
   int inject;             // fault injection: consumers do not wait
-  // start skew of the one-workgroup-per-tile stack launches, in ticks of s_memrealtime (10 ns): odd tiles of a row / odd rows start that much
-  // later, so that the conditioner bursts of an XCD's 32 workgroups (4 MB per layer through ONE XCD's share of the HBM path) do not coincide
-  int skew_tile, skew_row;
   // part forms of the split-fp16 launch (residual_part_h2_kernel, small batches): exchange of the P channel parts of a tile
   unsigned short* zx;     // [n_tiles][P parts][2 planes][tile frames][C/P] fp16: gated activation parts
   unsigned short* ix;     // [2 parities][n_tiles][P parts][2 planes][tile frames][C/P] fp16: image parts (core frames; neighbours read the edges)

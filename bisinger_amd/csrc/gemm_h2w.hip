@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
   _Float16* __restrict__ oh = g.out ? reinterpret_cast<_Float16*>(g.out) + (long long)z * g.sO : nullptr;
   constexpr int ER = ACT_IS_A ? BMA : 128, EC = ACT_IS_A ? 128 : BMA, EP = EC + 4;   // image rows x columns (columns = the output's contiguous axis), pitch
   float* et = reinterpret_cast<float*>(lds);
-  if (!ACT_IS_A && !g.up_u && !Rp && !RS && g.act_fn == ACT_NONE && !g.no_direct) {
+  if (!ACT_IS_A && !g.up_u && !Rp && !RS && g.act_fn == ACT_NONE && (!g.no_direct || g.Cq)) {
     // [feature][frame] output with nothing but bias / alpha in the epilogue (the conditioner hoist: 655 MB of fp32 per pass at B = 16): straight from
     // the accumulators — a register is 32 consecutive frames of one feature row per lane half (two 128-byte runs per store) — without the LDS
     // image, its two barriers and the rolled loop
@@ -307,6 +307,17 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
         float v = c[mi][r] * H2W_OUT + bv[r];
         if (g.alpha_ncols == 0 || wrow < g.alpha_ncols) v *= g.alpha;
         Cp[(long long)wrow * g.ldc + arow] = v;
+        c[mi][r] = v;
+      }
+      if (g.Cq) {
+        // channel-quad order: the 4 registers of a group are 4 consecutive feature rows of one frame = one 16-byte store, 512 B contiguous per
+        // half-wave (the 16-row stack launch loads its conditioner term as such quads, diffnet_h2q.hip)
+        float* __restrict__ Cq = g.Cq + (long long)z * g.sC;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int wrow = wt128 * 128 + wave * 32 + acc_row(4 * gq, lh);
+          *reinterpret_cast<f32x4*>(Cq + ((long long)(wrow >> 2) * g.rows + arow) * 4) = f32x4{c[mi][4 * gq], c[mi][4 * gq + 1], c[mi][4 * gq + 2], c[mi][4 * gq + 3]};
+        }
       }
     }
     return;
