@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
 if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
     LIB_PATH = os.environ['BSG_LIB']
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class BsgError(RuntimeError):
@@ -83,6 +83,9 @@ _SIGS = {
     'bsg_diffnet_uses_handoffs': (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_int32)]),
     'bsg_diffnet_set_split': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_debug_inject_giveup': (c_int32, [c_void_p, c_int32]),
+    'bsg_diffnet_debug_set_epoch': (c_int32, [c_void_p, c_uint32, c_void_p]),
+    'bsg_diffnet_debug_inject_xcc': (c_int32, [c_void_p, c_int32]),
+    'bsg_diffnet_set_parts': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_profile': (c_int32, [c_void_p, c_int32]),
     'bsg_diffnet_profile_read': (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64)]),
     'bsg_fs2midi_n_weights': (c_int32, [POINTER(Fs2Cfg)]),

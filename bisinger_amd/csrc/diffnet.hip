@@ -1103,6 +1103,8 @@ struct bsg_diffnet {
   unsigned split_epoch = 0;
   bool split_off = false;              // bsg_diffnet_set_split(h, 0): regular launches only (the self-heal path after a give-up)
   int inject_giveup = 0;               // bsg_diffnet_debug_inject_giveup: split launches left that give up without waiting
+  int inject_xcc = 0;                  // bsg_diffnet_debug_inject_xcc: part launches left in which odd parts report another XCD
+  bool parts_off = false;              // bsg_diffnet_set_parts(h, 0): no part forms (several workgroups per tile on CUs of ONE XCD); the one-workgroup-per-tile launches stay
   // residency of the split kernels on this handle's device (workgroups per CU; -1 = not queried yet): pair / 4-way form with the
   // padded LDS size (one workgroup per CU by construction) and with the plain size (two chains share a CU), 16-wave form
   int occ2 = -1, occ4 = -1, occw = -1, occ2s = -1, occ4s = -1;
@@ -1665,7 +1667,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
         };
         const long long t32 = (long long)B * cdiv(T, 32), t64 = (long long)B * cdiv(T, 64);
         const bool part_bufs = !capturing || (size_t)(2 * t64) <= h->part_cap;   // (sized in 32-frame tile equivalents; 2 t64 >= t32)
-        if (env_part && env_nct == 0 && h->apack1q && part_bufs) {
+        if (env_part && !h->parts_off && env_nct == 0 && h->apack1q && part_bufs) {
           if (env_quad && 4 * 8 * cdiv(t32, 8) <= h->num_cus && take_quad(1)) return B;
           if (env_quad64 && 4 * 8 * cdiv(t64, 8) <= h->num_cus && take_quad(2)) return B;
           static int env_pair64 = -1;
@@ -1734,6 +1736,13 @@ static int next_stack_epoch(bsg_diffnet* h, StackArgs& p) {
   p.fbase = 0;
   p.flag_words = (int)h->flags_cap;
   p.pflag_words = 0;   // part forms: set with p.pflags
+  // the flags a wrapping launch zeroes: BOTH arrays of the handle, whichever form wraps (a part launch that has to grow the part arrays
+  // replaces them below, zeroed, and updates these two)
+  p.wrap_pflags = h->part_flags;
+  p.wrap_pflag_words = h->part_flags ? (int)(2 * h->part_cap * 4) : 0;
+  static int env_old = -1;   // BSG_DEBUG_WRAP_R04=1: round 4's behaviour (only a PART launch zeroes the part flags at a wrap) — the negative control of tests/test_gpu_handoff.py
+  if (env_old < 0) { const char* e = getenv("BSG_DEBUG_WRAP_R04"); env_old = e ? atoi(e) : 0; }
+  if (env_old) { p.wrap_pflags = nullptr; p.wrap_pflag_words = 0; }
   return BSG_OK;
 }
 
@@ -1759,6 +1768,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.hx = h->hx; p.flags = h->flags; p.status = h->flags + h->flags_cap;
     TRY(next_stack_epoch(h, p));
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
+    else if (h->inject_xcc > 0 && h2 && h->stack_parts) { p.inject = 2; --h->inject_xcc; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (stamps) { const char* e = getenv("BSG_STAMP_MODE"); p.stamp_mode = e ? atoi(e) : 0; }
@@ -1785,6 +1795,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       }
       p.zx = h->part_zx; p.ix = h->part_ix; p.pflags = h->part_flags;
       p.pflag_words = (int)(2 * h->part_cap * 4);
+      p.wrap_pflags = h->part_flags; p.wrap_pflag_words = p.pflag_words;   // (also under BSG_DEBUG_WRAP_R04: a part launch always zeroed its own)
       p.apack1q = h->apack1q; p.apack2q = h->apack2q;
       TRY(launch_residual_part_h2(p, st, h->stack_parts, nct));
     } else if (h2) {
@@ -2234,6 +2245,34 @@ extern "C" int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable) {
 extern "C" int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable) {
   BSG_REQUIRE(h, "diffnet_set_h2: null handle");
   h->h2_off = enable == 0;
+  return BSG_OK;
+}
+
+// test hook (ABI v6): the launch epoch of the handle's stack / part launches (device memory) := epoch, so that the wrap at 2^25 — two
+// hours of single-utterance serving away — can be driven by a test
+extern "C" int bsg_diffnet_debug_set_epoch(bsg_diffnet* h, uint32_t epoch, void* stream) {
+  BSG_REQUIRE(h && h->epoch_dev && epoch >= 1u, "diffnet_debug_set_epoch: no launch epoch yet (prepare allocates it), or epoch 0");
+  hipStream_t st = (hipStream_t)stream;
+  BSG_HIP(hipStreamSynchronize(st));
+  const unsigned v[2] = {epoch, 0u};
+  BSG_HIP(hipMemcpy(h->epoch_dev, v, sizeof(v), hipMemcpyHostToDevice));
+  // flag words hold epoch x 64 + layer of launches that ran under smaller epochs: still older than every launch from here on
+  return BSG_OK;
+}
+
+// fault injection (ABI v6): in the next n_launches PART launches the odd parts of every tile report another XCC id than the one they run on —
+// what the parts would see under a dispatch order other than workgroup i -> XCD i mod 8
+extern "C" int bsg_diffnet_debug_inject_xcc(bsg_diffnet* h, int32_t n_launches) {
+  BSG_REQUIRE(h && n_launches >= 0, "diffnet_debug_inject_xcc: bad argument");
+  h->inject_xcc = n_launches;
+  return BSG_OK;
+}
+
+// part forms on / off for this handle (ABI v6): the first tier of the self-heal after a hand-off give-up inside a part launch — the
+// one-workgroup-per-tile stack launch needs no placement on one XCD and stays; bsg_diffnet_set_split(h, 0) is the second tier
+extern "C" int bsg_diffnet_set_parts(bsg_diffnet* h, int32_t enable) {
+  BSG_REQUIRE(h, "diffnet_set_parts: null handle");
+  h->parts_off = !enable;
   return BSG_OK;
 }
 

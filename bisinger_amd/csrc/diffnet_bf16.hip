@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
           for (int side = 0; side < 2; ++side) {
             if (side == 0 ? !has_left : !has_right) continue;
             const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
-            if (p.inject) { atomicAdd(p.status, 1u); continue; }
+            if (p.inject == 1) { atomicAdd(p.status, 1u); continue; }
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
               __builtin_amdgcn_s_sleep(2);
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
       unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (2 * 8 * C);
       const int side = tid >> 8, f = (tid >> 5) & 7, c16 = tid & 31;
       const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (HALO + (side ? NT - 8 : 0) + f) * ROWB + c16 * 16);
-      if (!(p.inject && (tile_id & 1))) {
+      if (!(p.inject == 1 && (tile_id & 1))) {
         const rsrc_t rs_hx = mk_rsrc(hx_t, 2 * 8 * C * 2);
         __builtin_amdgcn_raw_buffer_store_b128(v, rs_hx, ((side * 8 + f) * C + c16 * 8) * 2, 0, 16);   // sc1
       }

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
         float* hx_t = p.hx + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (2 * C * 8);
         const rsrc_t rs_hx = mk_rsrc(hx_t, 2 * C * 8 * 4);
         const int row = tid >> 3, f = tid & 7;
-        if (!(p.inject && (tile_id & 1))) {
+        if (!(p.inject == 1 && (tile_id & 1))) {
 #pragma unroll
           for (int side = 0; side < 2; ++side) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(xs + ((row * FS6 + HALO + (side ? NT6 - 8 : 0) + f) << 2));
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_f43_kernel(StackArgs p)
       for (int side = 0; side < 2; ++side) {
         if (side == 0 ? !has_left : !has_right) continue;
         const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
-        if (p.inject) { atomicAdd(p.status, 1u); continue; }
+        if (p.inject == 1) { atomicAdd(p.status, 1u); continue; }
         unsigned spins = 0;
         while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
           __builtin_amdgcn_s_sleep(2);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           const bool mine = lane == 0 ? has_left : (lane == 1 ? has_right : false);
           const unsigned* fl = p.flags + (lane == 0 ? tile_id - 1 : tile_id + 1);
           bool pend = mine;
-          if (p.inject) {
+          if (p.inject == 1) {
             if (pend) atomicAdd(p.status, 1u);
           } else {
             unsigned spins = 0;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
           for (int side = 0; side < 2; ++side) {
             if (side == 0 ? !has_left : !has_right) continue;
             const unsigned* fl = p.flags + (side == 0 ? tile_id - 1 : tile_id + 1);
-            if (p.inject) { atomicAdd(p.status, 1u); continue; }
+            if (p.inject == 1) { atomicAdd(p.status, 1u); continue; }
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
               __builtin_amdgcn_s_sleep(2);
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_h2_kernel(StackArgs p, 
       const char* srcp = xs + (HALO + (side ? NT - 8 : 0) + f) * ROWB + c16 * 16;
       const u32x4 vh = *reinterpret_cast<const u32x4*>(srcp);
       const u32x4 vl = *reinterpret_cast<const u32x4*>(srcp + XP);
-      if (!(p.inject && (tile_id & 1))) {
+      if (!(p.inject == 1 && (tile_id & 1))) {
         const rsrc_t rs_hx = mk_rsrc(hx_t, 4 * 8 * C * 2);
         const int o = ((side * 8 + f) * C + c16 * 8) * 2;
         __builtin_amdgcn_raw_buffer_store_b128(vh, rs_hx, o, 0, 16);                   // sc1
@@ -1219,10 +1219,13 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
   const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
   auto wait_flags = [&](const unsigned* fl, unsigned want) {   // a whole wave: every lane with a flag polls its own; bounded
     bool pend = fl != nullptr;
-    if (p.inject) {
+    if (p.inject == 1) {
       if (pend) atomicAdd(p.status, 1u);
       return;
     }
+    // a launch that has already counted a give-up (status != 0: the host repeats the call anyway) waits for nothing any more — in particular
+    // not for flags that partners on ANOTHER XCD store plainly and that never become visible here (checked first, below)
+    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     unsigned spins = 0;
     while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
       if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
@@ -1362,7 +1365,8 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     }
   };
   prefetch_a1(0);
-  if (tid == 0) __hip_atomic_store(xcc_tab + P * tile_id + q, p.fbase + my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (p.inject == 2, fault injection: odd parts publish ANOTHER id, as if the dispatcher had placed them on another XCD)
+  if (tid == 0) __hip_atomic_store(xcc_tab + P * tile_id + q, p.fbase + (p.inject == 2 && (q & 1) ? my_xcc ^ 1u : my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (p.clk && tile_id == 0 && q == 0 && tid == 0) { p.clk[0] = __builtin_amdgcn_s_memtime(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
   __syncthreads();   // the staged image and the tables
 
@@ -1471,7 +1475,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     // z is read by the partners only, and they sit on THIS XCD (checked below): plain stores, which keep the lines in the XCD's L2 — the
     // partners' L1-bypassing loads are served there at the same-XCD rate; write-through stores would drop them from L2
     // (MI355X_MICROARCH.md, stores of each flavour)
-    if (!(p.inject && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q), std::integral_constant<int, 0>{});
+    if (!(p.inject == 1 && (tile_id & 1))) part_out(zs, ZP, 0, q, zx_slot(tile_id, q), std::integral_constant<int, 0>{});
     if (p.stamp_mode) QUAD_STAMP(2);   // barrier Z1 passed, the z part copied out of LDS (stores issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached L2
     __syncthreads();
@@ -1487,14 +1491,28 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
       const char* zb = zs + l15 * ROWQ + kb * 16;
       auto mid2 = [&]() {
         if (wave == 0) {
-          wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
-          if (l == 0 && lane < P - 1) {
-            // once per launch: do the partners really run on this XCD?  (Each part stored its XCC id in front of its first flag.)  If not —
-            // another dispatch order than workgroup i -> XCD i mod 8 — their plain stores are not visible here: count a give-up, the host
-            // repeats the evaluation without hand-offs and keeps them off
-            const unsigned theirs = __hip_atomic_load(xcc_tab + P * tile_id + (lane < q ? lane : lane + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (theirs != p.fbase + my_xcc) atomicAdd(p.status, 1u);
+          if (l == 0) {
+            // once per launch, BEFORE the first wait on a plainly stored flag: do the partners really run on this XCD?  Each part stored
+            // launch epoch + XCC id with an agent-scope store at its start (visible from every XCD), so a bounded poll of those words
+            // terminates wherever the partner runs; another id than ours — another dispatch order than workgroup i -> XCD i mod 8 —
+            // counts a give-up at once (round 4 looked only behind the first flag wait: the partner's plain flag store never became
+            // visible here and the mismatch was noticed after a full bounded spin, seconds).  The host then takes the part forms off
+            // this handle and repeats the call on the one-workgroup-per-tile launch (DiffNet.guarded)
+            const unsigned* xw = lane < P - 1 ? xcc_tab + P * tile_id + (lane < q ? lane : lane + 1) : nullptr;
+            bool pend = xw != nullptr && p.inject != 1;
+            unsigned theirs = 0, spins = 0;
+            while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
+              if (pend) {
+                theirs = __hip_atomic_load(xw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend = theirs - p.fbase >= 16u;   // not yet this launch's word (epoch x 64 + id)
+              }
+              if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) break;
+            }
+            if (xw != nullptr && p.inject != 1 && (pend || theirs != p.fbase + my_xcc)) atomicAdd(p.status, 1u);
           }
+          wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
         }
         __syncthreads();   // the partners' parts of z are published
         parts_in(zs, ZP, 0, [&](int part) { return zx_slot(tile_id, part); });
@@ -1516,7 +1534,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     write_core();
     __syncthreads();   // (C1) the own quarter of the core rows is complete
     // the own part of the image: plain stores for the partners (this XCD, like z), the edges once more write-through for the neighbours
-    if (!(p.inject && (tile_id & 1))) {
+    if (!(p.inject == 1 && (tile_id & 1))) {
       part_out(xs, XP, HALO, q, ix_slot((l + 1) & 1, tile_id, q), std::integral_constant<int, 0>{});
       edges_out((l + 1) & 1);
     }

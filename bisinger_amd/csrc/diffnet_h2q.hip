@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
           const bool mine = lane == 0 ? has_left : (lane == 1 ? has_right : false);
           const unsigned* fl = p.flags + (lane == 0 ? tile_id - 1 : tile_id + 1);
           bool pend = mine;
-          if (p.inject) {
+          if (p.inject == 1) {
             if (pend) atomicAdd(p.status, 1u);
           } else {
             unsigned spins = 0;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
       const char* srcp = xs + (HALO + (side ? NT - 8 : 0) + f) * ROWB + c16 * 16;
       const u32x4 vh = *reinterpret_cast<const u32x4*>(srcp);
       const u32x4 vl = *reinterpret_cast<const u32x4*>(srcp + XP);
-      if (!(p.inject && (tile_id & 1))) {
+      if (!(p.inject == 1 && (tile_id & 1))) {
         const rsrc_t rs_hx = mk_rsrc(hx_t, 4 * 8 * C * 2);
         const int o = ((side * 8 + f) * C + c16 * 8) * 2;
         __builtin_amdgcn_raw_buffer_store_b128(vh, rs_hx, o, 0, 16);                   // sc1

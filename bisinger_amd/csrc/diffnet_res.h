@@ -67,6 +67,11 @@ struct StackArgs {
   unsigned* epoch;        // null: p.fbase
   int flag_words;         // words of `flags` to zero at a wrap (the status words behind them are not touched)
   int pflag_words;        // the same for `pflags` (part forms)
+  // zeroed at an epoch wrap by WHATEVER launch wraps (round 5): the handle's part-form flags even when this launch does not wait on
+  // them (p.pflags null) — a wrap inside a whole-tile launch used to leave them near 2^31 while the epochs restarted at 1, and the next part
+  // launch then saw every flag 'published'
+  unsigned* wrap_pflags;
+  int wrap_pflag_words;
   int stamp_mode;         // diagnostics (BSG_STAMP_MODE, part forms): 1 = stamp slots 1 / 2 mark the gate phase's inner boundaries instead of GEMM1's
   int inject;             // fault injection: consumers do not wait
   // part forms of the split-fp16 launch (residual_part_h2_kernel, small batches): exchange of the P channel parts of a tile
@@ -90,8 +95,8 @@ __device__ __forceinline__ void stack_epoch_done(const StackArgs& p, unsigned fb
   unsigned next = fbase / 64u + 1u;
   if (next >= (1u << 25)) {   // flag values = epoch * 64 + layer in 32 bits: start again from zeroed flags, as nothing else runs on them now
     for (int i = 0; i < p.flag_words; ++i) p.flags[i] = 0u;
-    if (p.pflags)
-      for (int i = 0; i < p.pflag_words; ++i) p.pflags[i] = 0u;
+    if (p.wrap_pflags)
+      for (int i = 0; i < p.wrap_pflag_words; ++i) p.wrap_pflags[i] = 0u;
     next = 1u;
   }
   __hip_atomic_store(p.epoch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

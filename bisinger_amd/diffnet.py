@@ -218,6 +218,7 @@ class DiffNet(nn.Module):
             _lib.check(_lib.load().bsg_diffnet_health_take(self._h, c, _lib.stream_ptr()), 'bsg_diffnet_health_take')
         return c[0], c[1]
 
+    PART_PATHS = ('stack_h2_quad', 'stack_h2_quad64', 'stack_h2_pair64')
     CLEAN_CALLS_TO_REENABLE = 32     # guarded calls without a give-up after which a demoted handle tries hand-off launches again
     H2_STRIKES_MAX = 3               # range events of the split-fp16 stack launch after which the handle stays on the fp32 matrix pipe
 
@@ -265,11 +266,19 @@ class DiffNet(nn.Module):
             if self._clean_calls >= self.CLEAN_CALLS_TO_REENABLE:
                 _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
                 self.split_disabled, self._clean_calls = False, 0
+                if getattr(self, 'parts_disabled', False):      # both tiers come back together
+                    _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
+                    self.parts_disabled, self._clean_calls_parts = False, 0
             return
         if not self.uses_handoffs(B, T):
             return
         give, rng = self.take_health()
         if not give and not rng:
+            if getattr(self, 'parts_disabled', False):      # part forms come back after as many clean calls as hand-off launches do
+                self._clean_calls_parts = getattr(self, '_clean_calls_parts', 0) + 1
+                if self._clean_calls_parts >= self.CLEAN_CALLS_TO_REENABLE:
+                    _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
+                    self.parts_disabled, self._clean_calls_parts = False, 0
             return
         if rng and not give:
             warnings.warn(f'bisinger_amd: {rng} waves saw an activation beyond the fp16 range of the split-fp16 launch (|x + d| >= 60000); '
@@ -290,6 +299,22 @@ class DiffNet(nn.Module):
                 return
             give, rng = self.take_health()
             if not give:
+                return
+        if self.last_path() in self.PART_PATHS and not getattr(self, 'parts_disabled', False):
+            # first tier: the give-up came out of a PART launch (several workgroups per tile on CUs of one XCD: partners not on this XCD, or not
+            # resident).  The one-workgroup-per-tile stack launch does not depend on that placement: part forms off, repeat; only if that
+            # launch gives up too does the handle go to launches without hand-offs (below)
+            warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up inside a part launch ({self.last_path()}); part forms are off '
+                          f'for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (one workgroup per tile) and the evaluation is repeated')
+            _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 0), 'bsg_diffnet_set_parts')
+            self.parts_disabled, self._clean_calls_parts = True, 0
+            if restore is not None:
+                restore()
+            run()
+            if not self.uses_handoffs(B, T):
+                return
+            give, rng = self.take_health()
+            if not give and not rng:
                 return
         warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up (a partner workgroup was not resident); channel-split and '
                       f'stack launches are off for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (per-layer launches '
@@ -330,11 +355,19 @@ class DiffNet(nn.Module):
         # the words are cumulative until a take resets them: the newest completed read says everything
         give, rng, give_split = words[-1]
         if not (give or rng or give_split):
+            if getattr(self, 'parts_disabled', False):
+                self._clean_calls_parts = getattr(self, '_clean_calls_parts', 0) + len(words)
+                if self._clean_calls_parts >= self.CLEAN_CALLS_TO_REENABLE:
+                    _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
+                    self.parts_disabled, self._clean_calls_parts = False, 0
             if getattr(self, 'split_disabled', False):
                 self._clean_calls = getattr(self, '_clean_calls', 0) + len(words)
                 if self._clean_calls >= self.CLEAN_CALLS_TO_REENABLE:
                     _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 1), 'bsg_diffnet_set_split')
                     self.split_disabled, self._clean_calls = False, 0
+                    if getattr(self, 'parts_disabled', False):
+                        _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
+                        self.parts_disabled, self._clean_calls_parts = False, 0
             return
         self.take_health()      # waits for the stream and resets the words;
         rec.pending.clear()     # reads enqueued before this point repeat the same (cumulative) counts: dropped — repeat everything issued since the last clean check
@@ -345,7 +378,13 @@ class DiffNet(nn.Module):
             self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
             what.append(f'{rng} waves saw a value beyond the fp16 range of the split-fp16 launch (this handle now runs the fp32 matrix pipe '
                         f'while this condition is bound)')
-        if give or give_split:
+        if give and not give_split and self.last_path() in self.PART_PATHS and not getattr(self, 'parts_disabled', False):
+            # first tier (as in the same-call mode): the give-up came out of a part launch; the one-workgroup-per-tile launch stays
+            _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 0), 'bsg_diffnet_set_parts')
+            self.parts_disabled, self._clean_calls_parts = True, 0
+            what.append(f'{give} inter-workgroup hand-offs gave up inside a part launch (part forms are off for the next '
+                        f'{self.CLEAN_CALLS_TO_REENABLE} calls)')
+        elif give or give_split:
             _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
             self.split_disabled, self._clean_calls = True, 0
             what.append(f'{give + give_split} inter-workgroup hand-offs gave up (hand-off launches are off for the next '
@@ -356,6 +395,14 @@ class DiffNet(nn.Module):
     def debug_inject_giveup(self, n_launches):
         """Fault injection (tests): the next ``n_launches`` channel-split launches give up their hand-offs without waiting."""
         _lib.check(_lib.load().bsg_diffnet_debug_inject_giveup(self.handle(), int(n_launches)), 'bsg_diffnet_debug_inject_giveup')
+
+    def debug_inject_xcc(self, n_launches):
+        """Fault injection (tests): in the next ``n_launches`` part launches the odd parts of a tile report another XCD than their own."""
+        _lib.check(_lib.load().bsg_diffnet_debug_inject_xcc(self.handle(), int(n_launches)), 'bsg_diffnet_debug_inject_xcc')
+
+    def debug_set_epoch(self, epoch):
+        """Test hook: the device-side launch epoch of the handle's stack / part launches (wraps to 1 at 2**25, zeroing the hand-off flags)."""
+        _lib.check(_lib.load().bsg_diffnet_debug_set_epoch(self.handle(), int(epoch), _lib.stream_ptr()), 'bsg_diffnet_debug_set_epoch')
 
     def profile(self, enable):
         """Record hipEvent pairs around the residual-layer launches of every evaluation (bench.py roofline)."""

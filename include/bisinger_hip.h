@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSG_ABI_VERSION 5
+#define BSG_ABI_VERSION 6
 
 #define BSG_OK 0
 #define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
@@ -184,6 +184,16 @@ int bsg_diffnet_set_split(bsg_diffnet* h, int32_t enable);
  * hand-off without waiting (counted exactly like a timed-out spin) and one producer per tile (pair) never publishes, so the
  * consumers deterministically read stale exchange data. */
 int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches);
+/* Fault injection (ABI v6): in the next n_launches PART launches (several workgroups per tile on CUs of one XCD) the odd parts report
+ * another XCC id than the one they run on — a dispatch order other than workgroup i -> XCD i mod 8.  Counted as hand-off give-ups. */
+int bsg_diffnet_debug_inject_xcc(bsg_diffnet* h, int32_t n_launches);
+/* Part forms on (1, default) / off (0) for this handle (ABI v6): with them off small batches run the one-workgroup-per-tile stack launch,
+ * which exchanges only tile edges with write-through stores and needs no placement on one XCD.  First tier of the recovery after a
+ * give-up inside a part launch; bsg_diffnet_set_split(h, 0) (no hand-off launches at all) is the second. */
+int bsg_diffnet_set_parts(bsg_diffnet* h, int32_t enable);
+/* Test hook (ABI v6): sets the device-side launch epoch of the handle's stack / part launches (hand-off flag values are epoch x 64 + layer;
+ * the epoch restarts at 1, with every flag array of the handle zeroed, once it reaches 2^25).  Waits for `stream`.  epoch >= 1. */
+int bsg_diffnet_debug_set_epoch(bsg_diffnet* h, uint32_t epoch, void* stream);
 /* Name of the form the last residual-layer launch on the handle took: "stack" (all L layers in one launch with the residual
  * stream on chip), "layer" (one launch per layer, one workgroup per tile), "split2" / "split4" (a tile as 2 / 4 workgroups),
  * "wide" (one 16-wave workgroup per tile), "bf16", or "none".  Static string. */
