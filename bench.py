@@ -175,10 +175,21 @@ def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps, repeats=3):
                 ret = omg.mel_gen(sd, inp, noise, fs2_out=fs2_out, n_steps=n_sample_steps)
             t2 = time.perf_counter()
             runs.append(((t1 - t0) + (t2 - t1) / min(n_sample_steps, N_DIFF_STEPS) * N_DIFF_STEPS, t1 - t0, t2 - t1))
-    torch.set_num_threads(default_threads)
     runs.sort()
     est, t_fs2, t_steps = runs[len(runs) // 2]
     best_n = min(sweep, key=sweep.get)
+    # the same timed leg once more at the sweep's FASTEST thread count — measured, not derived from the sweep's ratio
+    fast = None
+    if best_n != cores:
+        torch.set_num_threads(best_n)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            fo = ofs2.fs2_forward(sd, inp)
+            t1 = time.perf_counter()
+            omg.mel_gen(sd, inp, noise, fs2_out=fo, **({} if n_sample_steps >= N_DIFF_STEPS else {'n_steps': n_sample_steps}))
+            t2 = time.perf_counter()
+        fast = ((t1 - t0) + (t2 - t1) / min(n_sample_steps, N_DIFF_STEPS) * N_DIFF_STEPS, t1 - t0, t2 - t1)
+    torch.set_num_threads(default_threads)
     # replay on the GPU
     d = {k: v.to(device) for k, v in inp.items()}
     kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
@@ -214,6 +225,9 @@ def cpu_baseline_and_parity(model, inp_np, device, n_sample_steps, repeats=3):
         'value_at_fastest_sweep_setting': B * T_FRAMES / (t_fs2 + sweep[best_n] / sweep[cores] * t_steps / min(n_sample_steps, N_DIFF_STEPS) * N_DIFF_STEPS)
         if cores in sweep else None,
         'fastest_sweep_threads': best_n,
+        # measured at that thread count (one run of the same sample; None when the defined setting is the fastest)
+        'value_measured_at_fastest_threads': (B * T_FRAMES / fast[0]) if fast else None,
+        'seconds_per_pass_measured_at_fastest_threads': round(fast[0], 2) if fast else None,
     }
     return base, parity
 
@@ -298,8 +312,10 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None, clock=None):
         # split-fp16 stack launch (diffnet_h2.hip): every fp32 product as 3 fp16 MFMA products (hi hi, hi lo, lo hi), fp32 accumulate, so
         # the matrix pipe in use is the 16-bit one.  One launch = all 20 layers of up to 256 64-frame tiles; avg_ms = one layer over all rows
         executed = 3.0 * achieved
-        return dict(common, kernel='residual_stack_h2_kernel (20 fused DiffNet residual blocks + the step tail per launch; fp32 operands split exactly into hi + lo '
-                                   'fp16 terms, 3 fp16 MFMAs per fp32 product, fp32 accumulate; x and the skip sum on chip; figures per layer)',
+        kname = 'residual_stack_q_kernel' if (path or '').startswith('stack_h2q') else 'residual_stack_h2_kernel'
+        shape = 'v_mfma_f32_16x16x32_f16' if kname == 'residual_stack_q_kernel' else 'v_mfma_f32_32x32x16_f16'
+        return dict(common, kernel=f'{kname} (20 fused DiffNet residual blocks + the step tail per launch; fp32 operands split exactly into hi + lo '
+                                   f'fp16 terms, 3 fp16 MFMAs ({shape}) per fp32 product, fp32 accumulate; x and the skip sum on chip; figures per layer)',
                     frac_executed_at_sustained_clock=(executed / (PEAK_BF16_MFMA_TFLOPS * clock[0] / 2400.0)) if clock and clock[0] else None,
                     bound='mfma', achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_BF16_MFMA_TFLOPS,
                     executed_tflops=executed, frac_executed=executed / PEAK_BF16_MFMA_TFLOPS,
@@ -556,13 +572,22 @@ def secondary_e2e(model, device, fence):
             'higher_is_better': False, 'steps': n, 'warmup': 1, 'ms_per_step': dt * 1e3, 'audio_seconds': audio_s,
             'vocoder_ms': dv * 1e3, 'vocoder_rtf': dv / audio_s, 'finite': bool(torch.isfinite(wav).all()),
             'handoff_timeouts': model.denoise_fn.handoff_timeouts(),
-            'roofline': {'kernel': 'HiFi-GAN generator forward (all launches of one vocoder call)', 'bound': 'mfma', 'achieved': voc_tf,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': voc_tf / PEAK_F32_MFMA_TFLOPS, 'traffic': voc_traffic,
+            # HBM-bound by SURVEY §8(d) (channels <= 128, ~10 FLOP/B): `achieved` = HBM-side bytes the forward really moves (PMC) / its wall
+            # time; with no PMC summary of this build, the algorithmic bytes (mel in + wav out) — then `frac` says how far the launch chain
+            # is from streaming its input and output once.  The matrix work is priced against the pipe it runs on (16-bit: split-fp16 pairs)
+            'roofline': (lambda by_: {'kernel': 'HiFi-GAN generator forward (all launches of one vocoder call)', 'bound': 'hbm',
+                         'achieved': by_ / dv / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': by_ / dv / 1e9 / PEAK_HBM_GBS,
+                         'bytes_priced': 'HBM-side bytes of one forward (PMC)' if voc_traffic else 'algorithmic bytes (no PMC summary of this shape)',
+                         'traffic': voc_traffic, 'algorithmic_bytes_per_forward': N_MEL * T_FRAMES * 4 + T_FRAMES * hop * 4,
+                         'traffic_over_algorithmic': voc_traffic / (N_MEL * T_FRAMES * 4 + T_FRAMES * hop * 4) if voc_traffic else None,
                          'traffic_build_matches': bool(voc_traffic_build) and voc_traffic_build == build_digest(),
                          'traffic_condition': 'PMC passes of tools/prof_vocoder.py at B=1, T=1000 (profiles/traffic_voc.json): 2 x FETCH_SIZE + WRITE_SIZE '
                                               'summed over the launches of one forward; algorithmic bytes: mel in 0.32 MB + wav out 1.02 MB',
-                         'hbm_gbs': voc_traffic / dv / 1e9 if voc_traffic else None,
-                         'note': '38.51 MFLOP per mel frame (SURVEY §8d) / vocoder wall time; fp32 (vector = matrix peak)'}}
+                         'mfma_tflops_algorithmic': voc_tf, 'mfma_frac_of_pipe_in_use': voc_tf / PEAK_BF16_MFMA_TFLOPS,
+                         'mfma_frac_executed_of_pipe_in_use': 3.0 * voc_tf / PEAK_BF16_MFMA_TFLOPS,
+                         'note': '38.51 MFLOP per mel frame (SURVEY §8d) / vocoder wall time for the matrix figures: the 32/64/16-channel ResBlock pairs run as '
+                                 'split-fp16 products (3 fp16 MFMAs per fp32 product) on the 16-bit pipe, so that pipe\'s dense peak is the price; the 8-channel '
+                                 'stage and conv_post run on the vector pipe'})(voc_traffic or (N_MEL * T_FRAMES * 4 + T_FRAMES * hop * 4))}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -748,6 +773,12 @@ def main():
                                 'cfg3_rank': secondary_cfg3_rank(model, device, fence),
                                 'captured_sampler': secondary_captured(model, device, fence),
                                 'f32_matrix_pipe': secondary_fp32_pipe(args.steps, args.warmup)}
+            c3 = rec['secondary'].get('cfg3_rank') or {}
+            if c3.get('value_b64_one_gpu'):
+                # the base of a 1 -> 8 STRONG-scaling ratio: the N > 1 runs shard B = 64 utterances (configs[3]); this line's own `value` is
+                # configs[1] (B = 16) and must not be divided into them
+                rec['strong_denominator'] = {'B': B_CFG3_TOTAL, 'value': c3['value_b64_one_gpu'], 'ms_per_step': c3['ms_per_step_b64_one_gpu'],
+                                             'unit': 'mel-frames/s', 'note': 'configs[3] on ONE GPU: all 64 utterances, same pass as the N > 1 runs'}
         if world == 1 and args.cpu_steps > 0:
             base, parity = cpu_baseline_and_parity(model, wl.inp_np, device, args.cpu_steps)
             rec['cpu_baseline'] = base
@@ -755,7 +786,9 @@ def main():
             rec['gpu_over_cpu'] = value / base['value']
             # the same ratio against the CPU's FASTEST thread setting of the sweep (SURVEY §8d defines the baseline at one socket's
             # physical cores, where PyTorch-CPU is not at its best on a many-core host): quote this one
-            if base.get('value_at_fastest_sweep_setting'):
+            if base.get('value_measured_at_fastest_threads'):
+                rec['gpu_over_cpu_at_fastest_cpu_setting'] = value / base['value_measured_at_fastest_threads']      # both legs measured
+            elif base.get('value_at_fastest_sweep_setting'):
                 rec['gpu_over_cpu_at_fastest_cpu_setting'] = value / base['value_at_fastest_sweep_setting']
             if not parity['ok']:
                 print(f'bench.py: PARITY FAILED {json.dumps(parity)}', file=sys.stderr)

@@ -221,6 +221,13 @@ class _DeferredWord:
         self.pending.append((self.cur, ev))
         self.cur = None
 
+    def drop_pending(self):
+        """Forget the reads still in flight (their counts repeat what a blocking take has just reset).  Their pinned buffers are NOT handed
+        back to torch's allocator while a copy may still land in them (only the current stream was waited for): they are parked until their
+        event has passed."""
+        self.parked = [(b, e) for b, e in getattr(self, 'parked', []) + self.pending if not e.query()]
+        self.pending = []
+
     def take(self, block=False):
         out = []
         while self.pending:
@@ -261,7 +268,7 @@ def check_deferred(device=None, block=False):
         n = sum(w[0] for w in rec.take(block))
         if n:
             gemm_range_take(device)      # waits for the stream and resets the counter;
-            rec.pending.clear()          # reads enqueued before this point repeat the same (cumulative) count
+            rec.drop_pending()           # reads enqueued before this point repeat the same (cumulative) count
             with on_device(device):
                 check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
             _range_strikes += 1
@@ -311,10 +318,14 @@ def range_guarded(run, what, on_retry=None, device=None):
             check_deferred(device)
             restore = _restore_split_after
             _restore_split_after = False
-            out = run()
-            if restore:
-                with on_device(device):
-                    check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
+            try:
+                out = run()
+            finally:
+                # also when run() raises (a nested handle's check_deferred, say): the switch back to the split-fp16 GEMMs was consumed above and
+                # would otherwise be lost — every GEMM of the process on the fp32 matrix pipe for good, silently
+                if restore:
+                    with on_device(device):
+                        check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
             _deferred_enqueue(device)
             return out
         out = run()

@@ -1375,6 +1375,7 @@ struct ConvW {
 struct bsg_hifigan {
   bsg_hifigan_cfg cfg;
   std::vector<float*> owned;
+  std::vector<float*> create_tmp;   // reorder temporaries of the weight packing: freed behind create's stream synchronize
   ConvW pre, post;
   std::vector<ConvW> ups;                 // weight [Cin][Cout][K]
   std::vector<ConvW> rb1, rb2;            // [n_ups * n_kernels * n_dil]
@@ -1403,6 +1404,7 @@ extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
   if (h->planes) (void)hipFree(h->planes);
   h2w_free(&h->pre.h2w);
   for (ConvW& c : h->ups) h2w_free(&c.h2w);
+  for (float* t : h->create_tmp) (void)hipFree(t);
   delete h;
 }
 
@@ -1482,7 +1484,8 @@ static int pack_up_h2w(bsg_hifigan* h, ConvW& c, int u, hipStream_t st) {
   if (u != 8 || c.k != 16 || c.cin % 64 || (c.cout * u) % 128) return BSG_OK;
   float* tmp = nullptr;
   const int n = 2 * c.cout * u * c.cin;
-  TRY(hg_alloc(h, &tmp, n));
+  BSG_HIP(hipMalloc((void**)&tmp, (size_t)n * sizeof(float)));
+  h->create_tmp.push_back(tmp);   // (2-8 MB each; they used to stay until the handle was destroyed)
   hipLaunchKernelGGL(up_h2w_reorder_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, tmp, c.cin, c.cout, u);
   BSG_LAUNCH_CHECK();
   TRY(h2w_pack(&c.h2w, tmp, c.cout * u, c.cin, 2, (long long)c.cout * u * c.cin, c.cin, 1, h->w_range_bad, st));
@@ -1495,7 +1498,8 @@ static int pack_pre_h2w(bsg_hifigan* h, ConvW& c, hipStream_t st) {
   if (c.cout % 128 || c.k > 17) return BSG_OK;
   float* tmp = nullptr;
   const int n = c.k * c.cout * kp;
-  TRY(hg_alloc(h, &tmp, n));
+  BSG_HIP(hipMalloc((void**)&tmp, (size_t)n * sizeof(float)));
+  h->create_tmp.push_back(tmp);
   hipLaunchKernelGGL(conv_h2w_reorder_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const float*)c.w, tmp, c.cin, kp, c.cout, c.k);
   BSG_LAUNCH_CHECK();
   TRY(h2w_pack(&c.h2w, tmp, c.cout, kp, c.k, (long long)c.cout * kp, kp, 1, h->w_range_bad, st));
@@ -1627,6 +1631,8 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   if ((rc = take_conv(h, h->post, w, 1, h->post.cin * 7, st)) != BSG_OK) return fail(rc);
   if ((rc = pack_conv(h, h->post, st)) != BSG_OK) return fail(rc);
   if (hipStreamSynchronize(st) != hipSuccess) { set_error("hifigan_create: stream sync failed"); return fail(BSG_EHIP); }
+  for (float* t : h->create_tmp) (void)hipFree(t);
+  h->create_tmp.clear();
   {
     unsigned nbad = 0;
     if (hipMemcpy(&nbad, h->w_range_bad, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hifigan_create: copy failed"); return fail(BSG_EHIP); }
@@ -1671,7 +1677,9 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
   const float slope = 0.1f;   // LRELU_SLOPE, hifigan.py:11
   static int h2w_env = -1;   // BSG_HG_H2W=0: conv_pre and the u = 8 transposed convolutions on the vector pipe (conv1d_kernel / upsample_kernel)
   if (h2w_env < 0) { const char* e = getenv("BSG_HG_H2W"); h2w_env = e ? atoi(e) : 1; }
-  const bool h2w_on = h2w_env && h->h2_ok && gemm_split_enabled();
+  static int hg_split_env = -1;   // BSG_HG_SPLIT=0 (the fp32-MFMA / vector forms of the ResBlock pairs) takes these two off the 16-bit pipe as well: the switch
+  if (hg_split_env < 0) { const char* e = getenv("BSG_HG_SPLIT"); hg_split_env = e ? atoi(e) : 1; }   // means the WHOLE vocoder on fp32 products
+  const bool h2w_on = h2w_env && hg_split_env && h->h2_ok && gemm_split_enabled();
   if (h2w_on && h->pre.h2w.ok && h2w_supports(T, h->pre.cout, h->pre.h2w_kp, h->pre.k, h->pre.h2w_kp)) {
     // conv_pre :150 as a 7-tap product of the mel planes [T][n_mel padded to 128] with the pre-split weights; output [C0][T]
     const ConvW& p = h->pre;

@@ -370,7 +370,7 @@ class DiffNet(nn.Module):
                         self.parts_disabled, self._clean_calls_parts = False, 0
             return
         self.take_health()      # waits for the stream and resets the words;
-        rec.pending.clear()     # reads enqueued before this point repeat the same (cumulative) counts: dropped — repeat everything issued since the last clean check
+        rec.drop_pending()      # reads enqueued before this point repeat the same (cumulative) counts: dropped — repeat everything issued since the last clean check
         what = []
         if rng:
             _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')

@@ -83,7 +83,11 @@ def test_bf16_does_not_change_fp32_results(net):
 
 
 def test_sampler_bf16_deviation():
-    """full 100-step DDPM run, same supplied noise: bf16-operand mel vs fp32 mel (normalised units, range [-1, 1])"""
+    """full 100-step DDPM run, same supplied noise: bf16-operand mel vs fp32 mel (normalised units, range [-1, 1]).
+    A SELF-COMPARISON: both trajectories come from this library's HIP kernels (the fp32 one is pinned to the oracle elsewhere:
+    tests/test_gpu_configs.py); what pins the bf16 arithmetic to an independent restatement is ONE evaluation against the emulating oracle
+    (tests/test_gpu_configs.py::test_config2_bf16_full_size_vs_emulating_oracle) and the step tail on small shapes — not this trajectory.
+    configs[2] is a throughput configuration."""
     use_config()
     from bisinger_amd.diffnet import DiffNet
     from bisinger_amd.diffusion import GaussianDiffusion

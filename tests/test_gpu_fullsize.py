@@ -134,7 +134,9 @@ def test_full_size_shard_invariance_and_seed(model):
 
 
 def test_bf16_config_full_size():
-    """BASELINE configs[2] shape (B=64, T=1000): finite, deterministic, and close to the fp32 configuration"""
+    """BASELINE configs[2] shape (B=64, T=1000): finite, deterministic, and close to the fp32 configuration — a SELF-COMPARISON (HIP bf16 path
+    against the HIP fp32 path); the independent check of the bf16 arithmetic at this size is one DiffNet evaluation against the emulating
+    oracle, tests/test_gpu_configs.py::test_config2_bf16_full_size_vs_emulating_oracle"""
     use_config()
     from bisinger_amd.diffnet import DiffNet
     net = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()

@@ -113,7 +113,9 @@ for cfg in ('f32', 'bf16', 'voc', 'voc1', 'rank', 'b1'):
     if cfg == 'voc1':
         # HBM-side bytes of ONE vocoder forward at B = 1, T = 1000: sum over the kernels of (mean bytes per launch x launches) / forwards
         # (tools/prof_vocoder.py runs PN = 5 forwards per pass) -> profiles/traffic_voc.json, read by bench.py's configs[4] roofline
-        fw = 5
+        # forwards = launches of a once-per-forward kernel (conv_post: the warm-up forwards of prof_vocoder.py are profiled too, and PN may change)
+        once = [k for k in out if 'conv_post_kernel' in k]
+        fw = min((out[k]['FETCH_SIZE']['n'] for k in once), default=0) or int(os.environ.get('PN', 5))
         tot = sum(e['hbm_bytes_per_launch'] * out[k]['FETCH_SIZE']['n'] for k, e in per_kernel.items() if 'hbm_bytes_per_launch' in e and k in out)
         json.dump({'B': 1, 'T': 1000, 'forwards': fw, 'hbm_bytes_per_forward': tot / fw, 'build_sha256': BUILD,
                    'algorithmic_bytes_per_forward': 80 * 1000 * 4 + 256000 * 4,
