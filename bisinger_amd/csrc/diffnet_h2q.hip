@@ -45,9 +45,9 @@ __device__ __forceinline__ int kmapq(int i) {
 // MFMAs — lo hi, hi hi, hi lo for each of the 4 row tiles; an accumulator is revisited every 4th MFMA — on the k-step's 8 weight fragments
 // A[s][2 rt] = hi, A[s][2 rt + 1] = lo and the tile's two operand fragments; the fragments of the column tile after the next are read from LDS
 // inside the first MFMA group.  The ring slot is refilled during the LAST column tile of its k-step (lo fragments behind the first group, hi fragments
-// behind the last), two k-steps = 96 MFMAs ahead.  `mid()` runs after the first ROT k-steps have been issued (ROT = 0: never): the hand-off
+// behind the last), two k-steps = 96 MFMAs ahead.  `mid()` runs after the first MIDK k-steps have been issued (MIDK = 0: never): GEMM1's hand-off
 // with the neighbours sits there, under the centre tap's MFMAs.  FAIRB: the two waves of a SIMD take turns at issue priority.
-template <int ROT, int NEXT_ROT, bool FAIRB, int NQ, int DIAG, typename LDB, typename MID, typename STAMP>
+template <int ROT, int NEXT_ROT, int MIDK, bool FAIRB, int NQ, int DIAG, typename LDB, typename MID, typename STAMP>
 __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8], rsrc_t rs, rsrc_t rs_next, int vfrag, const int (&sa)[4], int n_ks, LDB ldb,
                                             MID mid, int half, bool diag_l1, STAMP stamp) {
   static_assert(NQ == 2 || NQ == 4, "four operand buffers, indexed by the item's position in a pass of two k-steps");
@@ -66,7 +66,7 @@ __device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8]
       if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
     }
-    if (ROT > 0 && ks == ROT) {
+    if (MIDK > 0 && ks == MIDK) {
       mid();
       ldb(kmapq<ROT>(ks), 0, B[0]);   // the B operands of the next two column tiles were read before the halo rows arrived: read them again
       ldb(kmapq<ROT>(ks), 1, B[1]);
@@ -147,16 +147,16 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   const unsigned plane = (unsigned)C * T * 4;
   const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
   const int rowT = T * 4, vfrag = lane * 16;
-  int vcol[NQ], vst[NQ], vquad[NQ];
-  bool col_ok[NQ];
-#pragma unroll
-  for (int ct = 0; ct < NQ; ++ct) {
-    const int col = t0 + n16 + fo(ct);
-    col_ok[ct] = col < T;
-    vcol[ct] = (q4 * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;
-    vst[ct] = (q4 * 4 * T + col) * 4;
-    vquad[ct] = (q4 * T + (col_ok[ct] ? col : T - 1)) * 16;   // channel-quad order: quad q4 of the wave's row tile, frame col
-  }
+  // global addressing: ONE per-lane byte offset per layout; column tile ct adds a constant (16 frames) that the compiler folds into the
+  // instruction's immediate offset.  Frames beyond T are NOT clamped (a clamp made the offsets of the four column tiles four live registers,
+  // three times over): such a lane reads the next row's first elements, or 0 behind the buffer — finite either way — and its image rows
+  // are written as zeros (write_core), its results never stored
+  const int col0 = t0 + n16;
+  const int vbase = (q4 * 4 * T + col0) * 4;       // fp32 [rows][T]: row q4 * 4 (+ the uniform row offset), frame col0
+  const int vqbase = (q4 * T + col0) * 16;         // channel-quad order [rows / 4][T][4]: quad q4, frame col0
+  auto col_ok = [&](int ct) { return col0 + 16 * ct < T; };
+  auto vcol = [&](int ct) { return vbase + 64 * ct; };
+  auto vquad = [&](int ct) { return vqbase + 256 * ct; };
   // row tiles (of 16) inside a plane of a k-step slab: gate / residual rows 2w, 2w + 1; filter / skip rows 16 + 2w, 17 + 2w
   const int sa[4] = {(2 * wave) * 1024, (2 * wave + 1) * 1024, (16 + 2 * wave) * 1024, (17 + 2 * wave) * 1024};
   const int cw = 32 * wave + 4 * q4;   // the lane's first channel; + 16 rt + i
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         const int so = (8 * wave + 4 * rt) * T * 16;
 #pragma unroll
         for (int ct = 0; ct < NQ; ++ct) {
-          y[rt][ct] = ldf4(rs_cq, vquad[ct], so);
-          y[2 + rt][ct] = ldf4(rs_cq, vquad[ct], so + (C / 4) * T * 16);
+          y[rt][ct] = ldf4(rs_cq, vquad(ct), so);
+          y[2 + rt][ct] = ldf4(rs_cq, vquad(ct), so + (C / 4) * T * 16);
         }
       }
       return;
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         const int so = (32 * wave + 16 * rt + i) * rowT;
 #pragma unroll
         for (int ct = 0; ct < NQ; ++ct) {
-          y[rt][ct][i] = ldf(rs_ct, vcol[ct], so);
-          y[2 + rt][ct][i] = ldf(rs_ct, vcol[ct], so + C * rowT);
+          y[rt][ct][i] = ldf(rs_ct, vcol(ct), so);
+          y[2 + rt][ct][i] = ldf(rs_ct, vcol(ct), so + C * rowT);
         }
       }
   };
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         const HiLo s0 = split2(v0, v1);
         const HiLo s1_ = split2(v2, v3);
         u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
-        if (!col_ok[ct]) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+        if (!col_ok(ct)) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
         char* dst = xs + (HALO + n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
         *reinterpret_cast<u32x2*>(dst) = wh;
         *reinterpret_cast<u32x2*>(dst + XP) = wl;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xr[ct][rt][i] = ldf(rs_x, vcol[ct], (32 * wave + 16 * rt + i) * rowT);
+        xr[ct][rt][i] = ldf(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT);
         sk[ct][rt][i] = 0.f;
       }
   {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         __syncthreads();   // (A) halo rows in place
         if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(2);
       };
-      mfma_pipe_q<8, 0, FAIRB, NQ, DIAG>(y, A, rs_a1, rs_a2, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); });
+      mfma_pipe_q<8, 0, 8, FAIRB, NQ, DIAG>(y, A, rs_a1, rs_a2, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); });
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -397,7 +397,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     __syncthreads();   // (B) zs complete; every wave is done reading xs and this layer's biases
     btab[tid] = bnext;
     STK_STAMP(4);
-    // ---- GEMM2: 8 k-steps of 32; y[0..1] = residual rows, y[2..3] = skip rows ----------------------------------------------
+    // ---- GEMM2: 8 k-steps of 32; y[0..1] = residual rows, y[2..3] = skip rows.  (Measured and not kept, profiles/r05_q_not_kept.txt: waves
+    // 0..3 — the older wave of each SIMD pair, which finish GEMM1 thousands of cycles before their partners — running GEMM2's k-steps over
+    // their own z before barrier (B), under the partners' gate: the partners' gate then takes 6.6k cycles instead of 3.3-4.3k, because the
+    // matrix instructions of the older wave win the vector issue; 164.4 k against 166.8 k mel-frames/s) ----------------------------------
     {
       const char* zb = zs + n16 * ROWB + q4 * 16;
       auto ldb = [&](int ks, int ct, f16x8 (&Bf)[2]) {
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         Bf[0] = *reinterpret_cast<const f16x8*>(q);
         Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
       };
-      mfma_pipe_q<0, 8, FAIRB, NQ, DIAG>(y, A, rs_a2, rs_a1n, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); });
+      mfma_pipe_q<0, 8, 0, FAIRB, NQ, DIAG>(y, A, rs_a2, rs_a1n, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); });
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (DIAG == 3) STK_STAMP(12);
@@ -464,11 +467,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     const float rdiv = 1.0f / sqrtf((float)L);
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
-      if (col_ok[ct]) {
+      if (col_ok(ct)) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) stf(sk[ct][rt][i] * rdiv, rs_sk, vst[ct], (32 * wave + 16 * rt + i) * rowT);
+          for (int i = 0; i < 4; ++i) stf(sk[ct][rt][i] * rdiv, rs_sk, vcol(ct), (32 * wave + 16 * rt + i) * rowT);
       }
   } else {
     // ================= fused step tail: s = skip sum / sqrt(L) -> hi / lo image rows (the conv image is dead: every wave is behind barrier
