@@ -462,6 +462,20 @@ struct SplitArgs {
   int inject;             // fault injection (bsg_diffnet_debug_inject_giveup): consumers give up at once, without waiting
 };
 
+// dconv[((s*L + l)*4 + v)*2C + row] = sum_ci w[row][ci][tap] * dproj[s][l][ci] for tap = v < 3, all three taps for v = 3 (fp64 accumulation):
+// the share of the step term d (constant over the frames) in dilated_conv_l(x + d), which the 16-row stack launch adds to the conditioner
+// term instead of adding d to every frame of its conv image (net.py:67,72-74)
+__global__ void dconv_kernel(const float* __restrict__ w, const float* __restrict__ dproj, float* __restrict__ out, int S, int L, int l) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * 4 * 2 * C) return;
+  const int row = i % (2 * C), v = (i / (2 * C)) % 4, s = i / (4 * 2 * C);
+  const float* d = dproj + ((long long)s * L + l) * C;
+  double acc = 0.0;
+  for (int tap = (v < 3 ? v : 0); tap < (v < 3 ? v + 1 : 3); ++tap)
+    for (int ci = 0; ci < C; ++ci) acc += (double)w[((long long)row * C + ci) * 3 + tap] * (double)d[ci];
+  out[(((long long)s * L + l) * 4 + v) * (2 * C) + row] = (float)acc;
+}
+
 // out[((mt*(K/16) + q)*64 + lane)*4 + jj] = W(m = 16*mt + (lane&15), k = 16*q + 4*jj + (lane>>4)),  W row-major [M][K]
 __global__ void pack_a16_kernel(const float* __restrict__ w, float* __restrict__ out, int M, int K) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1046,6 +1060,7 @@ struct bsg_diffnet {
   float* w_fin = nullptr;   // [M][C]
   float* b_fin = nullptr;
   float* dproj = nullptr;   // [S][L][C]
+  float* dconv = nullptr;   // [S][L][4][2C]: dilated_conv_l's taps applied to dproj[s][l] (tap 0, 1, 2, their sum): diffnet_h2q.hip
   // fused step tail/head (DDPM loop): packed skip / output / input projections
   float* ws_pack = nullptr;  // [C*C]
   float* wo_pack = nullptr;  // [96*C]
@@ -1129,7 +1144,7 @@ static void dev_free(float*& p) {
 extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (!h) return;
   float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->apackw, &h->apackw43, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
-                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->apack2w, &h->zbuf, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
+                   &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->dconv, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->apack2w, &h->zbuf, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
   for (float** p : all) dev_free(*p);
   for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -1219,6 +1234,7 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
   TRY(dev_alloc(&h->w_fin, (size_t)M * C));
   TRY(dev_alloc(&h->b_fin, M));
   TRY(dev_alloc(&h->dproj, (size_t)S * L * C));
+  TRY(dev_alloc(&h->dconv, (size_t)S * L * 4 * 2 * C));
   TRY(copy_dev(h->w_in, w[0], (size_t)C * M, st));
   TRY(copy_dev(h->b_in, w[1], C, st));
   // step-embedding MLP over the whole table: D = W2 * mish(W1 * e + b1) + b2        (net.py:92-96,120)
@@ -1265,6 +1281,10 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
     if (rc == BSG_OK) rc = copy_dev(h->b_out + (size_t)l * 2 * C, lw[7], 2 * C, st);
     // diffusion_projection of the tabulated step embedding -> dproj[s][l][:]            (net.py:67)
     if (rc == BSG_OK) rc = gemm_nt(dtab, (const float*)lw[2], h->dproj + (size_t)l * C, (const float*)lw[3], S, C, C, C, L * C, ACT_NONE, st);
+    if (rc == BSG_OK) {
+      hipLaunchKernelGGL(dconv_kernel, dim3(cdiv(S * 4 * 2 * C, 256)), dim3(256), 0, st, (const float*)lw[0], (const float*)h->dproj, h->dconv, S, L, l);
+      if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: dconv kernel failed"); rc = BSG_EHIP; }
+    }
   }
   const void* const* tw = w + 6 + 8 * L;
   if (rc == BSG_OK) rc = copy_dev(h->w_skip, tw[0], (size_t)C * C, st);
@@ -1759,7 +1779,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     p.x_in = h->xa + row * C * T;
     p.skip = h->skip + row * C * T;
     p.condterm = h->condterm + row * 2 * C * T;
-    p.dproj = h->dproj; p.t_dev = t_dev ? t_dev + r0 : nullptr; p.t_uniform = t_uniform;
+    p.dproj = h->dproj; p.dconv = h->dconv; p.t_dev = t_dev ? t_dev + r0 : nullptr; p.t_uniform = t_uniform;
     p.apackw = h->apackw; p.apack2 = h->apack2; p.bias_out = h->b_out;
     p.T = T; p.L = h->L; p.tiles_per_row = tpr;
     p.ct_stride = (long long)2 * C * (long long)bt;

@@ -31,6 +31,10 @@ namespace {
 constexpr int QPLB = 32 * 1024;            // bytes per plane of a k-step slab: 32 row tiles of 16 x 1 KB
 constexpr int QKSB = 2 * QPLB;             // bytes per k-step (32 deep): hi slab, lo slab
 using f32x4q = __attribute__((ext_vector_type(4))) float;
+// the conv image holds x x 2^4 (x alone, not x + d: see the kernel): with x of order 1 unscaled, most lo terms were subnormal fp16 (an ABSOLUTE
+// error of 2^-25 each — harmless as a GEMM operand, but the residual path takes x back from these planes: eps rms error 4.4e-7 against float64
+// instead of 7.5e-8, tests/test_gpu_h2.py); x 16 keeps lo normal down to |x| = 0.03 and the range guard at |x| < 3750
+constexpr float XSCALE = 16.0f, XINV = 1.0f / 16.0f;
 #define BSG_MFMA_Q(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACC, 0, 0, 0)
 
 // i-th executed k-step -> k-step index: GEMM1 (ROT = 8: 24 k-steps of 32, tap-major) starts with the CENTRE tap, whose B operand is the tile's
@@ -127,8 +131,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* xs = lds_raw;                  // [2 planes][NT + 16 frames][528 B]: hi / lo of x + d_l, frames t0-8 .. t0+NT+7
   char* zs = lds_raw + 2 * XP;         // [2 planes][NT frames][528 B]: hi / lo of 2^10 x gated activation
-  float* dtab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [256]: d_{l+1} per channel, fetched a layer ahead
-  float* btab = dtab + C;                                              // [512]: output-projection bias of the current layer
+  float* btab = reinterpret_cast<float*>(lds_raw + 2 * XP + 2 * ZP);   // [512]: output-projection bias of the current layer
 
   const int n_tiles = p.n_tiles, per_xcd = (n_tiles + 7) >> 3;
   const int tile_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -161,7 +164,14 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   const int sa[4] = {(2 * wave) * 1024, (2 * wave + 1) * 1024, (16 + 2 * wave) * 1024, (17 + 2 * wave) * 1024};
   const int cw = 32 * wave + 4 * q4;   // the lane's first channel; + 16 rt + i
 
-  float xr[NQ][2][4];     // x: element (ct, rt, i) = channel cw + 16 rt + i of frame 16 ct + n16
+  // x is NOT kept in registers through a layer (round 5): 32 registers that were live through both GEMM loops of a kernel that spilled 30-40
+  // registers per layer into the memory pipeline its weight stream needs.  The residual path takes x back from the conv image in LDS — and
+  // so that this costs no accuracy the image is the hi / lo split of x ITSELF, not of x + d_l (hi + lo = x to one ulp, mostly exactly): the
+  // diffusion-step term d_l is constant over the frames, so its share of the dilated conv is a vector per (step, layer, tap), D_tap = W_tap d_l,
+  // tabulated at create (StackArgs::dconv, fp64 accumulation) and added where the accumulators are initialised: y = (cond + D_0 [f >= dil] + D_1 +
+  // D_2 [f + dil < T]) s1 — a tap that falls on the reference's zero padding of x + d (net.py:72-74) contributes nothing.  (The first
+  // version took x = hi + lo - d from the image of x + d: correct to an ulp of x + d, which is not an ulp of x when |d| >> |x| —
+  // tests/test_gpu_h2.py 'big_act', rms error 6.5e-6 against 1.3-1.8e-6 for the fp32-pipe forms; now 0.6e-6.)
   float sk[NQ][2][4];     // running skip sum (fp32), same layout
   f32x4q y[4][NQ];        // accumulators: y[rt] gate / residual rows, y[2 + rt] filter / skip rows; GEMM1's start from the conditioner term x s1
   int range_flag = 0;     // see residual_stack_h2_kernel: a split value beyond 60000 (or not finite) raises the launch's status word 1
@@ -202,18 +212,60 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         }
       }
   };
-  // image core (frames t0 .. t0+NT-1, this wave's 32 channels) = hi / lo of x + d_l, zero beyond T (the conv pads x + d)
-  auto write_core = [&]() {   // d of the layer being prepared is in dtab (written a phase earlier, behind a barrier)
-    f32x4 dv[2];
-    unsigned worst = 0;
+  // the diffusion-step term's share of the dilated conv, rows of this lane (gate: cw + 16 rt + i, filter: C + ..): dA = D_0 + D_1 + D_2 for every
+  // frame, requested with the conditioner term.  On the first / last tile of a row the frames within a dilation of the sequence's start / end
+  // lack a tap (the reference pads x + d with zeros): its D_0 / D_2 is taken out again where the accumulators are initialised, fetched THERE —
+  // one exposed L2 round trip per layer on two tiles of a row; requested early like dA, its 16 registers were live on every tile from the
+  // image phase to the next layer's top and put 30 spilled registers back into the layer loop (164.5 k against 175.8 k mel-frames/s)
+  const bool first_tile = !has_left, last_tile = t0 + NT + HALO > T;   // (a tile whose right neighbour holds fewer frames than a dilation lacks right taps too)
+  f32x4 dA[4];   // [2 half + rt]
+  auto dconv_request = [&](int l) {
+    const rsrc_t rs_d = mk_rsrc(p.dconv + ((long long)tb * L + l) * (4 * 2 * C), 4 * 2 * C * 4);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) dv[rt] = *reinterpret_cast<const f32x4*>(dtab + cw + 16 * rt);
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) dA[2 * h + rt] = ldf4(rs_d, cw * 4, (3 * 2 * C + h * C + 16 * rt) * 4);
+  };
+  // y = (cond + D) x s1 on arrival of the requested terms (their first use)
+  auto acc_init = [&](int l, float s1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 ds = dA[k] * s1;
+#pragma unroll
+      for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[k][ct][i] = __builtin_fmaf(y[k][ct][i], s1, ds[i]);
+    }
+    if (first_tile || last_tile) {   // (uniform)
+      const int dil = 1 << (l % p.cycle);
+      const rsrc_t rs_d = mk_rsrc(p.dconv + ((long long)tb * L + l) * (4 * 2 * C), 4 * 2 * C * 4);
+#pragma unroll 1
+      for (int side = 0; side < 2; ++side) {   // 0: the left end (tap 0), 1: the right end (tap 2); a row of one tile has both
+        if (side == 0 ? !first_tile : !last_tile) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            const f32x4 de = ldf4(rs_d, cw * 4, ((side ? 2 : 0) * 2 * C + h * C + 16 * rt) * 4);
+#pragma unroll
+            for (int ct = 0; ct < NQ; ++ct) {
+              const int f = col0 + 16 * ct;
+              const float m = (side == 0 ? f < dil : f + dil >= T) ? -s1 : 0.f;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) y[2 * h + rt][ct][i] = __builtin_fmaf(m, de[i], y[2 * h + rt][ct][i]);
+            }
+          }
+      }
+    }
+  };
+  // image core (frames t0 .. t0+NT-1, this wave's 32 channels) = hi / lo of x, zero beyond T (the conv pads with zeros)
+  auto write_core = [&](const float (&xr)[NQ][2][4]) {
+    unsigned worst = 0;
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const float v0 = xr[ct][rt][0] + dv[rt][0], v1 = xr[ct][rt][1] + dv[rt][1];
-        const float v2 = xr[ct][rt][2] + dv[rt][2], v3 = xr[ct][rt][3] + dv[rt][3];
+        const float v0 = xr[ct][rt][0] * XSCALE, v1 = xr[ct][rt][1] * XSCALE, v2 = xr[ct][rt][2] * XSCALE, v3 = xr[ct][rt][3] * XSCALE;
         worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
         const HiLo s0 = split2(v0, v1);
         const HiLo s1_ = split2(v2, v3);
@@ -227,24 +279,24 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   };
 
   // ---- layer 0: x from HBM (the whole input exists, halo included) ------------------------------------------------------
+  float x0[NQ][2][4];
 #pragma unroll
   for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        xr[ct][rt][i] = ldf(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT);
+        x0[ct][rt][i] = ldf(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT);
         sk[ct][rt][i] = 0.f;
       }
   {
-    const rsrc_t rs_dp = mk_rsrc(p.dproj + ((long long)tb * L + 0) * C, C * 4);
     const int hf = tid & 15, hc = tid >> 4;   // 16 halo frames x 32 chunks of 8 channels
     const int th = hf < 8 ? t0 - HALO + hf : t0 + NT - 8 + hf;
     const int hrow = hf < 8 ? hf : NT + hf;
     const bool hok = th >= 0 && th < T;
     float hv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) hv[k] = ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0) + ldf(rs_dp, (8 * hc + k) * 4, 0);
+    for (int k = 0; k < 8; ++k) hv[k] = XSCALE * ldf(rs_x, hok ? ((8 * hc + k) * T + th) * 4 : 0, 0);
     range_check(max(max(max(absbits(hv[0]), absbits(hv[1])), max(absbits(hv[2]), absbits(hv[3]))),
                     max(max(absbits(hv[4]), absbits(hv[5])), max(absbits(hv[6]), absbits(hv[7])))));
     const HiLo h0 = split2(hv[0], hv[1]), h1 = split2(hv[2], hv[3]), h2 = split2(hv[4], hv[5]), h3 = split2(hv[6], hv[7]);
@@ -253,11 +305,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     *reinterpret_cast<u32x4*>(xs + hrow * ROWB + hc * 16) = wh;
     *reinterpret_cast<u32x4*>(xs + XP + hrow * ROWB + hc * 16) = wl;
   }
-  if (tid < C) dtab[tid] = p.dproj[((long long)tb * L + 0) * C + tid];
   btab[tid] = p.bias_out[tid];
   cond_request(0);
+  dconv_request(0);
   __syncthreads();
-  write_core();
+  write_core(x0);
   // weight ring, shared by both GEMMs and running through them (mfma_pipe_q); layer 0's first two k-steps (GEMM1 starts with the centre
   // tap: kmapq) are requested here
   f16x8 A[2][8];
@@ -293,14 +345,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     const rsrc_t rs_a1 = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
     const rsrc_t rs_a2 = mk_rsrc(p.apack2q + (long long)l * (2 * 2 * C * C), 2 * 2 * C * C * 2);
     const rsrc_t rs_a1n = mk_rsrc(p.apack1q + (long long)(l + 1 < L ? l + 1 : 0) * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);   // the next layer's GEMM1
-    const float s1 = p.h2_scale[4 * l], inv1 = p.h2_scale[4 * l + 1], s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
-    const float dnext = (tid < C && l + 1 < L) ? p.dproj[((long long)tb * L + l + 1) * C + tid] : 0.f;   // lands during GEMM1
+    // GEMM1's accumulators carry weights x s1 and x x 2^4: s1 / inv1 below are the products (powers of two: exact)
+    const float s1 = p.h2_scale[4 * l] * XSCALE, inv1 = p.h2_scale[4 * l + 1] * XINV, s2 = p.h2_scale[4 * l + 2], inv2 = p.h2_scale[4 * l + 3];
     const float bnext = l + 1 < L ? p.bias_out[(long long)(l + 1) * (2 * C) + tid] : 0.f;
-    // GEMM1 accumulates (conditioner term + W x) x s1: the requested term is scaled on arrival (its first use)
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < NQ; ++ct) y[rt][ct] *= s1;
+    // GEMM1 accumulates (conditioner term + D + W x) x s1: the requested terms are combined and scaled on arrival (their first use)
+    acc_init(l, s1);
     if (l == 0) __syncthreads();   // layer 0: the staged image (core + halo rows); later layers: barrier (C) below covers the core rows
     STK_STAMP(0);
     // ---- GEMM1: 24 k-steps of 32.  The centre tap (8 k-steps) reads the tile's own frames only, so it runs while the neighbours' edges of
@@ -367,7 +416,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     }
     STK_STAMP(3);
     // ---- gate -> zs (hi / lo of 2^10 z); GEMM2's first weights are on their way since GEMM1's last two k-steps -------------------------
-    if (tid < C) dtab[tid] = dnext;   // read by write_core() behind barrier (B)
     const float rs2 = inv2 * 0.70710678118654752440f;
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
 #pragma unroll
@@ -382,17 +430,25 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         *reinterpret_cast<u32x2*>(dst + ZP) = u32x2{s0.lo, s1_.lo};
       }
     }
-    // residual rows start from (x + b_out) x s2', skip rows from b_out x s2' (the accumulators of GEMM1 are free now)
+    // residual rows start from (x + b_out) x s2', skip rows from b_out x s2' (the accumulators of GEMM1 are free now); x = hi + lo from the
+    // image rows this lane wrote (the sum is exact in fp32)
+    {
+      using h4 = __attribute__((ext_vector_type(4))) _Float16;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const f32x4 br = *reinterpret_cast<const f32x4*>(btab + cw + 16 * rt), bs = *reinterpret_cast<const f32x4*>(btab + C + cw + 16 * rt);
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 br = *reinterpret_cast<const f32x4*>(btab + cw + 16 * rt), bs = *reinterpret_cast<const f32x4*>(btab + C + cw + 16 * rt);
 #pragma unroll
-      for (int ct = 0; ct < NQ; ++ct)
+        for (int ct = 0; ct < NQ; ++ct) {
+          const char* src = xs + (HALO + n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
+          const h4 hv = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(src));
+          const h4 lv = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(src + XP));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          y[rt][ct][i] = (xr[ct][rt][i] + br[i]) * s2;
-          y[2 + rt][ct][i] = bs[i] * s2;
+          for (int i = 0; i < 4; ++i) {
+            y[rt][ct][i] = (((float)hv[i] + (float)lv[i]) * XINV + br[i]) * s2;
+            y[2 + rt][ct][i] = bs[i] * s2;
+          }
         }
+      }
     }
     __syncthreads();   // (B) zs complete; every wave is done reading xs and this layer's biases
     btab[tid] = bnext;
@@ -412,13 +468,14 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (DIAG == 3) STK_STAMP(12);
+    float xn[NQ][2][4];   // the new x: lives from here to write_core() only (in the registers the operand fragments occupy inside the GEMM loops)
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          xr[ct][rt][i] = y[rt][ct][i] * rs2;          // (x + residual) / sqrt(2), net.py:78: un-scaling and 1 / sqrt(2) in one factor
+          xn[ct][rt][i] = y[rt][ct][i] * rs2;          // (x + residual) / sqrt(2), net.py:78: un-scaling and 1 / sqrt(2) in one factor
           sk[ct][rt][i] += y[2 + rt][ct][i] * inv2;
         }
     STK_STAMP(5);
@@ -431,7 +488,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     // longer: a CU takes ~12k cycles for its 128 KB wherever they are requested, profiles/r05_q_not_kept.txt)
     cond_request(l + 1);
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(1);   // diagnostics: the image phase's inner boundaries instead of GEMM1's
-    write_core();
+    write_core(xn);
+    dconv_request(l + 1);   // (L2-resident: 8 KB per step and layer; lands with the conditioner term)
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(2);
     __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
     STK_STAMP(6);
@@ -557,7 +615,7 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
 
 // the arguments of launch_residual_stack_h2 (diffnet_h2.hip); p.apack1q / p.apack2q must hold the 16-row weight fragments
 int launch_residual_stack_h2q(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct) {
-  BSG_REQUIRE(p.apack1q && p.apack2q, "16-row stack launch: the 16-row weight fragments are missing");
+  BSG_REQUIRE(p.apack1q && p.apack2q && p.dconv, "16-row stack launch: the 16-row weight fragments / the step-term table are missing");
   return nct == 1 ? h2q_launch<1>(p, tail, st) : h2q_launch<2>(p, tail, st);
 }
 

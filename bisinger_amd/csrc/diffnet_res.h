@@ -41,6 +41,7 @@ struct StackArgs {
   const float* condterm;  // layer 0, this launch's rows: [B][2C][T]; + l * ct_stride for layer l
   const float* condterm_q; // 16-row stack launch: the same in channel-quad order [B][2C/4][T][4] (null: `condterm`); + l * ct_stride
   const float* dproj;     // [S][L][C]
+  const float* dconv;     // 16-row stack launch: [S][L][4][2C] = W_tap d for tap 0, 1, 2 and their sum (the step term's share of the dilated conv)
   const long long* t_dev; // [B] or null
   const float* apackw;    // layer 0; + l * aw_stride
   const float* apackw43;  // F(4,3) form (diffnet_f43.hip), layer 0; + l * 6*2C*C
