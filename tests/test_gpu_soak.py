@@ -50,7 +50,7 @@ for B, T in shapes:                                   # undisturbed references a
     refs[(B, T)] = (cond, x0, m.sample(cond, x0.clone(), seed=3).clone())
     torch.cuda.synchronize(); base[(B, T)] = time.time() - t0
 # what a HEALED handle costs (VERDICT r03 item 9e), measured while the chip is still quiet: a give-up is injected, the call that sees it
-# repeats itself without hand-offs (per-layer launches on the fp32 matrix pipe) and the handle stays there for CLEAN_CALLS_TO_REENABLE calls
+# repeats itself without hand-offs (per-layer launches on the fp32 matrix pipe; after a give-up inside a PART launch: on the one-workgroup-per-tile stack launch) and the handle stays there for CLEAN_CALLS_TO_REENABLE calls
 from bisinger_amd import _lib
 net = m.denoise_fn
 healed = {}
@@ -61,7 +61,7 @@ for (B, T), (cond, x0, ref) in refs.items():
         warnings.simplefilter('ignore')
         m.sample(cond, x0.clone(), seed=3)
     net.debug_inject_giveup(0)
-    assert getattr(net, 'split_disabled', False)
+    assert getattr(net, 'split_disabled', False) or getattr(net, 'parts_disabled', False)   # (a give-up inside a part launch takes only the part forms off: round 5)
     torch.cuda.synchronize(); t0 = time.time()
     got = m.sample(cond, x0.clone(), seed=3)
     torch.cuda.synchronize(); dt = time.time() - t0
@@ -69,7 +69,8 @@ for (B, T), (cond, x0, ref) in refs.items():
                        'healed_over_normal': round(dt / base[(B, T)], 2), 'healed_path': net.last_path(),
                        'healed_max_abs_vs_normal': float((got - ref).abs().max())}
     _lib.check(_lib.load().bsg_diffnet_set_split(net._h, 1), 'set_split')      # back to the hand-off launches for the soak below
-    net.split_disabled, net._clean_calls = False, 0
+    _lib.check(_lib.load().bsg_diffnet_set_parts(net._h, 1), 'set_parts')
+    net.split_disabled, net._clean_calls, net.parts_disabled = False, 0, False
 print('refs ready', flush=True)
 sys.stdin.readline()                                  # the parent starts the second process now
 out = {'runs': 0, 'exact': 0, 'close': 0, 'wrong': 0, 'warnings': 0, 'worst_dev': 0.0, 'slowdown': 0.0, 'healed_state': healed}
