@@ -48,84 +48,105 @@ __device__ __forceinline__ int kmapq(int i) {
 // k-step pipeline over 4 row tiles (c[0], c[1]: gate / residual; c[2], c[3]: filter / skip) x NQ column tiles of 16 frames.  Per column tile 12
 // MFMAs — lo hi, hi hi, hi lo for each of the 4 row tiles; an accumulator is revisited every 4th MFMA — on the k-step's 8 weight fragments
 // A[s][2 rt] = hi, A[s][2 rt + 1] = lo and the tile's two operand fragments; the fragments of the column tile after the next are read from LDS
-// inside the first MFMA group.  The ring slot is refilled during the LAST column tile of its k-step (lo fragments behind the first group, hi fragments
-// behind the last), two k-steps = 96 MFMAs ahead.  `mid()` runs after the first MIDK k-steps have been issued (MIDK = 0: never): GEMM1's hand-off
-// with the neighbours sits there, under the centre tap's MFMAs.  FAIRB: the two waves of a SIMD take turns at issue priority.
-template <int ROT, int NEXT_ROT, int MIDK, bool FAIRB, int NQ, int DIAG, typename LDB, typename MID, typename STAMP>
-__device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[2][8], rsrc_t rs, rsrc_t rs_next, int vfrag, const int (&sa)[4], int n_ks, LDB ldb,
-                                            MID mid, int half, bool diag_l1, STAMP stamp) {
-  static_assert(NQ == 2 || NQ == 4, "four operand buffers, indexed by the item's position in a pass of two k-steps");
+// inside the first MFMA group.
+//   The weight ring holds NS k-steps (slot = executed k-step mod NS) and runs THROUGH the GEMMs: a slot is refilled during the LAST column tile
+// of its k-step (lo fragments behind the first MFMA group, hi fragments behind the last) with the k-step NS ahead — and the last NS k-steps of
+// a GEMM fetch the FIRST NS of the GEMM that follows (`rs_next`, in that GEMM's order NEXT_ROT), each into its own slot: k-step j of the next
+// GEMM behind the k-step of this one with (executed index mod NS) = j, so that every GEMM starts with its k-step 0 in slot 0 whatever N_KS mod
+// NS is.  (Clamped to the GEMM's last k-step instead, the reloads re-read it — 12 % more weight bytes per layer — and every GEMM began with a
+// burst of fragment requests of its own.)  N_KS need not be a multiple of NS: the remainder is a shorter, separately unrolled pass.
+//   `mid()` runs in front of executed k-step MIDK (0: never): GEMM1's hand-off with the neighbours sits there, under the centre tap's MFMAs.
+// FAIRB: the two waves of a SIMD take turns at issue priority.
+template <int ROT, int NEXT_ROT, int N_KS, int MIDK, bool FAIRB, int NQ, int NS, int DIAG, typename LDB, typename MID, typename STAMP>
+__device__ __forceinline__ void mfma_pipe_q(f32x4q (&c)[4][NQ], f16x8 (&A)[NS][8], rsrc_t rs, rsrc_t rs_next, int vfrag, const int (&sa)[4], LDB ldb, MID mid,
+                                            int half, bool diag_l1, STAMP stamp) {
+  static_assert((NQ == 2 || NQ == 4) && (NS * NQ) % 4 == 0 && N_KS >= NS, "four operand buffers, indexed by the item's position in a pass of NS k-steps");
   // operand fragments: item (k-step, column tile) -> buffer (item index in the pass) & 3, read from LDS TWO column tiles = 24 MFMAs ahead (one
   // tile ahead, its latency — 8 waves' 16-byte reads of 528-byte rows — showed between the column tiles: GEMM2 8.05 us against 6.14 for the 32-row form)
   f16x8 B[4][2];
-  const int last = n_ks - 1;
-  auto item_ks = [&](int ks, int s, int ct) { const int k = ks + s + ct / NQ; return kmapq<ROT>(k <= last ? k : last); };
+  constexpr int last = N_KS - 1;
   ldb(kmapq<ROT>(0), 0, B[0]);
   ldb(kmapq<ROT>(0), 1, B[1]);
-#pragma unroll 1
-  for (int ks = 0; ks < n_ks; ks += 2) {
-    if (DIAG == 3) stamp(ks >> 1);   // (diagnostic instantiation: one stamp per pass of two k-steps)
+  // one k-step: e0 = executed index of the pass's first k-step (a multiple of NS), s = position in the pass = ring slot
+  auto one_step = [&](int e0, auto s_) {
+    constexpr int s = decltype(s_)::value;
+    const int e = e0 + s;
+    if (MIDK > 0 && e == MIDK) {
+      mid();
+      ldb(kmapq<ROT>(e), 0, B[(s * NQ) & 3]);   // the B operands of the next two column tiles were read before the halo rows arrived: read them again
+      ldb(kmapq<ROT>(e), 1, B[(s * NQ + 1) & 3]);
+    }
+    const bool over = e + NS > last;   // this slot's next occupant belongs to the GEMM that follows: its k-step s
+    const int kr = diag_l1 ? 0 : (over ? kmapq<NEXT_ROT>(s) : kmapq<ROT>(e + NS)) * QKSB;   // (diag_l1: every reload from ONE L1-resident k-step — wrong results)
+    const rsrc_t rsr = over ? rs_next : rs;
+#pragma unroll
+    for (int ct = 0; ct < NQ; ++ct) {
+      const int item = s * NQ + ct;
+      if (DIAG != 2) {   // (DIAG: timing experiments, wrong results: 1 = no weight reloads, 2 = no operand reads either)
+        const int en = e + (ct + 2) / NQ;
+        ldb(kmapq<ROT>(en <= last ? en : last), (ct + 2) % NQ, B[(item + 2) & 3]);
+      }
+      const f16x8(&Bc)[2] = B[item & 3];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt + 1], Bc[0]);   // lo hi
+      if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8(rsr, vfrag, sa[rt] + kr + QPLB);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[0]);       // hi hi
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[1]);       // hi lo
+      if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8(rsr, vfrag, sa[rt] + kr);
+      }
+      if (DIAG != 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      } else if (DIAG != 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto pass_top = [&](int e0) {
+    if (DIAG == 3) stamp(e0 / NS);   // (diagnostic instantiation: one stamp per pass)
     if (FAIRB) {
       const unsigned tnow = (unsigned)__builtin_amdgcn_s_memtime();
       if (((tnow >> 12) & 1u) == (unsigned)half) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
     }
-    if (MIDK > 0 && ks == MIDK) {
-      mid();
-      ldb(kmapq<ROT>(ks), 0, B[0]);   // the B operands of the next two column tiles were read before the halo rows arrived: read them again
-      ldb(kmapq<ROT>(ks), 1, B[1]);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      // the ring runs THROUGH the GEMMs: the reloads of a GEMM's last two k-steps fetch the first two of the GEMM that follows (`rs_next`, in
-      // that GEMM's order) — clamped to the last k-step instead, they re-read it twice (12 % more weight bytes per layer), and every GEMM
-      // began with a burst of 16 fragment requests of its own
-      const bool over = ks + s + 2 > last;
-      const int kr = diag_l1 ? 0 : (over ? kmapq<NEXT_ROT>(ks + s + 2 - n_ks) : kmapq<ROT>(ks + s + 2)) * QKSB;   // (diag_l1: every reload from ONE L1-resident k-step — wrong results)
-      const rsrc_t rsr = over ? rs_next : rs;
-#pragma unroll
-      for (int ct = 0; ct < NQ; ++ct) {
-        const int item = s * NQ + ct;
-        if (DIAG != 2) ldb(item_ks(ks, s, ct + 2), (ct + 2) % NQ, B[(item + 2) & 3]);   // (DIAG: timing experiments, wrong results: 1 = no weight reloads, 2 = no operand reads either)
-        const f16x8(&Bc)[2] = B[item & 3];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt + 1], Bc[0]);   // lo hi
-        if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt + 1] = lda8(rsr, vfrag, sa[rt] + kr + QPLB);
-        }
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[0]);       // hi hi
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) BSG_MFMA_Q(c[rt][ct], A[s][2 * rt], Bc[1]);       // hi lo
-        if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) A[s][2 * rt] = lda8(rsr, vfrag, sa[rt] + kr);
-        }
-        if (DIAG != 2) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        if (ct == NQ - 1 && DIAG != 1 && DIAG != 2) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        } else if (DIAG != 2) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+  };
+  constexpr int FULL = N_KS / NS, REM = N_KS % NS;
+#pragma unroll 1
+  for (int e0 = 0; e0 < FULL * NS; e0 += NS) {
+    pass_top(e0);
+    one_step(e0, std::integral_constant<int, 0>{});
+    if constexpr (NS > 1) one_step(e0, std::integral_constant<int, 1>{});
+    if constexpr (NS > 2) one_step(e0, std::integral_constant<int, 2>{});
+    if constexpr (NS > 3) one_step(e0, std::integral_constant<int, 3>{});
+  }
+  if constexpr (REM > 0) {
+    pass_top(FULL * NS);
+    one_step(FULL * NS, std::integral_constant<int, 0>{});
+    if constexpr (REM > 1) one_step(FULL * NS, std::integral_constant<int, 1>{});
+    if constexpr (REM > 2) one_step(FULL * NS, std::integral_constant<int, 2>{});
   }
 }
 
-template <bool FAIRB, bool TAIL, int NCT, int DIAG = 0>
+template <bool FAIRB, bool TAIL, int NCT, int DIAG = 0, int NS = 2>
 __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, TailArgs a) {
   constexpr int NT = 32 * NCT, NQ = 2 * NCT, XP = h2_xp(NCT), ZP = h2_zp(NCT);   // frames / column tiles of 16 per workgroup; bytes per plane
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -312,11 +333,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   write_core(x0);
   // weight ring, shared by both GEMMs and running through them (mfma_pipe_q); layer 0's first two k-steps (GEMM1 starts with the centre
   // tap: kmapq) are requested here
-  f16x8 A[2][8];
+  f16x8 A[NS][8];
   auto prefetch_a1 = [&](int l) {
     const rsrc_t rs = mk_rsrc(p.apack1q + (long long)l * (2 * 2 * C * 3 * C), 2 * 2 * C * 3 * C * 2);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NS; ++k) {
       const int kr = kmapq<8>(k) * QKSB;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         __syncthreads();   // (A) halo rows in place
         if (p.stamp_mode != 3 && p.stamp_mode < 5) STK_STAMP(2);
       };
-      mfma_pipe_q<8, 0, 8, FAIRB, NQ, DIAG>(y, A, rs_a1, rs_a2, vfrag, sa, 24, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); });
+      mfma_pipe_q<8, 0, 24, 8, FAIRB, NQ, NS, DIAG>(y, A, rs_a1, rs_a2, vfrag, sa, ldb, mid, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(16 + it); });
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     STK_STAMP(3);
@@ -464,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         Bf[0] = *reinterpret_cast<const f16x8*>(q);
         Bf[1] = *reinterpret_cast<const f16x8*>(q + ZP);
       };
-      mfma_pipe_q<0, 8, 0, FAIRB, NQ, DIAG>(y, A, rs_a2, rs_a1n, vfrag, sa, 8, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); });
+      mfma_pipe_q<0, 8, 8, 0, FAIRB, NQ, NS, DIAG>(y, A, rs_a2, rs_a1n, vfrag, sa, ldb, [] {}, wave >> 2, p.stamp_mode >= 6, [&](int it) { STK_STAMP(8 + it); });
       if (FAIRB) __builtin_amdgcn_s_setprio(0);
     }
     if (DIAG == 3) STK_STAMP(12);
@@ -561,20 +582,30 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 
 }  // namespace
 
-template <int NCT>
-static int h2q_occupancy() {
+// depth of the weight ring in k-steps of 32.  Deeper rings were built (the pipe takes any NS) and measured slower, profiles/r05_q_not_kept.txt:
+// 3 k-steps on 64-frame tiles 157.5 k against 175.7 k mel-frames/s (65 spilled registers), 4 k-steps on 32-frame tiles — which have the
+// registers — 63.9 against 60.4 ms per pass at B = 8: the weight stream is not waiting for its latency
+constexpr int NS_DEEP_64 = 2, NS_DEEP_32 = 2;
+static int ring_depth(int) { return 2; }
+
+template <int NCT, int NS>
+static int h2q_occupancy_ns() {
   int o = 0;
   const int lds = (int)h2_lds(NCT);
-  if (hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-      hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT>, 512, h2_lds(NCT)) != hipSuccess)
+  if (hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, false, NCT, 0, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipFuncSetAttribute((const void*)residual_stack_q_kernel<true, true, NCT, 0, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)residual_stack_q_kernel<true, true, NCT, 0, NS>, 512, h2_lds(NCT)) != hipSuccess)
     return 0;
   return o;
 }
 // resident workgroups per CU (0 on error) of the form with `nct` units of 32 frames per workgroup (1 or 2)
-int stack_h2q_occupancy(int nct) { return nct == 1 ? h2q_occupancy<1>() : h2q_occupancy<2>(); }
+int stack_h2q_occupancy(int nct) {
+  const int ns = ring_depth(nct);
+  if (nct == 1) return ns == 2 ? h2q_occupancy_ns<1, 2>() : h2q_occupancy_ns<1, NS_DEEP_32>();
+  return ns == 2 ? h2q_occupancy_ns<2, 2>() : h2q_occupancy_ns<2, NS_DEEP_64>();
+}
 
-template <int NCT>
+template <int NCT, int NS>
 static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) {
   const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
   const TailArgs a = tail ? *tail : TailArgs{};
@@ -589,9 +620,9 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
         if (tail) hipLaunchKernelGGL(kt, grid, block, lds, st, p, a);
         else hipLaunchKernelGGL(kn, grid, block, lds, st, p, a);
       };
-      if (diag == 1) go(residual_stack_q_kernel<true, true, 2, 1>, residual_stack_q_kernel<true, false, 2, 1>);
-      else if (diag == 2) go(residual_stack_q_kernel<true, true, 2, 2>, residual_stack_q_kernel<true, false, 2, 2>);
-      else go(residual_stack_q_kernel<true, true, 2, 3>, residual_stack_q_kernel<true, false, 2, 3>);
+      if (diag == 1) go(residual_stack_q_kernel<true, true, 2, 1, NS>, residual_stack_q_kernel<true, false, 2, 1, NS>);
+      else if (diag == 2) go(residual_stack_q_kernel<true, true, 2, 2, NS>, residual_stack_q_kernel<true, false, 2, 2, NS>);
+      else go(residual_stack_q_kernel<true, true, 2, 3, NS>, residual_stack_q_kernel<true, false, 2, 3, NS>);
       BSG_LAUNCH_CHECK();
       return BSG_OK;
     }
@@ -601,14 +632,14 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
   if (!fair) {
     static bool attr = false;
     if (!attr) {
-      BSG_HIP(hipFuncSetAttribute((const void*)residual_stack_q_kernel<false, false, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      BSG_HIP(hipFuncSetAttribute((const void*)residual_stack_q_kernel<false, true, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      BSG_HIP(hipFuncSetAttribute((const void*)residual_stack_q_kernel<false, false, NCT, 0, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      BSG_HIP(hipFuncSetAttribute((const void*)residual_stack_q_kernel<false, true, NCT, 0, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr = true;
     }
-    if (tail) hipLaunchKernelGGL((residual_stack_q_kernel<false, true, NCT>), grid, block, lds, st, p, a);
-    else hipLaunchKernelGGL((residual_stack_q_kernel<false, false, NCT>), grid, block, lds, st, p, a);
-  } else if (tail) hipLaunchKernelGGL((residual_stack_q_kernel<true, true, NCT>), grid, block, lds, st, p, a);
-  else hipLaunchKernelGGL((residual_stack_q_kernel<true, false, NCT>), grid, block, lds, st, p, a);
+    if (tail) hipLaunchKernelGGL((residual_stack_q_kernel<false, true, NCT, 0, NS>), grid, block, lds, st, p, a);
+    else hipLaunchKernelGGL((residual_stack_q_kernel<false, false, NCT, 0, NS>), grid, block, lds, st, p, a);
+  } else if (tail) hipLaunchKernelGGL((residual_stack_q_kernel<true, true, NCT, 0, NS>), grid, block, lds, st, p, a);
+  else hipLaunchKernelGGL((residual_stack_q_kernel<true, false, NCT, 0, NS>), grid, block, lds, st, p, a);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
 }
@@ -616,7 +647,9 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
 // the arguments of launch_residual_stack_h2 (diffnet_h2.hip); p.apack1q / p.apack2q must hold the 16-row weight fragments
 int launch_residual_stack_h2q(const StackArgs& p, const TailArgs* tail, hipStream_t st, int nct) {
   BSG_REQUIRE(p.apack1q && p.apack2q && p.dconv, "16-row stack launch: the 16-row weight fragments / the step-term table are missing");
-  return nct == 1 ? h2q_launch<1>(p, tail, st) : h2q_launch<2>(p, tail, st);
+  const int ns = ring_depth(nct);
+  if (nct == 1) return ns == 2 ? h2q_launch<1, 2>(p, tail, st) : h2q_launch<1, NS_DEEP_32>(p, tail, st);
+  return ns == 2 ? h2q_launch<2, 2>(p, tail, st) : h2q_launch<2, NS_DEEP_64>(p, tail, st);
 }
 
 }  // namespace bsg

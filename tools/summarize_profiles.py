@@ -83,7 +83,8 @@ for cfg in ('f32', 'bf16', 'voc', 'voc1', 'rank', 'b1'):
                      ('residual_layer_kernel<false, true>', 'layer')],
              'bf16': [('residual_stack_bf16_kernel<true>', 'stack_bf16'), ('residual_stack_bf16_kernel<false>', 'stack_bf16'),
                       ('residual_layer_bf16_kernel<false>', 'bf16')]}.get(cfg, [])
-    cands = [(k, 'stack_h2') for k in per_kernel if k.startswith('residual_stack_h2_kernel')] + cands   # any instantiation (<FAIR, TAIL>)
+    cands = ([(k, 'stack_h2q') for k in per_kernel if k.startswith('residual_stack_q_kernel')] +          # 16-row matrix tiles (round 5's default)
+             [(k, 'stack_h2') for k in per_kernel if k.startswith('residual_stack_h2_kernel')] + cands)   # any instantiation (<FAIR, TAIL>)
     for dom, path in cands:
         if dom not in per_kernel or 'hbm_bytes_per_launch' not in per_kernel[dom]:
             continue
@@ -94,7 +95,7 @@ for cfg in ('f32', 'bf16', 'voc', 'voc1', 'rank', 'b1'):
             frames, by = batch_frames, by * groups / 20   # one layer over the batch
             # what the on-chip form must move per frame and layer: conditioner term (fp32 2 KB / bf16 1 KB) + running skip sum r+w
             # (fp32 2 KB; bf16 form: in registers) + x in / skip out once per 20 layers + edges through L2
-            if path == 'stack_h2':      # conditioner term fp32 2 KB + x in / skip out once per 20 layers + two fp16 planes of the edges through L2
+            if path in ('stack_h2', 'stack_h2q'):      # conditioner term fp32 2 KB + x in / skip out once per 20 layers + two fp16 planes of the edges through L2
                 alg_form = (2048 + 2048 / 20 + 2 * 16384 / 64) * frames
             else:
                 alg_form = (2048 + 2048 + 1024 / 20) * frames if cfg == 'f32' else (1024 + 2048 / 20 + 2 * 8192 / 64) * frames
