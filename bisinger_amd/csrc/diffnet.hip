@@ -464,16 +464,35 @@ struct SplitArgs {
 
 // dconv[((s*L + l)*4 + v)*2C + row] = sum_ci w[row][ci][tap] * dproj[s][l][ci] for tap = v < 3, all three taps for v = 3 (fp64 accumulation):
 // the share of the step term d (constant over the frames) in dilated_conv_l(x + d), which the 16-row stack launch adds to the conditioner
-// term instead of adding d to every frame of its conv image (net.py:67,72-74)
-__global__ void dconv_kernel(const float* __restrict__ w, const float* __restrict__ dproj, float* __restrict__ out, int S, int L, int l) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= S * 4 * 2 * C) return;
-  const int row = i % (2 * C), v = (i / (2 * C)) % 4, s = i / (4 * 2 * C);
-  const float* d = dproj + ((long long)s * L + l) * C;
-  double acc = 0.0;
-  for (int tap = (v < 3 ? v : 0); tap < (v < 3 ? v + 1 : 3); ++tap)
-    for (int ci = 0; ci < C; ++ci) acc += (double)w[((long long)row * C + ci) * 3 + tap] * (double)d[ci];
-  out[(((long long)s * L + l) * 4 + v) * (2 * C) + row] = (float)acc;
+// term instead of adding d to every frame of its conv image (net.py:67,72-74).  One workgroup per 4 weight rows: the layer's step terms
+// [S][C] (padded rows: the threads of a row group read one column of it) and the 4 rows' weights in LDS, a thread per (row, step).
+constexpr int DCONV_ROWS = 4, DCONV_SMAX = 128;
+__global__ __launch_bounds__(DCONV_ROWS * DCONV_SMAX) void dconv_kernel(const float* __restrict__ w, const float* __restrict__ dproj, float* __restrict__ out,
+                                                                           int S, int L, int l) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  float* ds = reinterpret_cast<float*>(lds_raw);            // [DCONV_SMAX][C + 1]: the steps blockIdx.y * DCONV_SMAX ..
+  float* ws = ds + (size_t)DCONV_SMAX * (C + 1);            // [DCONV_ROWS][3 C]
+  const int tid = threadIdx.x, row0 = blockIdx.x * DCONV_ROWS, s0 = blockIdx.y * DCONV_SMAX;
+  const int ns = S - s0 < DCONV_SMAX ? S - s0 : DCONV_SMAX;
+  for (int i = tid; i < ns * C; i += blockDim.x) ds[(i / C) * (C + 1) + i % C] = dproj[((long long)(s0 + i / C) * L + l) * C + i % C];
+  for (int i = tid; i < DCONV_ROWS * 3 * C; i += blockDim.x) ws[i] = w[(long long)row0 * 3 * C + i];
+  __syncthreads();
+  const int r = tid / DCONV_SMAX, sl = tid % DCONV_SMAX, st = s0 + sl;
+  if (sl >= ns) return;
+  double acc[3] = {0.0, 0.0, 0.0};
+  const float* wr = ws + r * 3 * C;
+  const float* dr = ds + sl * (C + 1);
+  for (int ci = 0; ci < C; ++ci) {
+    const double d = (double)dr[ci];
+    acc[0] += (double)wr[ci * 3] * d;
+    acc[1] += (double)wr[ci * 3 + 1] * d;
+    acc[2] += (double)wr[ci * 3 + 2] * d;
+  }
+  float* o = out + ((long long)st * L + l) * 4 * (2 * C) + row0 + r;
+  o[0] = (float)acc[0];
+  o[2 * C] = (float)acc[1];
+  o[2 * 2 * C] = (float)acc[2];
+  o[3 * 2 * C] = (float)(acc[0] + acc[1] + acc[2]);
 }
 
 // out[((mt*(K/16) + q)*64 + lane)*4 + jj] = W(m = 16*mt + (lane&15), k = 16*q + 4*jj + (lane>>4)),  W row-major [M][K]
@@ -1282,7 +1301,10 @@ static int create_impl(bsg_diffnet* h, const void* const* w, const float* step_t
     // diffusion_projection of the tabulated step embedding -> dproj[s][l][:]            (net.py:67)
     if (rc == BSG_OK) rc = gemm_nt(dtab, (const float*)lw[2], h->dproj + (size_t)l * C, (const float*)lw[3], S, C, C, C, L * C, ACT_NONE, st);
     if (rc == BSG_OK) {
-      hipLaunchKernelGGL(dconv_kernel, dim3(cdiv(S * 4 * 2 * C, 256)), dim3(256), 0, st, (const float*)lw[0], (const float*)h->dproj, h->dconv, S, L, l);
+      const size_t dl = ((size_t)DCONV_SMAX * (C + 1) + DCONV_ROWS * 3 * C) * sizeof(float);
+      (void)hipFuncSetAttribute((const void*)dconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl);
+      hipLaunchKernelGGL(dconv_kernel, dim3(2 * C / DCONV_ROWS, cdiv(S, DCONV_SMAX)), dim3(DCONV_ROWS * DCONV_SMAX), dl, st, (const float*)lw[0], (const float*)h->dproj,
+                         h->dconv, S, L, l);
       if (hipGetLastError() != hipSuccess) { set_error("diffnet_create: dconv kernel failed"); rc = BSG_EHIP; }
     }
   }
