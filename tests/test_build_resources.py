@@ -31,3 +31,18 @@ def test_h2_stack_kernel_register_spills():
     print(res)
     assert len(res) >= 4, res      # <FAIR = true> x <TAIL> x <NCT>
     assert max(res.values()) <= 32, f'residual_stack_h2_kernel spills {res}: the register allocation fell off the cliff (see the module docstring)'
+
+
+def test_q_stack_kernel_register_spills():
+    """residual_stack_q_kernel (csrc/diffnet_h2q.hip): x lives in the conv image, not in registers, so that NOTHING is spilled inside
+    the layer loop (5-6 registers at phase boundaries on 64-frame tiles, none on 32-frame tiles).  Holding 16 more registers across the
+    GEMM loops (the edge tiles' tap terms, loaded early) put 29-144 spilled registers back and cost 3-6 % (profiles/r05_q_layouts.txt)."""
+    res = _spills(os.path.join(ROOT, 'bisinger_amd', 'csrc', 'diffnet_h2q.hip'), 'residual_stack_q_kernel')
+    # the product instantiations: <FAIRB, TAIL, NCT, DIAG = 0, NS = 2>; DIAG != 0 are timing-only
+    prod = {k: v for k, v in res.items() if re.search(r'Li[12]ELi0ELi2EEE', k)}
+    print(prod)
+    assert len(prod) >= 8, res
+    wide = [v for k, v in prod.items() if 'Li2ELi0ELi2EEE' in k]
+    narrow = [v for k, v in prod.items() if 'Li1ELi0ELi2EEE' in k]
+    assert max(wide) <= 12, f'64-frame tiles spill {prod}'
+    assert max(narrow) == 0, f'32-frame tiles spill {prod}'
