@@ -1839,6 +1839,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
       p.pflag_words = (int)(2 * h->part_cap * 4);
       p.wrap_pflags = h->part_flags; p.wrap_pflag_words = p.pflag_words;   // (also under BSG_DEBUG_WRAP_R04: a part launch always zeroed its own)
       p.apack1q = h->apack1q; p.apack2q = h->apack2q;
+      p.condterm_q = h->cond_q_valid ? h->condterm_q + row * 2 * C * T : nullptr;
       TRY(launch_residual_part_h2(p, st, h->stack_parts, nct));
     } else if (h2) {
       p.apack1s = h->apack1s; p.apack2s = h->apack2s; p.h2_scale = h->h2_scale;

@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
   const unsigned plane = (unsigned)C * T * 4;
   const rsrc_t rs_x = mk_rsrc(p.x_in + (long long)b * C * T, plane);
   const int rowT = T * 4, vfrag = lane * 16;
-  int vcol[NC], vst[NC];
+  int vcol[NC], vst[NC], vq[NC];
   bool col_ok[NC];
 #pragma unroll
   for (int ct = 0; ct < NC; ++ct) {
@@ -1202,6 +1202,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     col_ok[ct] = col < T;
     vcol[ct] = (kb * 4 * T + (col_ok[ct] ? col : T - 1)) * 4;   // accumulator rows 4 kb + r
     vst[ct] = (kb * 4 * T + col) * 4;
+    vq[ct] = (kb * T + (col_ok[ct] ? col : T - 1)) * 16;        // the same rows as one channel quad
   }
   const int rt_g = W * q + wave;                                  // gate / residual row tile (of 16); filter / skip: + 16
   const int sa_g = rt_g * 1024, sa_f = (16 + rt_g) * 1024;
@@ -1241,6 +1242,18 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
   };
 
   auto cond_request = [&](int l) {
+    if (p.condterm_q) {
+      // channel-quad order [2C/4][T][4] (round 5, as residual_stack_q_kernel): the 4 registers of an accumulator tile are ONE 16-byte load,
+      // 256 B contiguous per 16 lanes — 2 NC requests per lane instead of 8 NC
+      const rsrc_t rs_cq = mk_rsrc(p.condterm_q + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
+      const int so = (cb >> 2) * T * 16;
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) {
+        yg[ct] = ldf4(rs_cq, vq[ct], so);
+        yf[ct] = ldf4(rs_cq, vq[ct], so + (C / 4) * T * 16);
+      }
+      return;
+    }
     const rsrc_t rs_ct = mk_rsrc(p.condterm + (long long)l * p.ct_stride + (long long)b * 2 * C * T, 2 * plane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
