@@ -790,6 +790,7 @@ int launch_pair_k(const PairArgs& a, int C, int B, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 using hf16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using hf16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 constexpr float HG_WSC = 256.0f, HG_ASC = 16.0f;
 
 // out[((((rt*K + k)*(C/16) + ks)*2 + plane)*64 + lane)*8 + j] = hi / lo of 2^8 W[co = 32 rt + (lane & 31)][ci = 16 ks + 8 (lane >> 5) + j][k]
@@ -1088,37 +1089,129 @@ __global__ void pack_conv_h16_kernel(const float* __restrict__ w, _Float16* __re
   out[base + 512] = (_Float16)(v - (float)hi);
 }
 
-template <int K, int C, int NC>   // NC column tiles of 16 positions per wave
-__device__ __forceinline__ void conv_h16(f32x4h (&acc)[NC], const _Float16* __restrict__ wpk, const char* img, int rowb, int plane, int n0,
-                                         int dil, int lane) {
+// LDS image of the 16-row forms (round 5): channels-last rows of 2 C bytes, NO padding — 32 B for 16 channels, 16 B for 8 — per plane.  A B
+// fragment is one ds_read_b128 of 8 channels of one position; ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
+// (MI355X_MICROARCH.md, LDS): 8 lanes of one k-block and 8 of the next.  With 48-byte rows (rounds 3-4) every group had five 2-way conflicts — PMC: half
+// of SQ_LDS_IDX_ACTIVE was SQ_LDS_BANK_CONFLICT.  With 32-byte rows the two k-blocks of a tap (channel halves 0 / 1) land on even / odd 16-byte
+// slots and a group covers all 16 slots of the 256-byte bank row once — provided the halves of rows 4..7 (mod 8) are swapped, which also halves the
+// conflicts of the 8-byte stores (rows r and r + 4 of one channel quad no longer share a bank).  8 channels: one slot per row, rows of a group are
+// consecutive or identical (broadcast): conflict-free except where the taps of two k-blocks are 16 rows apart (d = 5: one pair per group).
+template <int C>
+__device__ __forceinline__ int h16_off(int row, int byte) {   // byte offset of (row, byte within the logical row) in a plane
+  if (C == 16) return row * 32 + (byte ^ ((row & 4) << 2));
+  return row * 16 + byte;
+}
+
+// Exact hi + lo fp16 split of four values that are ALREADY scaled (x 2^4), 6 instructions: the compiler's form of `hi = (f16)x; lo = (f16)(x -
+// (float)hi)` is convert, convert back, subtract, convert, pack — 4.5 per value, and the 8- / 16-channel launches are bound by exactly this
+// vector work (PMC: 23 VALU instructions per MFMA in the 8-channel chain).  v_fma_mix{lo,hi}_f16 takes the f16 hi straight from the packed
+// pair, forms x - hi in fp32 (exact) and rounds it to f16 into one half of the destination: the same two roundings, bit for bit
+// (tools/split_asm_check.hip).  `worst` collects max |x| as integer bits (NaN included) for the range guard.
+struct Split4 { unsigned h0, h1, l0, l1; };
+#ifndef BSG_HG_ASM_SPLIT
+#define BSG_HG_ASM_SPLIT 1
+#endif
+__device__ __forceinline__ Split4 split4_scaled(float x0, float x1, float x2, float x3, unsigned& worst) {
+  worst = max(max(worst, max(__builtin_bit_cast(unsigned, x0) & 0x7fffffffu, __builtin_bit_cast(unsigned, x1) & 0x7fffffffu)),
+              max(__builtin_bit_cast(unsigned, x2) & 0x7fffffffu, __builtin_bit_cast(unsigned, x3) & 0x7fffffffu));
+  Split4 r;
+#if BSG_HG_ASM_SPLIT && defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc parses the function too)
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.h0) : "v"(x0), "v"(x1));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.h1) : "v"(x2), "v"(x3));
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(r.l0) : "v"(x0), "v"(x1), "v"(r.h0));
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(r.l1) : "v"(x2), "v"(x3), "v"(r.h1));
+#else
+  const _Float16 a = (_Float16)x0, b = (_Float16)x1, c = (_Float16)x2, d = (_Float16)x3;
+  using h2 = __attribute__((ext_vector_type(2))) _Float16;
+  r.h0 = __builtin_bit_cast(unsigned, h2{a, b});
+  r.h1 = __builtin_bit_cast(unsigned, h2{c, d});
+  r.l0 = __builtin_bit_cast(unsigned, h2{(_Float16)(x0 - (float)a), (_Float16)(x1 - (float)b)});
+  r.l1 = __builtin_bit_cast(unsigned, h2{(_Float16)(x2 - (float)c), (_Float16)(x3 - (float)d)});
+#endif
+  return r;
+}
+constexpr unsigned HG_RANGE_BITS = 0x477DE800u;   // 65000.0f: a scaled value at or beyond it (or not finite) counts as a range event
+
+// the whole conv's weights (KS x 2 KB of fragments) into registers: requested a phase BEFORE the conv that uses them (under the staging loop, the
+// t1 / image writes and the barrier), so that no conv starts with an L2 round trip
+template <int K, int C>
+__device__ __forceinline__ void conv_h16_weights(hf16x8 (&A)[(K + 32 / C - 1) / (32 / C)][2], const float* __restrict__ wpk, int lane) {
   constexpr int TPK = 32 / C, KS = (K + TPK - 1) / TPK;
-  const int l15 = lane & 15, kb = lane >> 4;
   const hf16x8* __restrict__ wp = reinterpret_cast<const hf16x8*>(wpk) + lane;
-  hf16x8 A[KS][2];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {   // the whole conv's weights: KS x 2 KB
+  for (int ks = 0; ks < KS; ++ks) {
     A[ks][0] = wp[ks * 128];
     A[ks][1] = wp[ks * 128 + 64];
   }
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
+}
+
+#ifndef BSG_HG_PF
+#define BSG_HG_PF 2
+#endif
+// acc[ct] += W * img over the wave's NC column tiles of 16 positions: tap k of position p reads image row row0 + p + k dil (row0 = the wave's
+// first row for tap 0).  BSG_HG_PF (build-time): column tiles per prefetch group — the B fragments of a step (a k-step x a group) are read from LDS
+// while the previous step's 3 G MFMAs run, and the MFMAs of a step are ordered product-major so that consecutive ones write different accumulators;
+// 0 = the first form (2 fragments, wait, 3 MFMAs on one accumulator).  Per accumulator the order of the products is the same in all forms.
+template <int K, int C, int NC>   // NC column tiles of 16 positions per wave
+__device__ __forceinline__ void conv_h16(f32x4h (&acc)[NC], const hf16x8 (&A)[(K + 32 / C - 1) / (32 / C)][2], const char* img, int plane, int row0,
+                                         int dil, int lane) {
+  constexpr int TPK = 32 / C, KS = (K + TPK - 1) / TPK, ROWB = 2 * C;
+  const int l15 = lane & 15, kb = lane >> 4;
+  auto frag = [&](int ks) {   // this lane's fragment address of k-step ks, column tile 0
     int tap = C == 16 ? 2 * ks + (kb >> 1) : 4 * ks + kb;
     if (tap > K - 1) tap = K - 1;   // padded tap (zero weights): a row that exists
-    const char* bk = img + (n0 + l15 + tap * dil) * rowb + (C == 16 ? (kb & 1) * 16 : 0);
+    return img + h16_off<C>(row0 + l15 + tap * dil, C == 16 ? (kb & 1) * 16 : 0);
+  };
+#if BSG_HG_PF == 0
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const char* bk = frag(ks);
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) {
-      const hf16x8 bh = *reinterpret_cast<const hf16x8*>(bk + 16 * ct * rowb);
-      const hf16x8 bl = *reinterpret_cast<const hf16x8*>(bk + 16 * ct * rowb + plane);
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bh, acc[ct], 0, 0, 0);
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bl, acc[ct], 0, 0, 0);
-      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][1], bh, acc[ct], 0, 0, 0);
+      const hf16x8 bh1 = *reinterpret_cast<const hf16x8*>(bk + 16 * ct * ROWB);
+      const hf16x8 bl1 = *reinterpret_cast<const hf16x8*>(bk + 16 * ct * ROWB + plane);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bh1, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bl1, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][1], bh1, acc[ct], 0, 0, 0);
     }
   }
+#else
+  constexpr int G = NC < BSG_HG_PF ? NC : BSG_HG_PF, NG = NC / G, NSTEP = KS * NG;
+  static_assert(NC % G == 0, "column tiles per wave");
+  hf16x8 bh[2][G], bl[2][G];
+  auto ldb = [&](int step, int buf) {
+    const char* bk = frag(step / NG) + 16 * G * (step % NG) * ROWB;   // (16 rows further: the swizzle bit of the row is unchanged)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      bh[buf][j] = *reinterpret_cast<const hf16x8*>(bk + 16 * j * ROWB);
+      bl[buf][j] = *reinterpret_cast<const hf16x8*>(bk + 16 * j * ROWB + plane);
+    }
+  };
+  ldb(0, 0);
+#pragma unroll
+  for (int step = 0; step < NSTEP; ++step) {
+    const int ks = step / NG, g = step % NG, buf = step & 1;
+    if (step + 1 < NSTEP) ldb(step + 1, buf ^ 1);
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[G * g + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bh[buf][j], acc[G * g + j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[G * g + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][0], bl[buf][j], acc[G * g + j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[G * g + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ks][1], bh[buf][j], acc[G * g + j], 0, 0, 0);
+    if (step + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2 * G, 0);   // the next step's LDS reads are issued first ...
+    __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);                          // ... and land under this step's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
 }
 
 template <int K, int C, int NB>
 __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
-  constexpr int PT = 128 * NB, H2 = (K - 1) / 2, POUT = PT - (K - 1), TS = PT + 16, ROWB = 48, NC = 2 * NB;
+  constexpr int PT = 128 * NB, H2 = (K - 1) / 2, POUT = PT - (K - 1), TS = PT + 16, ROWB = 2 * C, NC = 2 * NB;
   constexpr float ACC_SC = HG_WSC * HG_ASC, ACC_INV = 1.0f / (HG_WSC * HG_ASC);
   static_assert(C == 16 || C == 8, "channel count");
   extern __shared__ __attribute__((aligned(16))) char hlds[];   // lrelu(x) planes [span][ROWB], then t1 planes [TS][ROWB]
@@ -1142,6 +1235,8 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
   // ---- stage lrelu(x) over [t0 - H2 - h1, + span), zero outside [0, L): item = (4 channels, position), lanes = consecutive positions ----
   // the residual's x values in ACCUMULATOR layout (16 registers), requested first: the staging loop below then finds their lines in L2 instead
   // of the epilogue fetching the tile's x from HBM a second time, ~100 us after it was staged (PMC: 2.7 x the tensor fetched per pair)
+  hf16x8 Aw[(K + 32 / C - 1) / (32 / C)][2];
+  conv_h16_weights<K, C>(Aw, a.w1, lane);
   float xres[2 * NB][4];
   {
     const bool rows_ok_ = 4 * (lane >> 4) < C;
@@ -1174,8 +1269,8 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
       for (int e = 0; e < 4; ++e) v[u][e] = fmaxf(v[u][e], v[u][e] * slope);
       hf16x4 hi, lo;
       split4(v[u], hi, lo);
-      *reinterpret_cast<hf16x4*>(hlds + jx * ROWB + cq * 8) = hi;
-      *reinterpret_cast<hf16x4*>(hlds + plane + jx * ROWB + cq * 8) = lo;
+      *reinterpret_cast<hf16x4*>(hlds + h16_off<C>(jx, cq * 8)) = hi;
+      *reinterpret_cast<hf16x4*>(hlds + plane + h16_off<C>(jx, cq * 8)) = lo;
     }
   }
   const int n0 = 32 * NB * wave;
@@ -1191,7 +1286,8 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
   init_acc(a.b1);
   __syncthreads();
   // ---- conv1 (dilation d) at t1 positions u = t0 - H2 + p: reads x row p + k d ------------------------------------------------------
-  conv_h16<K, C, NC>(acc, reinterpret_cast<const _Float16*>(a.w1), hlds, ROWB, plane, n0, a.dil, lane);
+  conv_h16<K, C, NC>(acc, Aw, hlds, plane, n0, a.dil, lane);
+  conv_h16_weights<K, C>(Aw, a.w2, lane);
   __syncthreads();   // every wave is done reading x
   // ---- t1 = lrelu(conv1), zero outside [0, L) (conv2 pads its input) -> LDS planes [TS][ROWB] -----------------------------------------
   if (rows_ok) {
@@ -1207,7 +1303,7 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
       }
       hf16x4 hi, lo;
       split4(v, hi, lo);
-      char* dst = hlds + pcol * ROWB + (4 * kb) * 2;
+      char* dst = hlds + h16_off<C>(pcol, (4 * kb) * 2);
       *reinterpret_cast<hf16x4*>(dst) = hi;
       *reinterpret_cast<hf16x4*>(dst + plane) = lo;
     }
@@ -1221,7 +1317,7 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
   init_acc(a.b2);
   __syncthreads();
   // ---- conv2 (dilation 1) at output positions t = t0 + p: reads t1 row p + k ----------------------------------------------------------
-  conv_h16<K, C, NC>(acc, reinterpret_cast<const _Float16*>(a.w2), hlds, ROWB, plane, n0, 1, lane);
+  conv_h16<K, C, NC>(acc, Aw, hlds, plane, n0, 1, lane);
   if (a.range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(a.range_events, 1u);
   // ---- residual, MRF sum, store: lanes = 16 consecutive positions of 4 channels -------------------------------------------------------------
   if (!rows_ok) return;
@@ -1243,7 +1339,7 @@ __global__ __launch_bounds__(256) void resblock_pair_h16_kernel(PairArgs a) {
 
 template <int K, int C, int NB>
 int launch_pair_h16_t(const PairArgs& a, int B, hipStream_t st) {
-  constexpr int PT = 128 * NB, POUT = PT - (K - 1), ROWB = 48;
+  constexpr int PT = 128 * NB, POUT = PT - (K - 1), ROWB = 2 * C;
   const int span = PT + 2 * ((K - 1) / 2 * a.dil);
   const size_t lds = (size_t)2 * (span > PT + 16 ? span : PT + 16) * ROWB;
   static size_t attr = 0;
@@ -1284,6 +1380,195 @@ bool pair_h16_supported(int K, int C) {
   return (K == 3 || K == 7 || K == 11) && (C == 16 || (C == 8 && (h16_c8() == 1 || (h16_c8() == 11 && K == 11))));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// A whole ResBlock1 of 8 / 16 channels in ONE launch (round 5): its n_dil (dilated conv, conv) pairs run back to back on a
+// tile that carries the block's receptive-field halo, HT = (K - 1) / 2 x sum(d + 1) positions per side (60 for K = 11 and d = 1, 3, 5), so the
+// stage tensor is read ONCE and written once per ResBlock instead of once per pair (launched pair by pair a ResBlock moved the tensor through
+// HBM 6-7 times).  The residual stream stays in registers in accumulator layout (fp32, as the pairs store it), the image of lrelu(x) / t1 in
+// ONE LDS buffer of split-fp16 planes with zero pad rows on both sides — the convolutions are the pairs' conv_h16, the arithmetic is the
+// pairs' in the same order, so the valid positions are bit-identical to the pair launches.  All PT positions of the tile are computed in every
+// convolution; the outer HT see pad rows instead of their true neighbours and are never stored (at PT = 512: 23 % of the work for K = 11, 14 %
+// for K = 7, 5 % for K = 3).  Positions outside [0, L) are written as zeros at every step (each Conv1d pads its own input, hifigan.py:54-61).
+// ------------------------------------------------------------------------------------------------
+struct ChainArgs {
+  const float* x;        // [B][C][L]
+  const float* w1[3];    // conv1 of pair m: hi / lo fp16 fragments (pack_conv_h16_kernel)
+  const float* b1[3];
+  const float* w2[3];
+  const float* b2[3];
+  float* y;              // [B][C][L]
+  const float* acc_in;   // optional MRF running sum (may alias y: every element is read and written by the same lane)
+  float out_div, slope;
+  int L, n_pairs;
+  int dil[3];
+  unsigned* range_events;
+};
+
+template <int K, int C, int NC>   // NC column tiles of 16 positions per wave: a tile of PT = 64 NC positions
+__global__ __launch_bounds__(256) void resblock_chain_h16_kernel(ChainArgs a) {
+  constexpr int PT = 64 * NC, H2 = (K - 1) / 2, ROWB = 2 * C;
+  constexpr float ACC_SC = HG_WSC * HG_ASC, ACC_INV = 1.0f / (HG_WSC * HG_ASC);
+  static_assert(C == 16 || C == 8, "channel count");
+  extern __shared__ __attribute__((aligned(16))) char hlds[];   // planes [pa + PT + pa][ROWB]: lrelu(x_m), then t1 of pair m, then lrelu(x_m+1) ...
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kb = lane >> 4;
+  int ht = 0, dmax = 1;
+  for (int m = 0; m < a.n_pairs; ++m) {
+    ht += H2 * (a.dil[m] + 1);
+    dmax = a.dil[m] > dmax ? a.dil[m] : dmax;
+  }
+  const int pa = H2 * dmax;              // pad rows on each side of the image (always zero)
+  const int plane = (PT + 2 * pa) * ROWB;
+  float* btab = reinterpret_cast<float*>(hlds + 2 * plane);   // [2 n_pairs][16]: the biases x 2^12 (a global load in front of every conv was an L2 round trip)
+  if (tid < 32 * a.n_pairs) {
+    const int cv = tid >> 4, r = tid & 15;
+    btab[tid] = r < C ? ((cv & 1) ? a.b2[cv >> 1] : a.b1[cv >> 1])[r] * ACC_SC : 0.f;
+  }
+  const int pout = PT - 2 * ht;
+  const int t0 = blockIdx.x * pout - ht, b = blockIdx.y;   // tile row p <-> position t0 + p
+  const float* __restrict__ xb = a.x + (long long)b * C * a.L;
+  const float slope = a.slope;
+  const int n0 = 16 * NC * wave;
+  const bool rows_ok = 4 * kb < C;       // C = 8: accumulator rows 8..15 do not exist
+  unsigned worst = 0;   // max |scaled value| written to the image, as bits
+  // ---- the residual stream x of the tile, accumulator layout (row 4 kb + r, column n0 + 16 ct + l15), zero outside [0, L) ----------------
+  float xres[NC][4];
+  unsigned in_mask = 0;
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct) {
+    const int t = t0 + n0 + 16 * ct + l15;
+    const bool in = t >= 0 && t < a.L;
+    in_mask |= in ? 1u << ct : 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xres[ct][r] = (in && rows_ok) ? xb[(long long)(4 * kb + r) * a.L + t] : 0.f;
+  }
+  for (int idx = tid; idx < 2 * pa * (ROWB / 4); idx += 256) {   // the pad rows, both planes, once
+    const int r = idx / (ROWB / 4), c = idx % (ROWB / 4);
+    const int row = r < pa ? r : PT + r;
+    *reinterpret_cast<unsigned*>(hlds + row * ROWB + c * 4) = 0u;
+    *reinterpret_cast<unsigned*>(hlds + plane + row * ROWB + c * 4) = 0u;
+  }
+  // rows pa + p <- split(lrelu(sc val(ct, r)) 2^4), sc a power of two: this lane's 4 channels of its NC positions.  lrelu commutes with the
+  // power-of-two scales, so they are one product; a tile that lies inside [0, L) (all but the two at the ends of an utterance) skips the masks
+  const bool all_in = __builtin_amdgcn_ballot_w64(in_mask != (1u << NC) - 1u) == 0ull;
+  auto write_img = [&](auto&& val, float sc) {
+    if (!rows_ok) return;
+    const float sc_s = sc * slope;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = val(ct, e);
+        v[e] = fmaxf(y * sc, y * sc_s);
+      }
+      Split4 q = split4_scaled(v[0], v[1], v[2], v[3], worst);
+      if (!all_in && !(in_mask >> ct & 1u)) q = Split4{0u, 0u, 0u, 0u};
+      char* dst = hlds + h16_off<C>(pa + n0 + 16 * ct + l15, (4 * kb) * 2);
+      *reinterpret_cast<u32x2*>(dst) = u32x2{q.h0, q.h1};
+      *reinterpret_cast<u32x2*>(dst + plane) = u32x2{q.l0, q.l1};
+    }
+  };
+  f32x4h acc[NC];
+  auto init_acc = [&](int cv) {   // behind a barrier that follows the table's writes
+    const f32x4h bv = *reinterpret_cast<const f32x4h*>(btab + 16 * cv + 4 * kb);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = bv;
+  };
+  hf16x8 Aw[(K + 32 / C - 1) / (32 / C)][2];
+  conv_h16_weights<K, C>(Aw, a.w1[0], lane);
+  write_img([&](int ct, int e) { return xres[ct][e]; }, HG_ASC);
+#pragma unroll 1
+  for (int m = 0; m < a.n_pairs; ++m) {
+    const int d = a.dil[m];
+    __syncthreads();   // the image of lrelu(x_m) is complete
+    init_acc(2 * m);
+    // conv1 (dilation d): t1[p] reads image rows pa + p + (k - H2) d
+    conv_h16<K, C, NC>(acc, Aw, hlds, plane, pa - H2 * d + n0, d, lane);
+    conv_h16_weights<K, C>(Aw, a.w2[m], lane);
+    __syncthreads();   // every wave is done reading x_m's image
+    write_img([&](int ct, int e) { return acc[ct][e]; }, ACC_INV * HG_ASC);   // t1 = lrelu(conv1), zero outside [0, L)
+    __syncthreads();
+    init_acc(2 * m + 1);
+    // conv2 (dilation 1): reads t1 rows pa + p + k - H2
+    conv_h16<K, C, NC>(acc, Aw, hlds, plane, pa - H2 + n0, 1, lane);
+    if (m + 1 < a.n_pairs) conv_h16_weights<K, C>(Aw, a.w1[m + 1], lane);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[ct][r] = (in_mask >> ct & 1u) ? acc[ct][r] * ACC_INV + xres[ct][r] : 0.f;
+    if (m + 1 < a.n_pairs) {
+      __syncthreads();   // every wave is done reading t1
+      write_img([&](int ct, int e) { return xres[ct][e]; }, HG_ASC);
+    }
+  }
+  if (a.range_events && __builtin_amdgcn_ballot_w64(worst >= HG_RANGE_BITS) != 0ull && lane == 0) atomicAdd(a.range_events, 1u);
+  // ---- MRF sum, store: the inner pout positions --------------------------------------------------------------------------------------------
+  if (!rows_ok) return;
+  const bool has_acc = a.acc_in != nullptr, has_div = a.out_div != 1.0f;
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct) {
+    const int pcol = n0 + 16 * ct + l15, t = t0 + pcol;
+    if (pcol < ht || pcol >= PT - ht || t >= a.L) continue;
+    const long long i0 = ((long long)b * C + 4 * kb) * a.L + t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = xres[ct][r];
+      if (has_acc) v = a.acc_in[i0 + (long long)r * a.L] + v;
+      if (has_div) v = v / a.out_div;
+      a.y[i0 + (long long)r * a.L] = v;
+    }
+  }
+}
+
+template <int K, int C, int NC>
+int launch_chain_h16_t(const ChainArgs& a, int B, hipStream_t st) {
+  constexpr int PT = 64 * NC, H2 = (K - 1) / 2, ROWB = 2 * C;
+  int ht = 0, dmax = 1;
+  for (int m = 0; m < a.n_pairs; ++m) { ht += H2 * (a.dil[m] + 1); dmax = a.dil[m] > dmax ? a.dil[m] : dmax; }
+  const int pout = PT - 2 * ht;
+  const size_t lds = (size_t)2 * (PT + 2 * H2 * dmax) * ROWB + 6 * 16 * sizeof(float);
+  static size_t attr = 0;
+  if (lds > attr) {
+    BSG_HIP(hipFuncSetAttribute((const void*)resblock_chain_h16_kernel<K, C, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL((resblock_chain_h16_kernel<K, C, NC>), dim3(cdiv(a.L, pout), B), dim3(256), lds, st, a);
+  BSG_LAUNCH_CHECK();
+  return BSG_OK;
+}
+// the tile width by the number of tiles: 512 positions while that leaves >= 2 workgroups per CU, else 256 (more, smaller workgroups)
+bool chain_h16_supported(int K, int C, int n_pairs, const int* dil) {
+  if (!((K == 3 || K == 7 || K == 11) && (C == 16 || C == 8)) || n_pairs < 1 || n_pairs > 3) return false;
+  int ht = 0, dmax = 1;
+  for (int m = 0; m < n_pairs; ++m) { ht += (K - 1) / 2 * (dil[m] + 1); dmax = dil[m] > dmax ? dil[m] : dmax; }
+  return 2 * ht <= 128 && (size_t)2 * (512 + (K - 1) * dmax) * 2 * C <= 80 * 1024;   // >= half of a 256-position tile is output; two workgroups per CU
+}
+template <int K, int C>
+int launch_chain_h16_kc(const ChainArgs& a, int B, hipStream_t st) {
+  int ht = 0;
+  for (int m = 0; m < a.n_pairs; ++m) ht += (K - 1) / 2 * (a.dil[m] + 1);
+  static int nc_env = -1;   // BSG_HG_CHAIN_NC = 4 / 8: force the tile width
+  if (nc_env < 0) { const char* e = getenv("BSG_HG_CHAIN_NC"); nc_env = e ? atoi(e) : 0; }
+  const bool wide = nc_env ? nc_env == 8 : (long long)cdiv(a.L, 512 - 2 * ht) * B >= 512;
+  if (wide) return launch_chain_h16_t<K, C, 8>(a, B, st);
+  return launch_chain_h16_t<K, C, 4>(a, B, st);
+}
+int launch_chain_h16(const ChainArgs& a, int K, int C, int B, hipStream_t st) {
+  if (C == 16) {
+    if (K == 3) return launch_chain_h16_kc<3, 16>(a, B, st);
+    if (K == 7) return launch_chain_h16_kc<7, 16>(a, B, st);
+    if (K == 11) return launch_chain_h16_kc<11, 16>(a, B, st);
+  }
+  if (C == 8) {
+    if (K == 3) return launch_chain_h16_kc<3, 8>(a, B, st);
+    if (K == 7) return launch_chain_h16_kc<7, 8>(a, B, st);
+    if (K == 11) return launch_chain_h16_kc<11, 8>(a, B, st);
+  }
+  set_error("hifigan: no ResBlock chain kernel for K=%d, C=%d", K, C);
+  return BSG_EINVAL;
+}
 
 template <int K, int C, int NB>
 int launch_pair_mfma_t(const PairArgs& a, int B, hipStream_t st) {
@@ -1363,6 +1648,7 @@ struct ConvW {
   float* wpm = nullptr;   // ResBlock convs with 32 / 64 channels: MFMA fragment order for resblock_pair_mfma_kernel
   float* wps = nullptr;   // the same as hi / lo fp16 fragments (x 2^8) for resblock_pair_h2_kernel (m floats = 2 planes of m halves)
   float* wp16 = nullptr;  // 8 / 16 channels: hi / lo fp16 fragments of v_mfma_f32_16x16x32_f16 for resblock_pair_h16_kernel [ks][plane][64][8]
+  float* wp16c = nullptr; // the same fragments for resblock_chain_h16_kernel: packed for every K of an 8- / 16-channel ResBlock1 (wp16 where that exists)
   float* wpu = nullptr;   // ConvTranspose1d with K = 2u: per-phase 2-tap weights in CO-blocks of 8 for upsample_kernel
   float* b = nullptr;
   int cout = 0, cin = 0, k = 0;
@@ -1447,6 +1733,13 @@ static int pack_conv(bsg_hifigan* h, ConvW& c, hipStream_t st, bool pair = false
       const int tpk = 32 / c.cout, ks = (c.k + tpk - 1) / tpk;
       TRY(hg_alloc(h, &c.wp16, (size_t)ks * 512));   // ks x 2 planes x 64 lanes x 8 halves = ks x 512 floats
       hipLaunchKernelGGL(pack_conv_h16_kernel, dim3(cdiv(ks * 512, 256)), dim3(256), 0, st, (const float*)c.w, reinterpret_cast<_Float16*>(c.wp16), c.cout,
+                         c.k, h->w_range_bad);
+      BSG_LAUNCH_CHECK();
+      c.wp16c = c.wp16;
+    } else if ((c.cout == 8 || c.cout == 16) && (c.k == 3 || c.k == 7 || c.k == 11)) {   // (8 channels, K = 3 / 7: pairs on the vector pipe, chain on the matrix pipe)
+      const int tpk = 32 / c.cout, ks = (c.k + tpk - 1) / tpk;
+      TRY(hg_alloc(h, &c.wp16c, (size_t)ks * 512));
+      hipLaunchKernelGGL(pack_conv_h16_kernel, dim3(cdiv(ks * 512, 256)), dim3(256), 0, st, (const float*)c.w, reinterpret_cast<_Float16*>(c.wp16c), c.cout,
                          c.k, h->w_range_bad);
       BSG_LAUNCH_CHECK();
     }
@@ -1756,6 +2049,32 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
     for (int j = 0; j < c.n_kernels; ++j) {
       const int r = i * c.n_kernels + j;
       const float* y = xin;
+      {
+        // a whole ResBlock1 of 8 / 16 channels in one launch (resblock_chain_h16_kernel; BSG_HG_CHAIN=0: pair by pair)
+        static int chain_env = -1, split_env = -1, mfma_env2 = -1, h16_env2 = -1;
+        if (chain_env < 0) { const char* e = getenv("BSG_HG_CHAIN"); chain_env = e ? atoi(e) : 1; }
+        if (split_env < 0) { const char* e = getenv("BSG_HG_SPLIT"); split_env = e ? atoi(e) : 1; }
+        if (mfma_env2 < 0) { const char* e = getenv("BSG_HG_MFMA"); mfma_env2 = e ? atoi(e) : 1; }
+        if (h16_env2 < 0) { const char* e = getenv("BSG_HG_H16"); h16_env2 = e ? atoi(e) : 1; }
+        const ConvW& f1 = h->rb1[(size_t)r * c.n_dil];
+        bool chain = chain_env && split_env && mfma_env2 && h16_env2 && c.resblock != 2 && h->h2_ok && gemm_split_enabled() && c.n_dil <= 3 &&
+                     chain_h16_supported(f1.k, f1.cout, c.n_dil, c.resblock_dilations[j]);
+        for (int m = 0; chain && m < c.n_dil; ++m)
+          chain = h->rb1[(size_t)r * c.n_dil + m].wp16c && h->rb2[(size_t)r * c.n_dil + m].wp16c && h->rb1[(size_t)r * c.n_dil + m].k == f1.k &&
+                  h->rb2[(size_t)r * c.n_dil + m].k == f1.k;
+        if (chain) {
+          ChainArgs ca{};
+          ca.x = xin; ca.y = sum; ca.acc_in = j > 0 ? sum : nullptr; ca.out_div = j == c.n_kernels - 1 ? (float)c.n_kernels : 1.0f;
+          ca.slope = slope; ca.L = L; ca.n_pairs = c.n_dil; ca.range_events = gemm_range_counter();
+          for (int m = 0; m < c.n_dil; ++m) {
+            const ConvW& c1 = h->rb1[(size_t)r * c.n_dil + m];
+            const ConvW& c2 = h->rb2[(size_t)r * c.n_dil + m];
+            ca.w1[m] = c1.wp16c; ca.b1[m] = c1.b; ca.w2[m] = c2.wp16c; ca.b2[m] = c2.b; ca.dil[m] = c.resblock_dilations[j][m];
+          }
+          TRY(launch_chain_h16(ca, f1.k, f1.cout, B, st));
+          continue;
+        }
+      }
       for (int m = 0; m < c.n_dil; ++m) {
         const bool last = m == c.n_dil - 1;
         const ConvW& c1 = h->rb1[(size_t)r * c.n_dil + m];

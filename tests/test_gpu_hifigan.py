@@ -59,7 +59,8 @@ def test_hifigan_throughput_size_vs_oracle(B, tmp_path, hifigan_sd, sd_spec):
     /root/reference/train_bisinger/modules/hifigan/hifigan.py:30-67,144-173): split-fp16 on the 16-bit matrix pipe (default), fp32 MFMA
     (BSG_HG_SPLIT=0), VALU (BSG_HG_MFMA=0) — <= 5e-5 of the waveform's scale.  Round 4: the default also runs conv_pre and the u = 8 transposed
     convolutions on the pre-split GEMM (polyphase store), conv_post as its own kernel and — at B = 8 — the 4-samples-per-lane u = 2 stages;
-    'vector_convs' switches those four back to the round-3 kernels.  One child process per form (the switches are read once per process);
+    'vector_convs' switches those four back to the round-3 kernels.  Round 5: the default runs each 8- / 16-channel ResBlock1 as one launch
+    ('pairs' = pair by pair; 'chain_narrow' = the chain's other tile width).  One child process per form (the switches are read once per process);
     the oracle takes ~0.5 s per 1000 frames."""
     import json
     import os
@@ -81,7 +82,9 @@ np.save(sys.argv[2], y.cpu().numpy())
 print(json.dumps({'finite': bool(torch.isfinite(y).all())}))
 ''' % ROOT
     scale = max(1.0, float(np.abs(want).max()))
-    for name, env in (('split', {}), ('fp32_mfma', {'BSG_HG_SPLIT': '0'}), ('valu', {'BSG_HG_MFMA': '0'}),
+    outs = {}
+    for name, env in (('split', {}), ('pairs', {'BSG_HG_CHAIN': '0', 'BSG_HG_H16_C8': '1'}), ('chain_narrow', {'BSG_HG_CHAIN_NC': '4'} if B == 8 else {'BSG_HG_CHAIN_NC': '8'}),
+                      ('fp32_mfma', {'BSG_HG_SPLIT': '0'}), ('valu', {'BSG_HG_MFMA': '0'}),
                       ('vector_convs', {'BSG_HG_H2W': '0', 'BSG_NO_CONV_POST': '1', 'BSG_NO_UP2': '1'})):
         f = str(tmp_path / f'{name}.npy')
         res = subprocess.run([sys.executable, '-c', code, str(tmp_path / 'mel.npy'), f], env=dict(os.environ, **env), capture_output=True,
@@ -93,3 +96,9 @@ print(json.dumps({'finite': bool(torch.isfinite(y).all())}))
         dev = float(np.abs(got - want).max())
         print(f'B={B} T=1000 {name} vs oracle: max-abs {dev:.2e} (scale {scale:.2f})')
         assert dev <= 5e-5 * scale, (name, dev)
+        outs[name] = got
+    # round 5: the 8- / 16-channel ResBlocks run as ONE launch each (resblock_chain_h16_kernel) with the pairs' arithmetic in the pairs' order:
+    # bit-identical to the pair-by-pair launches on the same matrix form ('pairs': BSG_HG_CHAIN=0, and the 8-channel K = 3 / 7 pairs moved from the
+    # vector pipe to the 16-row matrix form the chain uses), for both tile widths of the chain
+    assert np.array_equal(outs['split'], outs['pairs']), float(np.abs(outs['split'] - outs['pairs']).max())
+    assert np.array_equal(outs['split'], outs['chain_narrow'])
