@@ -29,10 +29,26 @@ __device__ __forceinline__ f16x8 lda8(rsrc_t r, int voff, int soff) {
 }
 // hi / lo split of two values into two packed dwords
 struct HiLo { unsigned hi, lo; };
+// Round 5: 3 instructions per pair.  The compiler's form of `hi = (f16)x; lo = (f16)(x - (float)hi)` is pack-convert, two converts back, two
+// subtractions, pack-convert; v_fma_mix{lo,hi}_f16 takes the f16 hi straight from the packed pair, forms x - hi in fp32 (exact) and rounds it to
+// f16 into one half of the destination — the same two roundings, bit for bit (tools/split_asm_check.hip: 0 of 8.4 M values differ, subnormal
+// lo terms, the range edge and signed zeros included).  BSG_ASM_SPLIT=0 at build time keeps the plain form.
+#ifndef BSG_ASM_SPLIT
+#define BSG_ASM_SPLIT 1
+#endif
 __device__ __forceinline__ HiLo split2(float a, float b) {
+#if BSG_ASM_SPLIT && defined(__HIP_DEVICE_COMPILE__)
+  HiLo r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.hi) : "v"(a), "v"(b));
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(r.lo) : "v"(a), "v"(b), "v"(r.hi));
+  return r;
+#else
   const _Float16 ha = (_Float16)a, hb = (_Float16)b;
   return HiLo{__builtin_bit_cast(unsigned, f16x2{ha, hb}),
               __builtin_bit_cast(unsigned, f16x2{(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)})};
+#endif
 }
 
 #define BSG_MFMA_H(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, ACC, 0, 0, 0)
