@@ -440,14 +440,17 @@ __global__ __launch_bounds__(512, 2) void residual_stack_bf16_kernel(StackArgs p
   // the conditioner term of a layer: requested (16 x 8 B per lane) a phase before it is needed, unpacked into the accumulators at the
   // top of the layer — the unpack is the first use, so no wait for HBM sits between the request and the barriers that follow it
   u32x2 cr[16];
+#ifndef BSG_BQ_AUX
+#define BSG_BQ_AUX 3   // nt + sc0 on the conditioner term's loads, as in the split-fp16 launches (profiles/r05_cq_aux_ab.log)
+#endif
   auto cond_request = [&](int l) {
     const rsrc_t rs_ct = mk_rsrc(p.condterm_h + (long long)l * p.ct_stride + (long long)b * 2 * C * T, plane);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      cr[4 * g + 0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (8 * wave + 2 * g) * T * 8, 0));
-      cr[4 * g + 1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
-      cr[4 * g + 2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (8 * wave + 2 * g) * T * 8, 0));
-      cr[4 * g + 3] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (C / 4 + 8 * wave + 2 * g) * T * 8, 0));
+      cr[4 * g + 0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (8 * wave + 2 * g) * T * 8, BSG_BQ_AUX));
+      cr[4 * g + 1] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[0], (C / 4 + 8 * wave + 2 * g) * T * 8, BSG_BQ_AUX));
+      cr[4 * g + 2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (8 * wave + 2 * g) * T * 8, BSG_BQ_AUX));
+      cr[4 * g + 3] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_ct, vq[1], (C / 4 + 8 * wave + 2 * g) * T * 8, BSG_BQ_AUX));
     }
   };
   auto cond_unpack = [&]() {

@@ -1241,6 +1241,13 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     }
   };
 
+  // cache-policy bits of these loads: nt + sc0 for the pair form — the term is a stream read once per step that should not displace the weight
+  // fragments in L2 (same-box A/B, profiles/r05_cq_aux_ab.log: B = 8 55.6 -> 53.1 ms per pass; the quads, whose 4 parts share one XCD's L2 with a
+  // quarter of the weight stream each, lose 1-2 % with it)
+#ifndef BSG_PQ_AUX
+#define BSG_PQ_AUX 3
+#endif
+  constexpr int CQ_AUX = P == 2 ? BSG_PQ_AUX : 0;
   auto cond_request = [&](int l) {
     if (p.condterm_q) {
       // channel-quad order [2C/4][T][4] (round 5, as residual_stack_q_kernel): the 4 registers of an accumulator tile are ONE 16-byte load,
@@ -1249,8 +1256,8 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
       const int so = (cb >> 2) * T * 16;
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
-        yg[ct] = ldf4(rs_cq, vq[ct], so);
-        yf[ct] = ldf4(rs_cq, vq[ct], so + (C / 4) * T * 16);
+        yg[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cq, vq[ct], so, CQ_AUX));
+        yf[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cq, vq[ct], so + (C / 4) * T * 16, CQ_AUX));
       }
       return;
     }

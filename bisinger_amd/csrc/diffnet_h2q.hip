@@ -203,6 +203,11 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 
   // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 32 NCT dword loads per lane, 64 B contiguous per 16 lanes,
   // requested straight into the accumulators a phase before they are used
+#ifndef BSG_CQ_AUX
+#define BSG_CQ_AUX 3   // cache-policy bits of the conditioner term's loads: nt + sc0 — a stream read once per step that should not displace the
+                       // weight fragments in L2 (same-box A/B, profiles/r05_cq_aux_ab.log: 43.11 -> 42.8 us per layer; 0 = default policy, 16 = sc1)
+#endif
+#define BSG_CQ_LD(R, V, S) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, V, S, BSG_CQ_AUX))
   auto cond_request = [&](int l) {
     if (p.condterm_q) {
       // channel-quad order [2C/4][T][4]: the 4 registers of an accumulator tile are ONE 16-byte load, 256 B contiguous per 16 lanes: 8 NCT
@@ -214,8 +219,8 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
         const int so = (8 * wave + 4 * rt) * T * 16;
 #pragma unroll
         for (int ct = 0; ct < NQ; ++ct) {
-          y[rt][ct] = ldf4(rs_cq, vquad(ct), so);
-          y[2 + rt][ct] = ldf4(rs_cq, vquad(ct), so + (C / 4) * T * 16);
+          y[rt][ct] = BSG_CQ_LD(rs_cq, vquad(ct), so);
+          y[2 + rt][ct] = BSG_CQ_LD(rs_cq, vquad(ct), so + (C / 4) * T * 16);
         }
       }
       return;
