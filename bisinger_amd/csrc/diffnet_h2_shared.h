@@ -285,7 +285,8 @@ __device__ __forceinline__ void h2_fused_tail(const TailArgs& a, unsigned* statu
     for (int ct = 0; ct < NCT; ++ct)
       if (col_ok[ct]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) stf(fmaxf(hc[ct][r] * inv, 0.f), rs_xa, vst[ct], (32 * wave + acc_row0(r)) * rowT);
+        for (int r = 0; r < 16; ++r)   // 16 MB per step at B = 16, read once by the next launch: non-temporal, like the conditioner term's loads
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(hc[ct][r] * inv, 0.f)), rs_xa, vst[ct], (32 * wave + acc_row0(r)) * rowT, 2);
       }
   }
 }

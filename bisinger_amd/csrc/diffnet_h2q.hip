@@ -24,6 +24,11 @@
 #include "diffnet_h2_shared.h"
 #include <type_traits>
 
+#ifndef BSG_CQ_AUX
+#define BSG_CQ_AUX 3   // cache-policy bits of the conditioner term's loads: nt + sc0 — a stream read once per step that should not displace the
+                       // weight fragments in L2 (same-box A/B, profiles/r05_cq_aux_ab.log: 43.11 -> 42.8 us per layer; 0 = default policy, 16 = sc1)
+#endif
+
 namespace bsg {
 
 namespace {
@@ -203,10 +208,6 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 
   // the conditioner term of a layer (fp32 [2C][T] rows of this utterance): 32 NCT dword loads per lane, 64 B contiguous per 16 lanes,
   // requested straight into the accumulators a phase before they are used
-#ifndef BSG_CQ_AUX
-#define BSG_CQ_AUX 3   // cache-policy bits of the conditioner term's loads: nt + sc0 — a stream read once per step that should not displace the
-                       // weight fragments in L2 (same-box A/B, profiles/r05_cq_aux_ab.log: 43.11 -> 42.8 us per layer; 0 = default policy, 16 = sc1)
-#endif
 #define BSG_CQ_LD(R, V, S) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, V, S, BSG_CQ_AUX))
   auto cond_request = [&](int l) {
     if (p.condterm_q) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        x0[ct][rt][i] = ldf(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT);
+        x0[ct][rt][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT, BSG_CQ_AUX));   // read once per step
         sk[ct][rt][i] = 0.f;
       }
   {

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
         const int wrow = wt128 * 128 + wave * 32 + acc_row(r, lh);
         float v = c[mi][r] * H2W_OUT + bv[r];
         if (g.alpha_ncols == 0 || wrow < g.alpha_ncols) v *= g.alpha;
-        Cp[(long long)wrow * g.ldc + arow] = v;
+        __builtin_nontemporal_store(v, &Cp[(long long)wrow * g.ldc + arow]);   // (a result far larger than the caches: keep the operands' lines)
         c[mi][r] = v;
       }
       if (g.Cq) {
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int wrow = wt128 * 128 + wave * 32 + acc_row(4 * gq, lh);
-          *reinterpret_cast<f32x4*>(Cq + ((long long)(wrow >> 2) * g.rows + arow) * 4) = f32x4{c[mi][4 * gq], c[mi][4 * gq + 1], c[mi][4 * gq + 2], c[mi][4 * gq + 3]};
+          __builtin_nontemporal_store(f32x4{c[mi][4 * gq], c[mi][4 * gq + 1], c[mi][4 * gq + 2], c[mi][4 * gq + 3]},
+                                      reinterpret_cast<f32x4*>(Cq + ((long long)(wrow >> 2) * g.rows + arow) * 4));
         }
       }
     }
