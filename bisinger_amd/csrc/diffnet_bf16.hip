@@ -328,12 +328,15 @@ __global__ __launch_bounds__(512, 4) void residual_layer_bf16_kernel(ResArgs a) 
 //     layer) and is stored once;
 //   * the only HBM stream per layer is the conditioner term (bf16, 1 KB per frame), requested into the GEMM1 accumulators while the
 //     workgroup waits for its neighbours; neighbours exchange the two 8-frame edges of the new bf16 image (2 x 4 KB per tile);
-//   * one workgroup per CU with 256 registers per wave: the weight ring is 8 k-steps deep (>= 2000 cycles of cover for the L2
-//     latency of the 1-MB-per-tile weight stream that the per-layer kernel waits for with its 4-deep ring).
+//   * one workgroup per CU with 256 registers per wave and a weight ring of its own depth (8 k-steps until round 5; 4 since the conditioner
+//     term is loaded non-temporally and the 1-MB-per-tile weight stream hits L2: BSG_BF_NSS).
 // HBM bytes per frame and layer: 1.25 KB instead of 4.3 KB.  Arithmetic: as the per-layer bf16 kernel, except that the skip sum is
 // never rounded to bf16 and the conditioner term is the accumulators' initial value.
 // ------------------------------------------------------------------------------------------------
-constexpr int NSS = 8;   // weight ring of the stack kernel (k-steps)
+#ifndef BSG_BF_NSS
+#define BSG_BF_NSS 4   // (round 5, with the weights staying in L2: 4 k-steps 405 k against 8 k-steps 401 k mel-frames/s, profiles/r05_bf16_variants_ab.log)
+#endif
+constexpr int NSS = BSG_BF_NSS;   // weight ring of the stack kernel (k-steps)
 
 // i-th executed k-step -> k-step index: GEMM1 (ROT = 16, 48 k-steps, tap-major) starts with the CENTRE tap, whose B operand is
 // the tile's own 64 frames, and visits the two outer taps (which read the neighbours' halo frames) afterwards
