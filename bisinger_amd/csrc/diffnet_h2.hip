@@ -1336,7 +1336,13 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
     }
   };
   auto zx_slot = [&](int tile, int part) { return p.zx + ((size_t)tile * P + part) * slot_halfs; };
-  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)par * n_tiles + tile) * P + part) * slot_halfs; };
+  // ONE image slot per part (round 5; until then one per layer parity): a part writes its image of layer l + 2 behind its GEMM2 of layer l + 1, which
+  // needed the partners' z of that layer, which they published behind THEIR GEMM1 of layer l + 1 — i.e. after they had copied this part's image of
+  // layer l + 1 into LDS.  Half the exchange footprint in the XCD's L2, which the weight fragments share (BSG_IX_SINGLE=0 at build time: two).
+#ifndef BSG_IX_SINGLE
+#define BSG_IX_SINGLE 1
+#endif
+  auto ix_slot = [&](int par, int tile, int part) { return p.ix + (((size_t)(BSG_IX_SINGLE ? 0 : par) * n_tiles + tile) * P + part) * slot_halfs; };
 
   // ---- layer 0: x from HBM — this wave's channels into registers, the WHOLE image (all channels, halo frames included) into LDS ----------
 #pragma unroll
