@@ -435,7 +435,10 @@ def secondary_cfg3_rank(model, device, fence):
     import torch
     net = model.denoise_fn
     wl = Workload(model, device, B_CFG3_TOTAL, 1, 8, emulate=True)
-    dt, layer_ms, n_layer, mel = timed(wl, 3, 1, fence)
+    # both sides of the ratio are timed WITHOUT the per-launch HIP events of the profiling mode (round 5: the rank's passes carried them — two
+    # launches per sampler step, 400 event records per pass — and the one-GPU passes did not); the per-layer figure comes from one more pass
+    dt, _, _, mel = timed(wl, 3, 1, fence, profile=False)
+    _, layer_ms, n_layer, _ = timed(wl, 1, 0, fence)
     path = net.last_path()
     ok = bool(torch.isfinite(mel).all()) and tuple(mel.shape) == (8, T_FRAMES, N_MEL)
     wl1 = Workload(model, device, B_CFG3_TOTAL, 0, 1)
