@@ -97,6 +97,8 @@ struct H2wArgs {
   int ldc;
   long long sC;                // per batch index z
   float* Cq;                   // optional (act_is_a = 0, direct store only): the same output once more in CHANNEL-QUAD order [Wn / 4][rows][4] (+ z x sC)
+  unsigned short* Ch;          // optional (direct store only): the output rounded to bf16 in channel-quad order [Wn / 4][rows][4] (+ z x sC elements) — what the
+                               // bf16-operand stack launch loads; with Ch the fp32 output C may be null (round 5: the term went through HBM as fp32 first)
   unsigned short* out;         // optional (act_is_a only): the result as hi / lo planes [rows][ldo] for the next GEMM, lo `out_plane` halfs behind
   long long out_plane;
   int ldo;

@@ -1476,6 +1476,7 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   h->cond_q_valid = false;
   static int env_h2w = -1;   // BSG_GEMM_H2W=0: gemm_split_kernel (operands split while staged) instead of the pre-split GEMM
   if (env_h2w < 0) { const char* e = getenv("BSG_GEMM_H2W"); env_h2w = e ? atoi(e) : 1; }
+  bool bf16_direct = false;
   const bool h2w = env_h2w && h->cond_h2w_ok && gemm_split_enabled() && h2w_supports(T, 2 * C, C, 1, C) && (long long)h->L * B <= 65535;
   if (h2w) {
     // All L projections of all B rows as ONE launch on the 16-bit matrix pipe with pre-split operands (gemm_h2w.hip): cond is transposed and
@@ -1506,8 +1507,14 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     h->cond_q_valid = want_q;
     H2wArgs g{};
     g.Cq = want_q ? h->condterm_q : nullptr;
+    // bf16-operand configuration: the epilogue rounds the term to bf16 quads itself and writes NO fp32 copy (until round 5 the 2.6 GB of fp32 at
+    // B = 64 went to HBM and 20 conversion launches read them back; BSG_COND_BF16_DIRECT=0: that form)
+    static int env_hd = -1;
+    if (env_hd < 0) { const char* e = getenv("BSG_COND_BF16_DIRECT"); env_hd = e ? atoi(e) : 1; }
+    bf16_direct = env_hd && h->compute == BSG_COMPUTE_BF16 && h->condterm_h;
+    g.Ch = bf16_direct ? h->condterm_h : nullptr;
     g.act = h->cond_planes; g.act_plane = (long long)bt * C; g.lda = C; g.sAct = (long long)T * C; g.wpack = h->wcond_pack;
-    g.sW = (long long)2 * 2 * C * C; g.zdiv = B; g.rows = T; g.K = C; g.Wn = 2 * C; g.taps = 1; g.act_is_a = 0; g.C = h->condterm; g.ldc = T;
+    g.sW = (long long)2 * 2 * C * C; g.zdiv = B; g.rows = T; g.K = C; g.Wn = 2 * C; g.taps = 1; g.act_is_a = 0; g.C = bf16_direct ? nullptr : h->condterm; g.ldc = T;
     g.sC = (long long)2 * C * T; g.bias = h->b_cond; g.sBias = 2 * C; g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = h->L * B;
     TRY(launch_gemm_h2w(g, st));
   } else if (B == 1) {
@@ -1519,7 +1526,7 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     if (B != 1 && !h2w)
       TRY(conv1x1(h->w_cond + (size_t)l * 2 * C * C, h->b_cond + (size_t)l * 2 * C, cond,
                   h->condterm + (size_t)l * 2 * C * bt, 2 * C, C, B, T, ACT_NONE, st));
-    if (h->compute == BSG_COMPUTE_BF16)
+    if (h->compute == BSG_COMPUTE_BF16 && !bf16_direct)
       TRY(f32_to_quad_bf16(h->condterm + (size_t)l * 2 * C * bt, h->condterm_h + (size_t)l * 2 * C * bt, B, 2 * C, T, st));
   }
   h->prepared_compute = h->compute;

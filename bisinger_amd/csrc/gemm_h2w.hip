@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
   _Float16* __restrict__ oh = g.out ? reinterpret_cast<_Float16*>(g.out) + (long long)z * g.sO : nullptr;
   constexpr int ER = ACT_IS_A ? BMA : 128, EC = ACT_IS_A ? 128 : BMA, EP = EC + 4;   // image rows x columns (columns = the output's contiguous axis), pitch
   float* et = reinterpret_cast<float*>(lds);
-  if (!ACT_IS_A && !g.up_u && !Rp && !RS && g.act_fn == ACT_NONE && (!g.no_direct || g.Cq)) {
+  if (!ACT_IS_A && !g.up_u && !Rp && !RS && g.act_fn == ACT_NONE && (!g.no_direct || g.Cq || g.Ch)) {
     // [feature][frame] output with nothing but bias / alpha in the epilogue (the conditioner hoist: 655 MB of fp32 per pass at B = 16): straight from
     // the accumulators — a register is 32 consecutive frames of one feature row per lane half (two 128-byte runs per store) — without the LDS
     // image, its two barriers and the rolled loop
@@ -306,8 +306,21 @@ __global__ __launch_bounds__(256, 2) void gemm_h2w_kernel(H2wArgs g) {
         const int wrow = wt128 * 128 + wave * 32 + acc_row(r, lh);
         float v = c[mi][r] * H2W_OUT + bv[r];
         if (g.alpha_ncols == 0 || wrow < g.alpha_ncols) v *= g.alpha;
-        __builtin_nontemporal_store(v, &Cp[(long long)wrow * g.ldc + arow]);   // (a result far larger than the caches: keep the operands' lines)
+        if (Cp) __builtin_nontemporal_store(v, &Cp[(long long)wrow * g.ldc + arow]);   // (a result far larger than the caches: keep the operands' lines)
         c[mi][r] = v;
+      }
+      if (g.Ch) {
+        // the same quads rounded to bf16 (round to nearest even, as f32_to_quad_bf16_kernel rounds the fp32 term): 8 bytes per quad
+        using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+        using u32x2g = __attribute__((ext_vector_type(2))) unsigned;
+        unsigned short* __restrict__ Ch = g.Ch + (long long)z * g.sC;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int wrow = wt128 * 128 + wave * 32 + acc_row(4 * gq, lh);
+          const u32x2g pk = u32x2g{__builtin_bit_cast(unsigned, bf16x2{(__bf16)c[mi][4 * gq], (__bf16)c[mi][4 * gq + 1]}),
+                                   __builtin_bit_cast(unsigned, bf16x2{(__bf16)c[mi][4 * gq + 2], (__bf16)c[mi][4 * gq + 3]})};
+          __builtin_nontemporal_store(pk, reinterpret_cast<u32x2g*>(Ch + ((long long)(wrow >> 2) * g.rows + arow) * 4));
+        }
       }
       if (g.Cq) {
         // channel-quad order: the 4 registers of a group are 4 consecutive feature rows of one frame = one 16-byte store, 512 B contiguous per
@@ -555,7 +568,8 @@ int h2w_split_transposed(const float* src, unsigned short* hi, unsigned short* l
 
 int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
   H2wArgs g = g0;
-  BSG_REQUIRE(g.act && g.wpack && (g.C || g.out) && g.batch > 0, "gemm_h2w: null operand");
+  BSG_REQUIRE(g.act && g.wpack && (g.C || g.out || g.Ch) && g.batch > 0, "gemm_h2w: null operand");
+  BSG_REQUIRE(g.C || !g.Ch || (!g.act_is_a && !g.up_u && !g.R && !g.rowscale && g.act_fn == ACT_NONE), "gemm_h2w: a bf16-quad output without the fp32 one needs the direct-store epilogue");
   BSG_REQUIRE(h2w_supports(g.rows, g.Wn, g.K, g.taps, g.lda), "gemm_h2w: unsupported shape rows=%d Wn=%d K=%d taps=%d lda=%d", g.rows, g.Wn, g.K,
               g.taps, g.lda);
   BSG_REQUIRE(!g.out || g.act_is_a, "gemm_h2w: plane output needs the [token][feature] form");
