@@ -24,6 +24,18 @@
 #include "diffnet_h2_shared.h"
 #include <type_traits>
 
+// (float)hi + (float)lo of one half of two packed f16 pairs in ONE instruction (round 5)
+__device__ __forceinline__ float mix_add(unsigned hp, unsigned lp, int half) {
+  float r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (half == 0) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hp), "v"(lp));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hp), "v"(lp));
+#else
+  r = 0.f;
+#endif
+  return r;
+}
+
 #ifndef BSG_CQ_AUX
 #define BSG_CQ_AUX 3   // cache-policy bits of the conditioner term's loads: nt + sc0 — a stream read once per step that should not displace the
                        // weight fragments in L2 (same-box A/B, profiles/r05_cq_aux_ab.log: 43.11 -> 42.8 us per layer; 0 = default policy, 16 = sc1)
@@ -460,18 +472,18 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     // residual rows start from (x + b_out) x s2', skip rows from b_out x s2' (the accumulators of GEMM1 are free now); x = hi + lo from the
     // image rows this lane wrote (the sum is exact in fp32)
     {
-      using h4 = __attribute__((ext_vector_type(4))) _Float16;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const f32x4 br = *reinterpret_cast<const f32x4*>(btab + cw + 16 * rt), bs = *reinterpret_cast<const f32x4*>(btab + C + cw + 16 * rt);
 #pragma unroll
         for (int ct = 0; ct < NQ; ++ct) {
           const char* src = xs + (HALO + n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
-          const h4 hv = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(src));
-          const h4 lv = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(src + XP));
+          const u32x2 hp = *reinterpret_cast<const u32x2*>(src), lp = *reinterpret_cast<const u32x2*>(src + XP);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            y[rt][ct][i] = (((float)hv[i] + (float)lv[i]) * XINV + br[i]) * s2;
+            // (hi + lo) / 16 + b, times s2: v_fma_mix_f32 adds the two halves straight from the packed pairs (exact, as the two conversions and
+            // the addition it replaces), and s2 — a power of two — folds into the second fused multiply-add: 2 instructions per value instead of 5
+            y[rt][ct][i] = __builtin_fmaf(mix_add(hp[i >> 1], lp[i >> 1], i & 1), XINV * s2, br[i] * s2);
             y[2 + rt][ct][i] = bs[i] * s2;
           }
         }
