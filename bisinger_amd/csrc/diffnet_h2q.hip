@@ -298,18 +298,21 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     }
   };
   // image core (frames t0 .. t0+NT-1, this wave's 32 channels) = hi / lo of x, zero beyond T (the conv pads with zeros)
-  auto write_core = [&](const float (&xr)[NQ][2][4]) {
+  // xr16 = 16 x (the caller folds the factor into the product that forms x); a tile whose 64 frames all lie inside the utterance — all but the
+  // last of a row — skips the masks of the frames beyond T
+  const bool all_cols = t0 + NT <= T;   // (wave-uniform)
+  auto write_core = [&](const float (&xr16)[NQ][2][4]) {
     unsigned worst = 0;
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const float v0 = xr[ct][rt][0] * XSCALE, v1 = xr[ct][rt][1] * XSCALE, v2 = xr[ct][rt][2] * XSCALE, v3 = xr[ct][rt][3] * XSCALE;
+        const float v0 = xr16[ct][rt][0], v1 = xr16[ct][rt][1], v2 = xr16[ct][rt][2], v3 = xr16[ct][rt][3];
         worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
         const HiLo s0 = split2(v0, v1);
         const HiLo s1_ = split2(v2, v3);
         u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
-        if (!col_ok(ct)) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
+        if (!all_cols && !col_ok(ct)) { wh = u32x2{0u, 0u}; wl = u32x2{0u, 0u}; }
         char* dst = xs + (HALO + n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
         *reinterpret_cast<u32x2*>(dst) = wh;
         *reinterpret_cast<u32x2*>(dst + XP) = wl;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        x0[ct][rt][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT, BSG_CQ_AUX));   // read once per step
+        x0[ct][rt][i] = XSCALE * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vcol(ct), (32 * wave + 16 * rt + i) * rowT, BSG_CQ_AUX));   // read once per step
         sk[ct][rt][i] = 0.f;
       }
   {
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     }
     STK_STAMP(3);
     // ---- gate -> zs (hi / lo of 2^10 z); GEMM2's first weights are on their way since GEMM1's last two k-steps -------------------------
-    const float rs2 = inv2 * 0.70710678118654752440f;
+    const float rs2x = inv2 * 0.70710678118654752440f * XSCALE;   // (XSCALE is a power of two: the product's rounding is the unscaled one's)
     const float gcg = -1.44269504088896340736f * inv1, gcf = -2.88539008177792681472f * inv1, glim = 15.0f * s1;
 #pragma unroll
     for (int ct = 0; ct < NQ; ++ct) {
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          xn[ct][rt][i] = y[rt][ct][i] * rs2;          // (x + residual) / sqrt(2), net.py:78: un-scaling and 1 / sqrt(2) in one factor
+          xn[ct][rt][i] = y[rt][ct][i] * rs2x;         // 16 (x + residual) / sqrt(2), net.py:78: un-scaling, 1 / sqrt(2) and the image's 2^4 in one factor
           sk[ct][rt][i] += y[2 + rt][ct][i] * inv2;
         }
     STK_STAMP(5);
