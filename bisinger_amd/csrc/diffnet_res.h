@@ -158,8 +158,8 @@ __device__ __forceinline__ float gate1(float g, float f) {
 // cf = -2 log2(e) / s, lim = 15 s; s = 1, num = 1 is gate1 itself
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f32x2 gate2_scaled(f32x2 g, f32x2 f, float cg, float cf, float lim, float num) {
-  f[0] = fminf(fmaxf(f[0], -lim), lim);
-  f[1] = fminf(fmaxf(f[1], -lim), lim);
+  f[0] = __builtin_amdgcn_fmed3f(f[0], -lim, lim);   // (one instruction for the clamp; a NaN comes out as -lim in both forms)
+  f[1] = __builtin_amdgcn_fmed3f(f[1], -lim, lim);
   const f32x2 a = g * cg, b = f * cf;
   const f32x2 eg = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
   const f32x2 ef = f32x2{__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])};
