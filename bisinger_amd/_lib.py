@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libbisinger_hip.so')
 if os.environ.get('BSG_LIB'):      # development: an alternative build of the same ABI (kernel experiments)
     LIB_PATH = os.environ['BSG_LIB']
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class BsgError(RuntimeError):
@@ -93,6 +93,9 @@ _SIGS = {
     'bsg_fs2midi_destroy': (None, [c_void_p]),
     'bsg_fs2midi_encode': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    'bsg_fs2midi_encode_rows': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                          c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'bsg_fs2midi_last_rows': (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     'bsg_length_regulator': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'bsg_fs2midi_decode': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                      c_void_p, c_void_p]),

@@ -789,11 +789,12 @@ __global__ void embed_finish_kernel(const float* __restrict__ x0, const float* _
 
 // ---- ESM attention over the BATCH axis (reference quirk, common_layers.py:853) --------------------
 // q,k,v: [L=B][N=Tt][H]; for every (n, head) softmax over the L keys.  One thread per (l, n, head).
+// q / o hold the Lq QUERY utterances only (all L of them, or a rank's rows: bsg_fs2midi_encode_rows); k / v all L.
 template <int HD>
 __global__ void esm_attention_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                     float* __restrict__ o, int L, int N, int heads, float scale) {
+                                     float* __restrict__ o, int L, int Lq, int N, int heads, float scale) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)L * N * heads;
+  const long long total = (long long)Lq * N * heads;
   if (idx >= total) return;
   const int h = (int)(idx % heads);
   const int n = (int)((idx / heads) % N);
@@ -836,7 +837,7 @@ __global__ void esm_attention_kernel(const float* __restrict__ q, const float* _
 // above (max, then exp and sum) in the same order of operations.  ld = row stride of q / k / v; out fp32 [.][H] and / or hi / lo planes of 16 x out.
 __global__ __launch_bounds__(256) void esm_attention_wave_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                  const float* __restrict__ v, int ldq, int ldkv, float* __restrict__ o,
-                                                                 _Float16* __restrict__ oh, long long o_plane, int L, int N, int heads,
+                                                                 _Float16* __restrict__ oh, long long o_plane, int L, int Lq, int N, int heads,
                                                                  float scale, unsigned* __restrict__ range_events) {
   constexpr int HD = 32;
   __shared__ __attribute__((aligned(16))) float kv[4][2][64][HD];
@@ -853,8 +854,8 @@ __global__ __launch_bounds__(256) void esm_attention_wave_kernel(const float* __
     }
   }
   __syncthreads();
-  if (!live || lane >= L) return;
-  const int l = lane;
+  if (!live || lane >= Lq) return;
+  const int l = lane;   // LOCAL query row: q, o and the planes hold the Lq query utterances only; the keys are all L
   float qv[HD];
   {
     const float* qp = q + ((long long)l * N + n) * ldq + hh * HD;
@@ -1070,6 +1071,8 @@ struct bsg_fs2midi {
   size_t cap_fsk = 0, cap_fcnt = 0;
   unsigned* pack_bad = nullptr;                      // device word: packed weights beyond the fp16 range (then the pre-split GEMMs are not used)
   bool h2w_ok = false;
+  int last_token_rows = 0;   // rows (utterances x tokens) the last encode ran its encoder on; rows of the last FFT stack (bsg_fs2midi_last_rows)
+  int last_stack_rows = 0;
 };
 
 static int fs2_alloc(bsg_fs2midi* h, float** p, size_t n) {
@@ -1286,9 +1289,10 @@ static int ln_planes(const float* x, const float* w, const float* b, unsigned sh
 }
 // y[rows][N] = epi(planes[rows][K] W^T): Linear through gemm_h2w_kernel (W pre-split); `planes_out`: the result as planes [2][rows][N] instead
 static int linear_h2w(const unsigned short* planes, const H2wWeights& W, int N, const float* bias, float* Y, unsigned short* planes_out, long long rows,
-                      int act, const float* R, const float* rowscale, hipStream_t st, float alpha = 1.f, int alpha_ncols = 0) {
+                      int act, const float* R, const float* rowscale, hipStream_t st, float alpha = 1.f, int alpha_ncols = 0,
+                      long long act_plane = 0) {
   H2wArgs g{};
-  g.act = planes; g.act_plane = rows * W.K; g.lda = W.K; g.wpack = W.pack; g.rows = (int)rows; g.K = W.K; g.Wn = W.Wn; g.taps = 1;
+  g.act = planes; g.act_plane = act_plane ? act_plane : rows * W.K; g.lda = W.K; g.wpack = W.pack; g.rows = (int)rows; g.K = W.K; g.Wn = W.Wn; g.taps = 1;
   g.act_is_a = 1; g.C = Y; g.ldc = N; g.out = planes_out; g.out_plane = rows * N; g.ldo = N; g.bias = bias; g.alpha = alpha;
   g.alpha_ncols = alpha_ncols; g.act_fn = act; g.R = R; g.ldr = N; g.rowscale = rowscale; g.batch = 1;
   return launch_gemm_h2w(g, st);
@@ -1298,6 +1302,7 @@ static int linear_h2w(const unsigned short* planes, const H2wWeights& W, int N, 
 static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const float* lnw, const float* lnb, int ksz,
                      float* x, const float* keep, int B, int T, hipStream_t st) {
   const long long rows = (long long)B * T;
+  h->last_stack_rows = (int)rows;
   const int heads = h->cfg.num_heads, hd = H / heads;
   const float qscale = (float)sqrt(1.0 / (double)hd);
   static int env_h2w = -1;   // BSG_GEMM_H2W=0: gemm_split_kernel (operands split while staged) instead of the pre-split GEMMs
@@ -1444,25 +1449,30 @@ static int fft_stack(bsg_fs2midi* h, const std::vector<FftLayerW>& layers, const
   return BSG_OK;
 }
 
-extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
-                                  const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t Tt,
-                                  float* enc_out, float* dur_xs, int64_t* dur, void* stream) {
-  BSG_REQUIRE(h && txt && pitch_midi && midi_dur && is_slur && lang && spk_id && enc_out, "fs2midi_encode: null argument");
-  BSG_REQUIRE(B > 0 && Tt > 0 && Tt <= h->cfg.n_rel, "fs2midi_encode: B=%d T_txt=%d (rel-pos table has %d rows)", B, Tt, h->cfg.n_rel);
-  BSG_REQUIRE((dur_xs == nullptr) == (dur == nullptr), "fs2midi_encode: dur_xs and dur go together");
-  hipStream_t st = (hipStream_t)stream;
-  const long long rows = (long long)B * Tt;
-  TRY(ensure_ws(h, (size_t)rows, (size_t)B * h->cfg.num_heads * Tt * Tt, st));
-  const dim3 rg(cdiv(rows, 4)), rb(256);
+// Token-level front for the batch rows [row0, row0 + nb) of a batch of B utterances.  Only the ESM couples rows (it attends over the BATCH
+// axis, common_layers.py:853), and only through K / V = projections of LN(lang_embed[lang]) of every row (:850-853): the other rows
+// contribute their `lang` ints and nothing else.  So K / V are projected for all B rows, and everything else — Q, the attention's queries,
+// the ESM's FFN, the embedding sum, the 4-layer FFT encoder, the duration predictor — runs on the nb rows asked for.  row0 = 0, nb = B is
+// the whole batch (bsg_fs2midi_encode); a rank of a sharded run asks for its own rows (bsg_fs2midi_encode_rows): the same arithmetic
+// on an eighth of the tokens at configs[3].
+static int encode_impl(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur, const int64_t* is_slur,
+                       const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t Tt, int32_t row0, int32_t nb, float* enc_out,
+                       float* dur_xs, int64_t* dur, hipStream_t st) {
+  const long long rows = (long long)B * Tt;        // every utterance: the lang embedding and K / V
+  const long long lrows = (long long)nb * Tt;      // the rows asked for
+  const long long off = (long long)row0 * Tt;
+  TRY(ensure_ws(h, (size_t)rows, (size_t)nb * h->cfg.num_heads * Tt * Tt, st));
+  h->last_token_rows = (int)lrows;
+  const dim3 rg(cdiv(rows, 4)), lg(cdiv(lrows, 4)), rb(256);
   const float sq = sqrtf((float)H);
-  float* x0 = h->w_x;      // sqrt(H) * tok
-  float* lange = h->w_b;   // lang embedding LP
+  float* x0 = h->w_x;      // sqrt(H) * tok                [rows][H]
+  float* lange = h->w_b;   // lang embedding LP            [rows][H]
   static int esm_env = -1;   // BSG_ESM_H2W=0: the ESM's Linear layers on gemm_split_kernel and the thread-per-query attention
   if (esm_env < 0) { const char* e = getenv("BSG_ESM_H2W"); esm_env = e ? atoi(e) : 1; }
   static int esm_gemm_env = -1;
   if (esm_gemm_env < 0) { const char* e = getenv("BSG_GEMM_H2W"); esm_gemm_env = e ? atoi(e) : 1; }
   const bool esm_h2w = esm_env && esm_gemm_env && h->h2w_ok && gemm_split_enabled() && B <= 64 && h2w_supports((int)rows, H, H, 1, H) &&
-                       rows * 4 * H * 2 < (1LL << 31);
+                       h2w_supports((int)lrows, H, H, 1, H) && rows * 4 * H * 2 < (1LL << 31);
   if (esm_h2w) {
     // ---- ESM (common_layers.py:848-860) on the pre-split GEMM: every operand is written as hi / lo planes by its producer; the K and V
     // projections (both of LN(lang)) are ONE product of 512 weight rows; the attention runs one wave per (position, head)
@@ -1472,18 +1482,18 @@ extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int6
                        reinterpret_cast<_Float16*>(fp), reinterpret_cast<_Float16*>(fp) + rows * H, gemm_range_counter());
     BSG_LAUNCH_CHECK();
     TRY(ln_planes(lange, h->esm_ln1w, h->esm_ln1b, ap, rows, 1e-5f, st));
-    float* q = h->w_qkv;
+    float* q = h->w_qkv;                // [lrows][H]
     float* kvp = h->w_qkv + rows * H;   // [rows][2H]: K | V
-    TRY(linear_h2w(fp, h->p_esm_q, H, h->esm_in_b, q, nullptr, rows, ACT_NONE, nullptr, nullptr, st));
+    TRY(linear_h2w(fp + off * H, h->p_esm_q, H, h->esm_in_b, q, nullptr, lrows, ACT_NONE, nullptr, nullptr, st, 1.f, 0, rows * H));
     TRY(linear_h2w(ap, h->p_esm_kv, 2 * H, h->esm_in_b + H, kvp, nullptr, rows, ACT_NONE, nullptr, nullptr, st));
     hipLaunchKernelGGL(esm_attention_wave_kernel, dim3(cdiv(Tt * 8, 4)), dim3(256), 0, st, (const float*)q, (const float*)kvp, (const float*)(kvp + H), H,
-                       2 * H, (float*)nullptr, reinterpret_cast<_Float16*>(ap), rows * H, B, Tt, 8, (float)sqrt(1.0 / 32.0), gemm_range_counter());
+                       2 * H, (float*)nullptr, reinterpret_cast<_Float16*>(ap), lrows * H, B, nb, Tt, 8, (float)sqrt(1.0 / 32.0), gemm_range_counter());
     BSG_LAUNCH_CHECK();
     float* Mo = h->w_c;
-    TRY(linear_h2w(ap, h->p_esm_out, H, h->esm_out_b, Mo, nullptr, rows, ACT_NONE, lange, nullptr, st));       // Mo = out_proj + LP
-    TRY(ln_planes(Mo, h->esm_ln2w, h->esm_ln2b, ap, rows, 1e-5f, st));
-    TRY(linear_h2w(ap, h->p_esm_f0, H, h->esm_f0b, nullptr, fp, rows, ACT_RELU, nullptr, nullptr, st));
-    TRY(linear_h2w(fp, h->p_esm_f2, H, h->esm_f2b, h->w_a, nullptr, rows, ACT_NONE, Mo, nullptr, st));          // Fo = ffn + Mo
+    TRY(linear_h2w(ap, h->p_esm_out, H, h->esm_out_b, Mo, nullptr, lrows, ACT_NONE, lange + off * H, nullptr, st));   // Mo = out_proj + LP
+    TRY(ln_planes(Mo, h->esm_ln2w, h->esm_ln2b, ap, lrows, 1e-5f, st));
+    TRY(linear_h2w(ap, h->p_esm_f0, H, h->esm_f0b, nullptr, fp, lrows, ACT_RELU, nullptr, nullptr, st));
+    TRY(linear_h2w(fp, h->p_esm_f2, H, h->esm_f2b, h->w_a, nullptr, lrows, ACT_NONE, Mo, nullptr, st));          // Fo = ffn + Mo
   } else {
   hipLaunchKernelGGL(embed_tokens_kernel, rg, rb, 0, st, (const long long*)txt, (const long long*)lang, h->Etok, h->Elang, x0, lange, rows, sq,
                      (_Float16*)nullptr, (_Float16*)nullptr, (unsigned*)nullptr);
@@ -1491,52 +1501,81 @@ extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int6
   // ---- ESM (common_layers.py:848-860): attention over the batch axis
   float* lpn = h->w_a;
   TRY(ln(lange, h->esm_ln1w, h->esm_ln1b, lpn, nullptr, rows, 1e-5f, st));
-  float* q = h->w_qkv;
-  float* k = h->w_qkv + rows * H;
+  float* q = h->w_qkv;                     // [lrows][H]
+  float* k = h->w_qkv + rows * H;          // [rows][H]
   float* v = h->w_qkv + 2 * rows * H;
-  TRY(linear(x0, h->esm_in_w, h->esm_in_b, q, rows, H, H, ACT_NONE, nullptr, nullptr, st));
+  TRY(linear(x0 + off * H, h->esm_in_w, h->esm_in_b, q, lrows, H, H, ACT_NONE, nullptr, nullptr, st));
   TRY(linear(lpn, h->esm_in_w + (size_t)H * H, h->esm_in_b + H, k, rows, H, H, ACT_NONE, nullptr, nullptr, st));
   TRY(linear(lpn, h->esm_in_w + (size_t)2 * H * H, h->esm_in_b + 2 * H, v, rows, H, H, ACT_NONE, nullptr, nullptr, st));
   float* att = h->w_a;   // lpn is dead once k, v exist
   {
-    const long long total = rows * 8;
+    const long long total = lrows * 8;
     hipLaunchKernelGGL(esm_attention_kernel<32>, dim3(cdiv(total, 128)), dim3(128), 0, st, (const float*)q, (const float*)k,
-                       (const float*)v, att, B, Tt, 8, (float)sqrt(1.0 / 32.0));
+                       (const float*)v, att, B, nb, Tt, 8, (float)sqrt(1.0 / 32.0));
     BSG_LAUNCH_CHECK();
   }
   float* Mo = h->w_c;
-  TRY(linear(att, h->esm_out_w, h->esm_out_b, Mo, rows, H, H, ACT_NONE, lange, nullptr, st));       // Mo = out_proj + LP
-  TRY(ln(Mo, h->esm_ln2w, h->esm_ln2b, h->w_a, nullptr, rows, 1e-5f, st));
-  TRY(linear(h->w_a, h->esm_f0w, h->esm_f0b, h->w_b, rows, H, H, ACT_RELU, nullptr, nullptr, st));
-  TRY(linear(h->w_b, h->esm_f2w, h->esm_f2b, h->w_a, rows, H, H, ACT_NONE, Mo, nullptr, st));      // Fo = ffn + Mo
+  TRY(linear(att, h->esm_out_w, h->esm_out_b, Mo, lrows, H, H, ACT_NONE, lange + off * H, nullptr, st));       // Mo = out_proj + LP
+  float* t1 = h->w_a;
+  float* t2 = h->w_qkv;   // (q, k, v are dead; w_b still holds the lang embedding of every row)
+  TRY(ln(Mo, h->esm_ln2w, h->esm_ln2b, t1, nullptr, lrows, 1e-5f, st));
+  TRY(linear(t1, h->esm_f0w, h->esm_f0b, t2, lrows, H, H, ACT_RELU, nullptr, nullptr, st));
+  TRY(linear(t2, h->esm_f2w, h->esm_f2b, h->w_a, lrows, H, H, ACT_NONE, Mo, nullptr, st));      // Fo = ffn + Mo
   }
-  // ---- sum of embeddings, *sqrt(H) + reversed positional table, mask
+  // ---- sum of embeddings, *sqrt(H) + reversed positional table, mask (the rows asked for; row0 * Tt is a multiple of Tt: the position of a
+  // row inside its utterance is unchanged)
   float* x = h->w_c;
-  hipLaunchKernelGGL(embed_finish_kernel, rg, rb, 0, st, (const float*)x0, (const float*)h->w_a, (const long long*)txt,
-                     (const long long*)pitch_midi, midi_dur, (const long long*)is_slur, h->Emidi, h->Wdur, h->bdur, h->Eslur,
-                     h->rel_table, x, h->w_keep, rows, Tt, sq);
+  hipLaunchKernelGGL(embed_finish_kernel, lg, rb, 0, st, (const float*)(x0 + off * H), (const float*)h->w_a, (const long long*)txt + off,
+                     (const long long*)pitch_midi + off, midi_dur + off, (const long long*)is_slur + off, h->Emidi, h->Wdur, h->bdur, h->Eslur,
+                     h->rel_table, x, h->w_keep, lrows, Tt, sq);
   BSG_LAUNCH_CHECK();
-  TRY(fft_stack(h, h->enc, h->enc_lnw, h->enc_lnb, h->cfg.enc_ffn_kernel_size, x, h->w_keep, B, Tt, st));
-  BSG_HIP(hipMemcpyAsync(enc_out, x, rows * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+  TRY(fft_stack(h, h->enc, h->enc_lnw, h->enc_lnb, h->cfg.enc_ffn_kernel_size, x, h->w_keep, nb, Tt, st));
+  BSG_HIP(hipMemcpyAsync(enc_out, x, lrows * H * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (dur) {
     // duration predictor (tts_modules.py:108-133) on (enc + spk) * keep
     float* a = h->w_a;
     float* b = h->w_b;
-    hipLaunchKernelGGL(add_spk_kernel, rg, rb, 0, st, (const float*)x, (const long long*)spk_id, h->Espk, h->w_keep, a, rows, Tt);
+    hipLaunchKernelGGL(add_spk_kernel, lg, rb, 0, st, (const float*)x, (const long long*)spk_id + row0, h->Espk, h->w_keep, a, lrows, Tt);
     BSG_LAUNCH_CHECK();
     const int ks = h->cfg.dur_kernel;
     for (int l = 0; l < h->cfg.dur_layers; ++l) {
       GemmArgs g{};
       g.A = a; g.B = h->dur_conv[l]; g.C = b; g.M = Tt; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.trans_b = 1;
       g.taps = ks; g.tap_shift0 = -(ks / 2); g.sTapB = (long long)H * H; g.bias_n = h->dur_convb[l]; g.alpha = 1.f;
-      g.act = ACT_RELU; g.batch = B; g.sA = (long long)Tt * H; g.sC = (long long)Tt * H;
+      g.act = ACT_RELU; g.batch = nb; g.sA = (long long)Tt * H; g.sC = (long long)Tt * H;
       TRY(launch_gemm(g, st));
-      TRY(ln(b, h->dur_lnw[l], h->dur_lnb[l], a, h->w_keep, rows, 1e-12f, st));
+      TRY(ln(b, h->dur_lnw[l], h->dur_lnb[l], a, h->w_keep, lrows, 1e-12f, st));
     }
-    TRY(linear(a, h->dur_lin_w, h->dur_lin_b, dur_xs, rows, 1, H, ACT_NONE, nullptr, h->w_keep, st));
-    hipLaunchKernelGGL(dur_from_log_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, (const float*)dur_xs, (long long*)dur, rows);
+    TRY(linear(a, h->dur_lin_w, h->dur_lin_b, dur_xs, lrows, 1, H, ACT_NONE, nullptr, h->w_keep, st));
+    hipLaunchKernelGGL(dur_from_log_kernel, dim3(cdiv(lrows, 256)), dim3(256), 0, st, (const float*)dur_xs, (long long*)dur, lrows);
     BSG_LAUNCH_CHECK();
   }
+  return BSG_OK;
+}
+
+extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
+                                  const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t Tt,
+                                  float* enc_out, float* dur_xs, int64_t* dur, void* stream) {
+  BSG_REQUIRE(h && txt && pitch_midi && midi_dur && is_slur && lang && spk_id && enc_out, "fs2midi_encode: null argument");
+  BSG_REQUIRE(B > 0 && Tt > 0 && Tt <= h->cfg.n_rel, "fs2midi_encode: B=%d T_txt=%d (rel-pos table has %d rows)", B, Tt, h->cfg.n_rel);
+  BSG_REQUIRE((dur_xs == nullptr) == (dur == nullptr), "fs2midi_encode: dur_xs and dur go together");
+  return encode_impl(h, txt, pitch_midi, midi_dur, is_slur, lang, spk_id, B, Tt, 0, B, enc_out, dur_xs, dur, (hipStream_t)stream);
+}
+
+extern "C" int bsg_fs2midi_encode_rows(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
+                                       const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t Tt,
+                                       int32_t row0, int32_t n_rows, float* enc_out, float* dur_xs, int64_t* dur, void* stream) {
+  BSG_REQUIRE(h && txt && pitch_midi && midi_dur && is_slur && lang && spk_id && enc_out, "fs2midi_encode_rows: null argument");
+  BSG_REQUIRE(B > 0 && Tt > 0 && Tt <= h->cfg.n_rel, "fs2midi_encode_rows: B=%d T_txt=%d (rel-pos table has %d rows)", B, Tt, h->cfg.n_rel);
+  BSG_REQUIRE(row0 >= 0 && n_rows > 0 && row0 + n_rows <= B, "fs2midi_encode_rows: rows [%d, %d) of a batch of %d", row0, row0 + n_rows, B);
+  BSG_REQUIRE((dur_xs == nullptr) == (dur == nullptr), "fs2midi_encode_rows: dur_xs and dur go together");
+  return encode_impl(h, txt, pitch_midi, midi_dur, is_slur, lang, spk_id, B, Tt, row0, n_rows, enc_out, dur_xs, dur, (hipStream_t)stream);
+}
+
+extern "C" int bsg_fs2midi_last_rows(const bsg_fs2midi* h, int32_t* token_rows, int32_t* stack_rows) {
+  BSG_REQUIRE(h && token_rows && stack_rows, "fs2midi_last_rows: null argument");
+  *token_rows = h->last_token_rows;
+  *stack_rows = h->last_stack_rows;
   return BSG_OK;
 }
 

@@ -264,10 +264,12 @@ class FastSpeech2MIDI(nn.Module):
 
     # ------------------------------------------------------------------ reference forward (fs2.py:94-197)
     @torch.no_grad()
-    def encode(self, txt_tokens, spk_embed, predict_dur=False, **kwargs):
+    def encode(self, txt_tokens, spk_embed, predict_dur=False, rows=None, **kwargs):
         """Token-level front: embeddings + ESM + FFT encoder (+ duration predictor)   (fs2.py:111-165).
-        ESM attends over the batch axis (common_layers.py:853), so a sharded run must call this with
-        the *whole* batch and slice rows afterwards."""
+        ESM attends over the batch axis (common_layers.py:853): the inputs are always the WHOLE batch's.  ``rows`` (a contiguous slice,
+        extension): the outputs for these batch rows only — K / V of the ESM (projections of LN(lang_embed[lang]), :850-853, the only thing
+        other rows contribute) are still formed for every row; Q, the ESM's FFN, the encoder and the duration predictor run on the rows
+        asked for (bsg_fs2midi_encode_rows; SURVEY.md §8e: a rank of a sharded batch encodes its own utterances, not everybody's)."""
         lib = _lib.load()
         h = self.handle()
         dev = txt_tokens.device
@@ -281,14 +283,32 @@ class FastSpeech2MIDI(nn.Module):
         pitch_midi, lang, is_slur = i64(kwargs['pitch_midi']), i64(kwargs['lang']), i64(kwargs['is_slur'])
         midi_dur = kwargs['midi_dur'].to(dev, torch.float32).contiguous()
         spk = i64(spk_embed)
-        enc_out = torch.empty(B, Tt, self.hidden_size, device=dev)
-        dur_xs = torch.empty(B, Tt, device=dev) if predict_dur else None
-        dur = torch.empty(B, Tt, dtype=torch.long, device=dev) if predict_dur else None
+        row0, nb = 0, B
+        if rows is not None:
+            row0, stop, stride = rows.indices(B)
+            if stride != 1 or stop <= row0:
+                raise _lib.BsgError('rows must be a contiguous non-empty slice')
+            nb = stop - row0
+        enc_out = torch.empty(nb, Tt, self.hidden_size, device=dev)
+        dur_xs = torch.empty(nb, Tt, device=dev) if predict_dur else None
+        dur = torch.empty(nb, Tt, dtype=torch.long, device=dev) if predict_dur else None
         with torch.cuda.device(dev):
-            _lib.check(lib.bsg_fs2midi_encode(h, _lib.ptr(txt), _lib.ptr(pitch_midi), _lib.ptr(midi_dur), _lib.ptr(is_slur),
-                                              _lib.ptr(lang), _lib.ptr(spk), B, Tt, _lib.ptr(enc_out), _lib.ptr(dur_xs),
-                                              _lib.ptr(dur), _lib.stream_ptr()), 'bsg_fs2midi_encode')
+            if rows is None:
+                _lib.check(lib.bsg_fs2midi_encode(h, _lib.ptr(txt), _lib.ptr(pitch_midi), _lib.ptr(midi_dur), _lib.ptr(is_slur),
+                                                  _lib.ptr(lang), _lib.ptr(spk), B, Tt, _lib.ptr(enc_out), _lib.ptr(dur_xs),
+                                                  _lib.ptr(dur), _lib.stream_ptr()), 'bsg_fs2midi_encode')
+            else:
+                _lib.check(lib.bsg_fs2midi_encode_rows(h, _lib.ptr(txt), _lib.ptr(pitch_midi), _lib.ptr(midi_dur), _lib.ptr(is_slur),
+                                                       _lib.ptr(lang), _lib.ptr(spk), B, Tt, row0, nb, _lib.ptr(enc_out),
+                                                       _lib.ptr(dur_xs), _lib.ptr(dur), _lib.stream_ptr()), 'bsg_fs2midi_encode_rows')
         return dict(enc_out=enc_out, txt=txt, spk=spk, dur_xs=dur_xs, dur=dur)
+
+    def last_rows(self):
+        """-> (token rows the last encode ran its encoder on, rows of the last FFT stack): test introspection."""
+        from ctypes import c_int32
+        a, b = c_int32(), c_int32()
+        _lib.check(_lib.load().bsg_fs2midi_last_rows(self.handle(), byref(a), byref(b)), 'bsg_fs2midi_last_rows')
+        return a.value, b.value
 
     @torch.no_grad()
     def regulate(self, enc):
@@ -326,14 +346,17 @@ class FastSpeech2MIDI(nn.Module):
 
     def forward(self, txt_tokens, mel2ph=None, spk_embed=None, ref_mels=None, f0=None, uv=None, energy=None,
                 skip_decoder=False, spk_embed_dur_id=None, spk_embed_f0_id=None, infer=False, rows=None, **kwargs):
-        """``rows`` (slice, extension): decode only these batch rows — the token-level front still sees the whole
-        batch, which is what keeps a sharded run identical to the unsharded reference."""
+        """``rows`` (slice, extension): generate only these batch rows — what a rank of a sharded run asks for.  The inputs
+        stay the WHOLE batch's: the ESM attends over the batch axis, so every row's ``lang`` enters this rank's K / V; with ``mel2ph``
+        given nothing else of the other rows is computed (``encode(rows=...)``).  With predicted durations the frame count T is the
+        maximum over the whole batch (tts_modules.py:182), so the token-level front then runs on every row and is sliced afterwards."""
         return _lib.range_guarded(lambda: self._forward(txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs),
                                   'FastSpeech2MIDI.forward', device=self)
 
     def _forward(self, txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs):
         ret = {}
-        enc = self.encode(txt_tokens, spk_embed, predict_dur=mel2ph is None, **kwargs)
+        local = rows is not None and mel2ph is not None      # the token front on this rank's rows only
+        enc = self.encode(txt_tokens, spk_embed, predict_dur=mel2ph is None, rows=rows if local else None, **kwargs)
         if mel2ph is None:
             mel2ph = self.regulate(enc)
             ret['dur'] = enc['dur_xs'][:, :, None]
@@ -341,7 +364,9 @@ class FastSpeech2MIDI(nn.Module):
         # (with mel2ph given the reference also runs the predictor for its training loss; inference does not use it)
         enc_out, spk, speechsing = enc['enc_out'], enc['spk'], kwargs['speechsing']
         if rows is not None:
-            enc_out, spk, speechsing, mel2ph = enc_out[rows], spk[rows], speechsing[rows], mel2ph[rows]
+            if not local:
+                enc_out = enc_out[rows]
+            spk, speechsing, mel2ph = spk[rows], speechsing[rows], mel2ph[rows]
         ret['mel2ph'] = mel2ph
         ret['decoder_inp'], mel_out = self.decode(enc_out, mel2ph, spk, speechsing, skip_decoder)
         if not skip_decoder:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BSG_ABI_VERSION 6
+#define BSG_ABI_VERSION 7
 
 #define BSG_OK 0
 #define BSG_EINVAL (-22)  /* bad argument / shape the kernels do not support            */
@@ -269,6 +269,20 @@ void bsg_fs2midi_destroy(bsg_fs2midi* h);
 int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
                        const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B,
                        int32_t T_txt, float* enc_out, float* dur_xs, int64_t* dur, void* stream);
+
+/* ABI v7 (one rank of a sharded batch): the same front for the batch rows [row0, row0 + n_rows) only.  The inputs are the
+ * WHOLE batch's ([B,T_txt] / [B]); enc_out [n_rows,T_txt,H], dur_xs / dur [n_rows,T_txt].  Only the ESM couples the utterances of a batch
+ * (it attends over the batch axis, common_layers.py:853) and only through K / V = projections of LN(lang_embed[lang]) (:850-853): K / V
+ * are projected for all B rows; Q, the ESM's FFN, the embedding sum, the FFT encoder (tts_modules.py:312-328) and the duration predictor
+ * run on the n_rows rows asked for.  Row for row the result equals bsg_fs2midi_encode's on the whole batch (same kernels, same order of
+ * summation per row).  row0 = 0, n_rows = B is bsg_fs2midi_encode. */
+int bsg_fs2midi_encode_rows(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
+                            const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t T_txt,
+                            int32_t row0, int32_t n_rows, float* enc_out, float* dur_xs, int64_t* dur, void* stream);
+
+/* ABI v7, introspection (tests): token rows (utterances x T_txt) the last encode ran its ENCODER on, and rows of the last FFT stack
+ * (encoder or decoder) — how a test sees that a rank's front did not encode the other ranks' utterances. */
+int bsg_fs2midi_last_rows(const bsg_fs2midi* h, int32_t* token_rows, int32_t* stack_rows);
 
 /* mel2ph [B,T] from dur [B,T_txt] (padded tokens, txt == 0, count 0 when txt != NULL); T = max_b sum(dur). */
 int bsg_length_regulator(const int64_t* dur, const int64_t* txt, int64_t* mel2ph, int32_t B, int32_t T_txt,

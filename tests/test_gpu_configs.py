@@ -111,8 +111,8 @@ def test_config2_bf16_full_size_vs_emulating_oracle():
 
 def test_config3_rank_rows_of_64():
     """BASELINE configs[3] as ONE rank sees it (B_total = 64 utterances sharded 8 per GPU over 8 GPUs): the token-level front
-    (embeddings, ESM over the batch axis — common_layers.py:848-860 — and the encoder) runs on all 64 rows, the frame-level part and the
-    100-step sampler on this rank's rows 8..15 only (shallow_diffusion_tts.py:230-273 with rows=slice(8, 16)).
+    (embeddings, ESM over the batch axis — common_layers.py:848-860 — with K / V from all 64 rows' lang ids, the encoder on the rank's rows
+    8..15: bsg_fs2midi_encode_rows), the frame-level part and the 100-step sampler on this rank's rows 8..15 only (shallow_diffusion_tts.py:230-273 with rows=slice(8, 16)).
       * against the same rows of the UNSHARDED B=64 run on this GPU (the 8-row shard takes 32-frame tiles, the unsharded run 64-frame
         tiles in four launch groups: another summation order of the same sums): <= 1e-5 of the de-normalised mel;
       * against the CPU oracle with the full-batch front and the same supplied noise: <= 1e-3 (north_star's bar)."""
@@ -131,6 +131,8 @@ def test_config3_rank_rows_of_64():
     part = model(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True, noise=nz, rows=rows, **kw)
     path_part = model.denoise_fn.last_path()
     torch.cuda.synchronize()
+    # round 6: the rank's token-level front encodes ITS 8 utterances (K / V of the ESM from all 64 rows' lang ids), not the batch's 64
+    assert model.fs2.last_rows()[0] == 8 * Tt, model.fs2.last_rows()
     assert part['mel_out'].shape == (8, T, 80) and full.shape == (B, T, 80)
     dev_shard = maxabs(part['mel_out'], full[rows])
     sd = cpu_sd(model)

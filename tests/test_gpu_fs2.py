@@ -63,6 +63,41 @@ def test_fs2_larger_vs_oracle(fs2):
         assert maxabs(got['mel_out'], want['mel_out']) <= 2e-4
 
 
+@pytest.mark.parametrize('B,Tt,Tm,rows,ragged', [(3, 12, 64, slice(1, 2), True), (5, 30, 301, slice(2, 5), True), (64, 100, 200, slice(8, 16), False),
+                                                 (8, 40, 120, slice(0, 8), False)])
+def test_fs2_rank_rows_front(fs2, B, Tt, Tm, rows, ragged):
+    """a rank's token-level front (bsg_fs2midi_encode_rows) — K / V of the ESM from EVERY row's lang ids (the ESM attends over the
+    batch axis, common_layers.py:848-860), everything else on the rank's rows only — equals the same rows of the whole-batch front
+    (bsg_fs2midi_encode), and the oracle with the whole-batch front; the encoder ran on the rank's token rows, not on the batch's."""
+    inp = synth.synth_inputs(B, Tt, Tm, seed=11, ragged=ragged)
+    inp['lang'] = np.random.RandomState(5).randint(0, 2, (B, Tt)).astype(np.int64)      # rows differ in lang: K / V differ by row
+    d = {k: torch.from_numpy(v).cuda() for k, v in inp.items()}
+    kw = {k: d[k] for k in ('pitch_midi', 'midi_dur', 'is_slur', 'lang', 'speechsing')}
+    full = fs2.encode(d['txt_tokens'], d['spk_embed'], predict_dur=True, **kw)
+    assert fs2.last_rows()[0] == B * Tt
+    part = fs2.encode(d['txt_tokens'], d['spk_embed'], predict_dur=True, rows=rows, **kw)
+    nb = rows.stop - rows.start
+    assert fs2.last_rows()[0] == nb * Tt, 'the rank front encoded rows it does not own'
+    assert part['enc_out'].shape == (nb, Tt, 256)
+    assert maxabs(part['enc_out'], full['enc_out'][rows]) <= 5e-6
+    assert maxabs(part['dur_xs'], full['dur_xs'][rows]) <= 1e-5      # (the predictor's GEMM picks its tiles by the batch: another order of the same sums)
+    assert torch.equal(part['dur'], full['dur'][rows])
+    # the whole forward with rows: against the oracle's whole-batch front sliced to the rows
+    got = fs2(d['txt_tokens'], d['mel2ph'], d['spk_embed'], None, None, None, None, infer=True, rows=rows, **kw)
+    assert fs2.last_rows()[0] == nb * Tt
+    want = ofs2.fs2_forward(cpu_sd(fs2, 'fs2.'), {k: torch.from_numpy(v) for k, v in inp.items()}, 'fs2.', rows=rows)
+    assert maxabs(got['decoder_inp'], want['decoder_inp']) <= 1e-4
+    assert maxabs(got['mel_out'], want['mel_out']) <= 2e-4
+    # a front that ignored the other rows' lang would be wrong by far more than that (tests/test_dist_cpu.py shows the same on the oracle)
+    alone = fs2.encode(d['txt_tokens'][rows], d['spk_embed'][rows], predict_dur=False, **{k: v[rows] for k, v in kw.items() if k != 'speechsing'})
+    if B > nb:
+        assert maxabs(alone['enc_out'], full['enc_out'][rows]) > 1e-3
+    # predicted durations with rows: T is the batch's maximum, so the front runs on every row (documented) and is sliced
+    pred = fs2(d['txt_tokens'], None, d['spk_embed'], None, None, None, None, infer=True, rows=rows, **kw)
+    allp = fs2(d['txt_tokens'], None, d['spk_embed'], None, None, None, None, infer=True, **kw)
+    assert torch.equal(pred['mel2ph'], allp['mel2ph'][rows]) and maxabs(pred['mel_out'], allp['mel_out'][rows]) <= 1e-5
+
+
 def test_length_regulator_hand_case(gold):
     from bisinger_amd import _lib
     g = gold('fs2')
