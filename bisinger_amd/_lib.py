@@ -113,8 +113,13 @@ _SIGS = {
                                c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, c_void_p]),
     'bsg_gemm_set_split': (c_int32, [c_int32]),
     'bsg_diffnet_set_h2': (c_int32, [c_void_p, c_int32]),
+    'bsg_diffnet_set_h2q': (c_int32, [c_void_p, c_int32]),
     'bsg_gemm_range_events': (c_int32, [POINTER(c_int32), c_int32, c_void_p]),
     'bsg_gemm_range_events_async': (c_int32, [c_void_p, c_void_p]),
+    'bsg_handle_range_events': (c_int32, [c_int32, c_void_p, POINTER(c_int32), c_int32, c_void_p]),
+    'bsg_handle_range_events_async': (c_int32, [c_int32, c_void_p, c_void_p, c_void_p]),
+    'bsg_handle_set_gemm_split': (c_int32, [c_int32, c_void_p, c_int32]),
+    'bsg_handle_get_gemm_split': (c_int32, [c_int32, c_void_p, POINTER(c_int32)]),
     'bsg_gemm_presplit_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                         c_int32, c_void_p]),
 }
@@ -142,15 +147,32 @@ def load():
     return lib
 
 
-range_retries = 0      # calls repeated on the fp32 matrix pipe because an operand left the fp16 range of the split-fp16 GEMMs
-_range_depth = 0       # > 0 inside a range_guarded() call: nested entries leave the check to the outermost one
-_range_strikes = 0     # range events seen by this process; from RANGE_STRIKES_MAX on the GEMMs stay on the fp32 matrix pipe
-RANGE_STRIKES_MAX = 3
+range_retries = 0      # calls repeated on the fp32 matrix pipe because an operand left the fp16 range of the split-fp16 GEMMs (process total)
+RANGE_STRIKES_MAX = 3  # range events of ONE handle after which its GEMMs stay on the fp32 matrix pipe
+HANDLE_KINDS = {'diffnet': 0, 'fs2midi': 1, 'hifigan': 2, 'pitchext': 3, 'fftden': 4}     # include/bisinger_hip.h BSG_HANDLE_*
+
+import threading  # noqa: E402
+import weakref  # noqa: E402
+
+_tls = threading.local()      # per host thread: nesting depth of range_guarded, the handles inside the outermost call, "this is the repeated pass"
+
+
+def _state():
+    st = _tls
+    if not hasattr(st, 'depth'):
+        st.depth, st.owners, st.in_retry = 0, [], False
+    return st
+
+
+def in_retry():
+    """True while range_guarded runs the REPEATED pass of the calling thread (the handles that tripped are on the fp32 matrix pipe):
+    handles keep their fallbacks then (DiffNet.prepare)."""
+    return _state().in_retry
 
 
 def on_device(device):
-    """Context: `device` (a torch.device, a tensor, a module, or None = leave the ambient device) current.  The guard counters live
-    per device and are read on the current stream OF that device: a model on cuda:1 while cuda:0 is current must not wait on, read
+    """Context: `device` (a torch.device, a tensor, a module, or None = leave the ambient device) current.  A handle's guard words live
+    on ITS device and are read on the current stream OF that device: a model on cuda:1 while cuda:0 is current must not wait on, read
     or reset cuda:0's state."""
     import contextlib
     import torch
@@ -169,8 +191,9 @@ def on_device(device):
 
 
 def gemm_range_take(device=None):
-    """Wait for the current stream of `device`; number of split-fp16 GEMM waves that staged an out-of-range operand there since the
-    last take (reset)."""
+    """PROCESS-WIDE word (the handle-less entries bsg_gemm_f32 / bsg_gemm_presplit_f32 count into it; handles have their own —
+    GemmGuarded): wait for the current stream of `device`; number of split-fp16 GEMM waves that staged an out-of-range operand there
+    since the last take (reset)."""
     n = c_int32()
     with on_device(device):
         check(load().bsg_gemm_range_events(ctypes.byref(n), 1, stream_ptr()), 'bsg_gemm_range_events')
@@ -178,15 +201,67 @@ def gemm_range_take(device=None):
 
 
 def gemm_range_peek(device=None):
-    """The same count without resetting it (a nested guard looks at it and leaves the take to the outermost one)."""
+    """The same count without resetting it."""
     n = c_int32()
     with on_device(device):
         check(load().bsg_gemm_range_events(ctypes.byref(n), 0, stream_ptr()), 'bsg_gemm_range_events')
     return n.value
 
 
-_in_retry = False      # True while range_guarded runs the REPEATED pass (every GEMM on the fp32 matrix pipe): handles keep their fallbacks
-_restore_split_after = False   # deferred mode: a detection moved the GEMMs to the fp32 pipe for the next call; that call puts them back
+class GemmGuarded:
+    """Mixin of every module that owns a library handle (``self._h``; ``GUARD_KIND`` names its type): the range guard of the handle's
+    split-fp16 GEMMs / fused attention / ResBlock convolutions is the HANDLE's — its own device word, its own switch to the fp32 matrix
+    pipe, its own strike count (include/bisinger_hip.h bsg_handle_*).  An out-of-range input to one model demotes that model only."""
+    GUARD_KIND = None
+
+    def _guard_args(self):
+        h = getattr(self, '_h', None)
+        return (HANDLE_KINDS[self.GUARD_KIND], h) if h is not None else None
+
+    def gemm_range_take(self):
+        """Wait for the current stream of the handle's device; waves of this handle's kernels that staged an operand beyond the fp16
+        range (|v| >= 4062) since the last take; resets the word.  0 when the handle does not exist yet."""
+        a = self._guard_args()
+        if a is None:
+            return 0
+        n = c_int32()
+        with on_device(self):
+            check(load().bsg_handle_range_events(a[0], a[1], ctypes.byref(n), 1, stream_ptr()), 'bsg_handle_range_events')
+        return n.value
+
+    def gemm_range_peek(self):
+        a = self._guard_args()
+        if a is None:
+            return 0
+        n = c_int32()
+        with on_device(self):
+            check(load().bsg_handle_range_events(a[0], a[1], ctypes.byref(n), 0, stream_ptr()), 'bsg_handle_range_events')
+        return n.value
+
+    def set_gemm_split(self, enable):
+        """False: this handle's GEMMs on the fp32 matrix pipe (remembered across a re-creation of the handle); True: split-fp16 again."""
+        self._gemm_split_off = not enable
+        a = self._guard_args()
+        if a is not None:
+            check(load().bsg_handle_set_gemm_split(a[0], a[1], int(bool(enable))), 'bsg_handle_set_gemm_split')
+
+    def gemm_split_enabled(self):
+        """The effective switch: this handle's AND the process-wide one (BSG_GEMM_SPLIT, bsg_gemm_set_split)."""
+        a = self._guard_args()
+        if a is None:
+            return not getattr(self, '_gemm_split_off', False)
+        v = c_int32()
+        check(load().bsg_handle_get_gemm_split(a[0], a[1], ctypes.byref(v)), 'bsg_handle_get_gemm_split')
+        return bool(v.value)
+
+    def _apply_guard_state(self):
+        """After (re)creating the handle: a handle that was demoted stays demoted."""
+        if getattr(self, '_gemm_split_off', False):
+            self.set_gemm_split(False)
+
+    @property
+    def gemm_range_strikes(self):
+        return getattr(self, '_gemm_strikes', 0)
 
 
 def guard_mode():
@@ -245,9 +320,7 @@ class _DeferredWord:
         return out
 
 
-_deferred_gemm = {}    # device index -> _DeferredWord(1)
-import weakref  # noqa: E402
-_deferred_objs = weakref.WeakSet()   # handles (DiffNet) with health words of their own: _check_deferred_own() raises for the previous call
+_deferred_objs = weakref.WeakSet()   # handles with reads in flight (guard_mode 'deferred'): their GEMM word, and DiffNet's health words
 
 
 def _device_index(device):
@@ -256,31 +329,37 @@ def _device_index(device):
         return torch.cuda.current_device()
 
 
+def _split_env_on():
+    return os.environ.get('BSG_GEMM_SPLIT', '1') != '0'
+
+
 def check_deferred(device=None, block=False):
     """Deferred guard mode: raise BsgError if a guarded call on `device` whose work has completed since the last check left an invalid
-    result — a split-fp16 GEMM staged an operand beyond the fp16 range (the GEMMs are then on the fp32 matrix pipe for the next call), or
-    one of the registered handles (DiffNet) reports a give-up / a range event.  Never waits for the GPU unless block=True (then every
-    pending read is waited for: call it before trusting the last results of a stream of requests).  The counters are per DEVICE: with
-    several streams in flight an event cannot be attributed to one of them — treat every result issued since the last clean check as
-    suspect."""
-    global _range_strikes, range_retries, _restore_split_after
+    result — a split-fp16 GEMM of some handle staged an operand beyond the fp16 range (THAT handle's GEMMs are then on the fp32 matrix
+    pipe for the next call), or a DiffNet handle reports a give-up / a range event of its stack launch.  Never waits for the GPU unless
+    block=True (then every pending read is waited for: call it before trusting the last results of a stream of requests).  With several
+    streams in flight an event cannot be attributed to one of them — treat every result issued on the handle since the last clean
+    check as suspect."""
+    global range_retries
     idx = _device_index(device)
     errs = []
-    rec = _deferred_gemm.get(idx)
-    if rec is not None and rec.armed():
-        n = sum(w[0] for w in rec.take(block))
-        if n:
-            gemm_range_take(device)      # waits for the stream and resets the counter;
-            rec.drop_pending()           # reads enqueued before this point repeat the same (cumulative) count
-            with on_device(device):
-                check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
-            _range_strikes += 1
-            range_retries += 1
-            _restore_split_after = _range_strikes < RANGE_STRIKES_MAX and os.environ.get('BSG_GEMM_SPLIT', '1') != '0'
-            errs.append(f'{n} split-fp16 GEMM waves of a PREVIOUS call staged an operand beyond the fp16 range (|v| >= 4062): its result '
-                        f'was invalid (guard_mode=deferred).  Every GEMM is on the fp32 matrix pipe for the next call: repeat the work')
     for obj in list(_deferred_objs):      # one error for everything the previous call left, whichever entry looks first
-        if _device_index(obj) == idx:
+        if _device_index(obj) != idx:
+            continue
+        rec = getattr(obj, '_deferred_gemm', None)
+        if rec is not None and rec.armed():
+            n = sum(w[0] for w in rec.take(block))
+            if n:
+                obj.gemm_range_take()        # waits for the stream and resets the word;
+                rec.drop_pending()           # reads enqueued before this point repeat the same (cumulative) count
+                obj.set_gemm_split(False)
+                obj._gemm_strikes = obj.gemm_range_strikes + 1
+                range_retries += 1
+                obj._restore_split_after = obj._gemm_strikes < RANGE_STRIKES_MAX and _split_env_on()
+                errs.append(f'{n} split-fp16 GEMM waves of a PREVIOUS call on this {type(obj).__name__} handle staged an operand beyond the '
+                            f'fp16 range (|v| >= 4062): its result was invalid (guard_mode=deferred).  The handle\'s GEMMs are on the fp32 '
+                            f'matrix pipe for the next call: repeat the work')
+        if hasattr(obj, '_check_deferred_own'):
             try:
                 obj._check_deferred_own(block)
             except BsgError as e:
@@ -289,68 +368,117 @@ def check_deferred(device=None, block=False):
         raise BsgError(' | '.join(errs))
 
 
-def _deferred_enqueue(device):
-    idx = _device_index(device)
-    rec = _deferred_gemm.get(idx)
-    if rec is None:
-        rec = _deferred_gemm[idx] = _DeferredWord(1)
-    with on_device(device):
-        check(load().bsg_gemm_range_events_async(c_void_p(rec.next_buf().data_ptr()), stream_ptr()), 'bsg_gemm_range_events_async')
-        rec.arm()
+def _deferred_enqueue(owners):
+    for o in owners:
+        a = o._guard_args()
+        if a is None:
+            continue
+        rec = getattr(o, '_deferred_gemm', None)
+        if rec is None:
+            rec = o._deferred_gemm = _DeferredWord(1)
+        with on_device(o):
+            check(load().bsg_handle_range_events_async(a[0], a[1], c_void_p(rec.next_buf().data_ptr()), stream_ptr()), 'bsg_handle_range_events_async')
+            rec.arm()
+        _deferred_objs.add(o)
 
 
-def range_guarded(run, what, on_retry=None, device=None):
-    """Every public entry that may enqueue split-fp16 products outside the residual stack (FS2 linears and fused attention, the
-    conditioner / input projections, HiFi-GAN's ResBlock pairs, PitchExtractor, the FFT denoiser) goes through here, so that an operand
-    beyond the fp16 range of the split (|v| >= 4062 after scaling: counted by the kernels, never clipped) cannot leave the call as a
-    silent NaN: the OUTERMOST guarded call waits for its stream once, and on an event moves every GEMM to the fp32 matrix pipe
-    (bsg_gemm_set_split(0)), warns and runs `run()` again (`on_retry()` first restores what run() consumed).  The split form comes
-    back for the next call — the event was a property of this input — until RANGE_STRIKES_MAX events have been seen in the process.
-    Inside a stream capture nothing can wait: the counter is left for the next guarded call (which then repeats its own work).
-    `device`: where the guarded work runs (device, tensor or module): the counter of THAT device is read on ITS current stream.
-    guard_mode 'deferred' (see guard_mode()): no wait; the previous call's counter is looked at instead, and a BsgError raised for it."""
-    global _range_depth, range_retries, _range_strikes, _in_retry, _restore_split_after
+def _take_all(owners, device):
+    """ONE wait for everything the outermost call enqueued: the words of all its handles are copied to pinned host memory behind the work,
+    the stream is waited for once, and only the words that are non-zero are reset.  -> [(owner, count)] of the handles with events."""
     import torch
+    live = [(o, o._guard_args()) for o in owners]
+    live = [(o, a) for o, a in live if a is not None]
+    if not live:
+        return []
+    st = _state()
+    n = len(live)
+    if getattr(st, 'pin', None) is None or st.pin.numel() < n:
+        st.pin = torch.zeros(max(8, n), dtype=torch.int32).pin_memory()
+    hits = []
+    by_dev = {}
+    for i, (o, a) in enumerate(live):
+        by_dev.setdefault(_device_index(o), []).append((i, o, a))
+    for _, group in by_dev.items():
+        with on_device(group[0][1]):
+            for i, o, a in group:
+                check(load().bsg_handle_range_events_async(a[0], a[1], c_void_p(st.pin.data_ptr() + 4 * i), stream_ptr()), 'bsg_handle_range_events_async')
+            torch.cuda.current_stream().synchronize()
+        for i, o, a in group:
+            v = int(st.pin[i])
+            if v:
+                o.gemm_range_take()      # reset (the stream is idle: no second wait of any length)
+                hits.append((o, v))
+    return hits
+
+
+def range_guarded(run, what, on_retry=None, device=None, owners=()):
+    """Every public entry that may enqueue split-fp16 products outside the residual stack (FS2 linears and fused attention, the
+    conditioner / input projections, HiFi-GAN's ResBlock pairs, PitchExtractor, the FFT denoiser) goes through here with the handle(s)
+    it drives (`owners`: GemmGuarded objects), so that an operand beyond the fp16 range of the split (|v| >= 4062 after scaling: counted
+    by the kernels into the HANDLE's word, never clipped) cannot leave the call as a silent NaN: the OUTERMOST guarded call of a thread
+    waits for its stream once, looks at the words of every handle that ran inside it (nested guarded calls register theirs), and on an
+    event moves THOSE handles' GEMMs to the fp32 matrix pipe (bsg_handle_set_gemm_split), warns and runs `run()` again (`on_retry()`
+    first restores what run() consumed).  The split form comes back for the next call — the event was a property of this input — until a
+    handle has seen RANGE_STRIKES_MAX events.  Other handles of the process are not touched.
+    Inside a stream capture nothing can wait: the words are left for the next guarded call (which then repeats its own work).
+    `device`: where the guarded work runs (device, tensor or module).
+    guard_mode 'deferred' (see guard_mode()): no wait; the previous call's words are looked at instead, and a BsgError raised for them."""
+    global range_retries
+    import torch
+    st = _state()
     with on_device(device):
         capturing = torch.cuda.is_current_stream_capturing()
-    if _range_depth > 0 or capturing:
+    if st.depth > 0 or capturing:
+        if st.depth > 0:
+            for o in owners:
+                if all(o is not p for p in st.owners):
+                    st.owners.append(o)
         return run()
-    _range_depth += 1
+    st.depth += 1
+    st.owners = list(owners)
     try:
         if guard_mode() == 'deferred':
             check_deferred(device)
-            restore = _restore_split_after
-            _restore_split_after = False
+            # a detection moved some handles to the fp32 pipe for THIS call; it puts them back (also when run() raises — a nested handle's
+            # check_deferred, say: the switch back would otherwise be lost and the handle stay on the fp32 pipe for good, ADVICE r04)
+            restore = [o for o in _deferred_objs if getattr(o, '_restore_split_after', False)]
+            for o in restore:
+                o._restore_split_after = False
             try:
                 out = run()
             finally:
-                # also when run() raises (a nested handle's check_deferred, say): the switch back to the split-fp16 GEMMs was consumed above and
-                # would otherwise be lost — every GEMM of the process on the fp32 matrix pipe for good, silently (ADVICE r04)
-                if restore:
-                    with on_device(device):
-                        check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
-            _deferred_enqueue(device)
+                for o in restore:
+                    o.set_gemm_split(True)
+            _deferred_enqueue(st.owners)
             return out
         out = run()
-        if gemm_range_take(device):
+        hits, demoted = _take_all(st.owners, device), []
+        while hits:
             import warnings
-            warnings.warn(f'bisinger_amd: {what}: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4062); the call is '
-                          f'repeated with every GEMM on the fp32 matrix pipe')
-            check(load().bsg_gemm_set_split(0), 'bsg_gemm_set_split')
+            names = ', '.join(f'{type(o).__name__} ({n} waves)' for o, n in hits)
+            warnings.warn(f'bisinger_amd: {what}: an operand left the fp16 range of the split-fp16 GEMMs (|v| >= 4062) in {names}; the call '
+                          f'is repeated with the GEMMs of that handle on the fp32 matrix pipe')
+            for o, _ in hits:
+                o.set_gemm_split(False)
+                o._gemm_strikes = o.gemm_range_strikes + 1
+                demoted.append(o)
             range_retries += 1
-            _range_strikes += 1
-            _in_retry = True
+            st.in_retry = True
             try:
                 if on_retry is not None:
                     on_retry()
                 out = run()
             finally:
-                _in_retry = False
-            gemm_range_take(device)
-            if _range_strikes < RANGE_STRIKES_MAX and os.environ.get('BSG_GEMM_SPLIT', '1') != '0':
-                check(load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
+                st.in_retry = False
+            # a handle that was clean before can trip in the repeated pass (its input changed with the other handle's arithmetic): it is
+            # demoted too and the call repeated once more — every pass takes at least one more handle off the 16-bit pipe, so this ends
+            hits = [(o, n) for o, n in _take_all(st.owners, device) if all(o is not p for p in demoted)]
+        for o in demoted:
+            if o.gemm_range_strikes < RANGE_STRIKES_MAX and _split_env_on():
+                o.set_gemm_split(True)
     finally:
-        _range_depth -= 1
+        st.depth -= 1
+        st.owners = []
     return out
 
 

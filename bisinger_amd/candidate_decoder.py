@@ -16,7 +16,9 @@ from .fs2 import FFTBlocks
 from .hparams import hparams
 
 
-class FFT(FFTBlocks):
+class FFT(FFTBlocks, _lib.GemmGuarded):
+    GUARD_KIND = 'fftden'
+
     def __init__(self, hidden_size=None, num_layers=None, kernel_size=None, num_heads=None):
         num_heads = hparams['num_heads'] if num_heads is None else num_heads
         hidden_size = hparams['hidden_size'] if hidden_size is None else hidden_size
@@ -63,6 +65,7 @@ class FFT(FFTBlocks):
                                              self.max_steps, self._n_pos, cast(arr, POINTER(c_void_p)), len(ws),
                                              _lib.ptr(step_table), _lib.ptr(pos_table), _lib.stream_ptr()), 'bsg_fftden_create')
         self._h, self._h_key, self._bound = h, key, None
+        self._apply_guard_state()
         return h
 
     def release(self):
@@ -110,5 +113,5 @@ class FFT(FFTBlocks):
         def again():
             self._bound = None          # the hoisted condition part was projected by the same GEMMs: bind again
 
-        _lib.range_guarded(run, 'FFT denoiser forward', on_retry=again, device=self)
+        _lib.range_guarded(run, 'FFT denoiser forward', on_retry=again, device=self, owners=(self,))
         return eps[:, None, :, :]

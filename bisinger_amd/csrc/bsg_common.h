@@ -69,11 +69,32 @@ struct GemmArgs {
   const float* rowscale; // v *= rowscale[b][i] (the reference's nonpadding masks), after the residual
   long long sRS;
   int batch;
+  unsigned* range_events;   // set by launch_gemm: the counter of the handle in whose call the product runs (gemm_range_counter())
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);
 // the split-fp16 forms (gemm.hip, fs2.hip flash attention): true while products are formed on the 16-bit matrix pipe (BSG_GEMM_SPLIT,
 // bsg_gemm_set_split); an operand that cannot be split is counted in the range-event counter (bsg_gemm_range_events)
 bool gemm_split_enabled();
+
+// Range guard state of ONE handle (bsg_diffnet, bsg_fs2midi, bsg_hifigan, bsg_pitchext, bsg_fftden each own one; include/bisinger_hip.h
+// "distinct handles are independent"): the device word its split-fp16 kernels count out-of-range operands into, and its switch between
+// the split-fp16 GEMMs (1) and the fp32 matrix pipe (0).  Every compute entry of a handle opens a GuardScope on its guard: inside it
+// gemm_range_counter() / gemm_split_enabled() answer for THAT handle (the scope is thread-local, so two host threads driving two
+// handles do not see each other's state).  Outside any scope (bsg_gemm_f32, bsg_gemm_presplit_f32, tools) the process-wide counter and
+// bsg_gemm_set_split apply — a test hook, also AND-ed into every handle's switch.
+struct Guard {
+  unsigned* counter = nullptr;   // device word, zero at create
+  int split = 1;
+};
+int guard_init(Guard* g, hipStream_t st);
+void guard_free(Guard* g);
+int guard_events(Guard* g, int32_t* events, int reset, hipStream_t st);       // waits for `st`
+int guard_events_async(Guard* g, int32_t* host_word, hipStream_t st);        // pinned host word, valid once `st` has passed
+struct GuardScope {
+  explicit GuardScope(Guard* g);
+  ~GuardScope();
+  Guard* prev;
+};
 
 // Split-fp16 GEMM with PRE-SPLIT operands (gemm_h2w.hip): weights packed once as hi / lo fp16 MFMA fragments in execution order, the
 // activation as two fp16 planes [rows][K] of 16 x value written by its producer.

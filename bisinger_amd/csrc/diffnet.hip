@@ -1046,6 +1046,7 @@ using namespace bsg;
 struct bsg_diffnet {
   bsg_diffnet_cfg cfg;
   int M, L;
+  Guard guard;   // this handle's range-event word and split-fp16 GEMM switch (input / conditioner projections)
   // packed / derived weights (library-owned)
   float* w_in = nullptr;    // [C][M]
   float* b_in = nullptr;    // [C]
@@ -1093,6 +1094,11 @@ struct bsg_diffnet {
   float* condterm_q = nullptr;   // the same in channel-quad order [L][B][2C/4][T][4]: what the 16-row stack launch loads (16 bytes per lane)
   size_t cap_cond_q = 0;         // frames it holds
   bool cond_q_valid = false;     // written by the last prepare
+  // the ROW layout (condterm) is what the fallback launches read (32-row stack launch, F(4,3), per-layer and channel-split kernels); the
+  // default launches read the quads.  Round 6: prepare writes ONE layout — the quads when the shape's default launch reads them — and the
+  // rows are derived from the quads by ensure_cond_rows() the first time a launch that reads them runs (655 MB less per pass at B = 16)
+  size_t cap_cond_rows = 0;      // frames condterm holds (allocated on demand)
+  bool cond_rows_valid = false;  // condterm holds the term of the bound condition
   float* xa = nullptr;        // [B][C][T]
   float* xb = nullptr;
   float* skip = nullptr;
@@ -1116,6 +1122,7 @@ struct bsg_diffnet {
   bool stack_is_f43 = false;           // the last stack_rows() chose the F(4,3) stack launch
   bool stack_is_h2 = false;            // ... the split-fp16 stack launch (diffnet_h2.hip)
   bool h2_off = false;                 // bsg_diffnet_set_h2(h, 0): this handle multiplies on the fp32 matrix pipe only
+  bool q_off = false;                  // bsg_diffnet_set_h2q(h, 0): the 32-row stack launch (|x + d| < 60000) instead of the 16-row one (|x| < 3750)
   int occ_stack_h2q[3] = {-1, -1, -1}; // the same for residual_stack_q_kernel (16-row matrix tiles, diffnet_h2q.hip)
   bool stack_q = false;                // the stack launch of the current shape runs on 16-row matrix tiles
   int occ_stack_h2[3] = {-1, -1, -1};  // resident workgroups per CU of residual_stack_h2_kernel<.., NCT> by NCT (-1: not queried)
@@ -1162,6 +1169,7 @@ static void dev_free(float*& p) {
 
 extern "C" void bsg_diffnet_destroy(bsg_diffnet* h) {
   if (!h) return;
+  guard_free(&h->guard);
   float** all[] = {&h->w_in, &h->b_in, &h->apack1, &h->apack2, &h->apackw, &h->apackw43, &h->w_cond, &h->b_cond, &h->b_out, &h->w_skip,
                    &h->b_skip, &h->w_fin, &h->b_fin, &h->dproj, &h->dconv, &h->ws_pack, &h->wo_pack, &h->wi_pack, &h->b_fin96, &h->apack2w, &h->zbuf, &h->condterm, &h->xa, &h->xb, &h->skip, &h->hid,
                    &h->eps, &h->eps_hist[0], &h->eps_hist[1], &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
@@ -1386,7 +1394,8 @@ extern "C" int bsg_diffnet_create(bsg_diffnet** out, const bsg_diffnet_cfg* cfg,
   h->cfg = *cfg;
   h->M = cfg->in_dims;
   h->L = cfg->residual_layers;
-  int rc = create_impl(h, dev_weights, step_table, (hipStream_t)stream);
+  int rc = guard_init(&h->guard, (hipStream_t)stream);
+  if (rc == BSG_OK) rc = create_impl(h, dev_weights, step_table, (hipStream_t)stream);
   if (rc != BSG_OK) {
     bsg_diffnet_destroy(h);
     return rc;
@@ -1395,7 +1404,50 @@ extern "C" int bsg_diffnet_create(bsg_diffnet** out, const bsg_diffnet_cfg* cfg,
   return BSG_OK;
 }
 
+// condterm (row layout [L][B][2C][T]) on demand: only the fallback launches read it (bsg_diffnet.cond_rows_valid)
+static int alloc_cond_rows(bsg_diffnet* h, size_t bt, hipStream_t st) {
+  if (bt <= h->cap_cond_rows) return BSG_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st) (void)hipStreamIsCapturing(st, &cap);
+  BSG_REQUIRE(cap == hipStreamCaptureStatusNone, "diffnet: the row layout of the conditioner term is allocated by the first eager call of a fallback launch; run it once before capturing");
+  BSG_HIP(hipStreamSynchronize(st));
+  dev_free(h->condterm);
+  h->cap_cond_rows = 0;
+  TRY(dev_alloc(&h->condterm, (size_t)h->L * 2 * C * bt));
+  h->cap_cond_rows = bt;
+  return BSG_OK;
+}
+
+// [z][R/4][T][4] -> [z][R][T]: lanes along T, one 16-byte load and four dword stores (256 B contiguous per row and wave)
+__global__ __launch_bounds__(256) void quad_to_rows_kernel(const float* __restrict__ q, float* __restrict__ rows, int R, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const long long z = blockIdx.z, qr = blockIdx.y;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(q + ((z * (R / 4) + qr) * T + t) * 4);
+  float* o = rows + (z * R + 4 * qr) * T + t;
+  o[0] = v[0]; o[(long long)T] = v[1]; o[2LL * T] = v[2]; o[3LL * T] = v[3];
+}
+
+// the rows of the bound condition's term, derived from its quads the first time a launch that reads rows runs behind a prepare that wrote
+// only the quads (a fallback after a range event or a give-up, BSG_H2_Q=0 shapes, the per-layer hooks): 2 x 655 MB at B = 16, once
+static int ensure_cond_rows(bsg_diffnet* h, hipStream_t st) {
+  if (h->cond_rows_valid) return BSG_OK;
+  if (!h->cond_q_valid) {
+    set_error("diffnet: the conditioner term of the bound condition exists in the bf16 layout only (bound under BSG_COMPUTE_BF16); call bsg_diffnet_prepare again");
+    return BSG_ESTATE;
+  }
+  const size_t bt = (size_t)h->B * h->T;
+  TRY(alloc_cond_rows(h, bt, st));
+  const long long zs = (long long)h->L * h->B;
+  BSG_REQUIRE(zs <= 65535, "diffnet: L * B = %lld launch slices", zs);
+  hipLaunchKernelGGL(quad_to_rows_kernel, dim3(cdiv(h->T, 256), 2 * C / 4, (unsigned)zs), dim3(256), 0, st, (const float*)h->condterm_q, h->condterm, 2 * C, h->T);
+  BSG_LAUNCH_CHECK();
+  h->cond_rows_valid = true;
+  return BSG_OK;
+}
+
 extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && cond, "diffnet_prepare: null argument");
   BSG_REQUIRE(B > 0 && T > 0, "diffnet_prepare: B=%d T=%d", B, T);
   BSG_REQUIRE((long long)B * T < (1LL << 31) / (2 * C), "diffnet_prepare: B*T=%lld too large", (long long)B * T);
@@ -1403,11 +1455,10 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
   const size_t bt = (size_t)B * T;
   if (bt > h->cap_bt) {
     BSG_HIP(hipStreamSynchronize(st));
-    float** bufs[] = {&h->condterm, &h->xa, &h->xb, &h->skip, &h->hid, &h->eps, &h->eps_hist[0], &h->eps_hist[1],
+    float** bufs[] = {&h->xa, &h->xb, &h->skip, &h->hid, &h->eps, &h->eps_hist[0], &h->eps_hist[1],
                       &h->eps_hist[2], &h->eps_hist[3], &h->xpred};
     for (float** p : bufs) dev_free(*p);
     h->cap_bt = 0;
-    TRY(dev_alloc(&h->condterm, (size_t)h->L * 2 * C * bt));
     TRY(dev_alloc(&h->xa, C * bt));
     TRY(dev_alloc(&h->xb, C * bt));
     TRY(dev_alloc(&h->skip, C * bt));
@@ -1474,6 +1525,7 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     h->cap_bt_h = bt;
   }
   h->cond_q_valid = false;
+  h->cond_rows_valid = false;
   static int env_h2w = -1;   // BSG_GEMM_H2W=0: gemm_split_kernel (operands split while staged) instead of the pre-split GEMM
   if (env_h2w < 0) { const char* e = getenv("BSG_GEMM_H2W"); env_h2w = e ? atoi(e) : 1; }
   bool bf16_direct = false;
@@ -1495,14 +1547,20 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     // (BSG_H2_Q=0 / BSG_COND_QUAD=0: not)
     static int env_cq = -1;
     if (env_cq < 0) { const char* e = getenv("BSG_COND_QUAD"); const char* q = getenv("BSG_H2_Q"); env_cq = (e ? atoi(e) : 1) && (q ? atoi(q) : 1); }
-    const bool want_q = env_cq && h->compute == BSG_COMPUTE_F32 && h->apack1q && !h->h2_off && !h->split_off;
+    bool want_q = env_cq && h->compute == BSG_COMPUTE_F32 && h->apack1q && !h->h2_off && !h->split_off;
     if (want_q && bt > h->cap_cond_q) {
       BSG_HIP(hipStreamSynchronize(st));
       if (h->condterm_q) (void)hipFree(h->condterm_q);
       h->condterm_q = nullptr;
       h->cap_cond_q = 0;
-      BSG_HIP(hipMalloc((void**)&h->condterm_q, (size_t)h->L * 2 * C * bt * sizeof(float)));
-      h->cap_cond_q = bt;
+      if (hipMalloc((void**)&h->condterm_q, (size_t)h->L * 2 * C * bt * sizeof(float)) != hipSuccess) {
+        // out of memory for the quads: the launches read the rows instead (dword loads: a few per cent slower), nothing fails
+        (void)hipGetLastError();
+        h->condterm_q = nullptr;
+        want_q = false;
+      } else {
+        h->cap_cond_q = bt;
+      }
     }
     h->cond_q_valid = want_q;
     H2wArgs g{};
@@ -1513,14 +1571,26 @@ extern "C" int bsg_diffnet_prepare(bsg_diffnet* h, const float* cond, int32_t B,
     if (env_hd < 0) { const char* e = getenv("BSG_COND_BF16_DIRECT"); env_hd = e ? atoi(e) : 1; }
     bf16_direct = env_hd && h->compute == BSG_COMPUTE_BF16 && h->condterm_h;
     g.Ch = bf16_direct ? h->condterm_h : nullptr;
+    // ONE layout per pass: the rows only when neither the quads nor the bf16 quads are written (BSG_COND_ROWS=1: the rows as well, round 5's way)
+    static int env_rows = -1;
+    if (env_rows < 0) { const char* e = getenv("BSG_COND_ROWS"); env_rows = e ? atoi(e) : 0; }
+    const bool rows_now = env_rows || !(want_q || bf16_direct);
+    if (rows_now) TRY(alloc_cond_rows(h, bt, st));
+    h->cond_rows_valid = rows_now;
     g.act = h->cond_planes; g.act_plane = (long long)bt * C; g.lda = C; g.sAct = (long long)T * C; g.wpack = h->wcond_pack;
-    g.sW = (long long)2 * 2 * C * C; g.zdiv = B; g.rows = T; g.K = C; g.Wn = 2 * C; g.taps = 1; g.act_is_a = 0; g.C = bf16_direct ? nullptr : h->condterm; g.ldc = T;
+    g.sW = (long long)2 * 2 * C * C; g.zdiv = B; g.rows = T; g.K = C; g.Wn = 2 * C; g.taps = 1; g.act_is_a = 0; g.C = rows_now ? h->condterm : nullptr; g.ldc = T;
     g.sC = (long long)2 * C * T; g.bias = h->b_cond; g.sBias = 2 * C; g.alpha = 1.f; g.act_fn = ACT_NONE; g.batch = h->L * B;
     TRY(launch_gemm_h2w(g, st));
   } else if (B == 1) {
+    TRY(alloc_cond_rows(h, bt, st));
+    h->cond_rows_valid = true;
     // a single utterance: the L projections are ONE GEMM of L x 2C rows ([L][2C][C] weights and [L][1][2C][T] outputs are contiguous) — twenty
     // launches of 64 workgroups each left most of the chip idle (1.0 -> 0.15 ms of a 25-ms pass)
     TRY(conv1x1(h->w_cond, h->b_cond, cond, h->condterm, h->L * 2 * C, C, 1, T, ACT_NONE, st));
+  }
+  if (B != 1 && !h2w) {
+    TRY(alloc_cond_rows(h, bt, st));
+    h->cond_rows_valid = true;
   }
   for (int l = 0; l < h->L; ++l) {
     if (B != 1 && !h2w)
@@ -1737,7 +1807,7 @@ static int stack_rows(bsg_diffnet* h, int B, int T, hipStream_t st) {
       static int env_q = -1;
       if (env_q < 0) { const char* e = getenv("BSG_H2_Q"); env_q = e ? atoi(e) : 1; }
       h->stack_q = false;
-      if (env_q && h->apack1q && h->apack2q) {
+      if (env_q && !h->q_off && h->apack1q && h->apack2q) {
         if (h->occ_stack_h2q[nct] < 0) h->occ_stack_h2q[nct] = stack_h2q_occupancy(nct) >= 1 ? 1 : 0;
         h->stack_q = h->occ_stack_h2q[nct] >= 1;
       }
@@ -1931,11 +2001,24 @@ static int check_bound(bsg_diffnet* h, int B, int T, const char* who) {
     set_error("%s: (B=%d,T=%d) does not match the condition bound by bsg_diffnet_prepare (B=%d,T=%d)", who, B, T, h->B, h->T);
     return BSG_ESTATE;
   }
-  if (h->compute == BSG_COMPUTE_BF16 && h->prepared_compute != BSG_COMPUTE_BF16) {
-    set_error("%s: the condition was bound before bsg_diffnet_set_compute(BF16); call bsg_diffnet_prepare again", who);
+  if (h->compute != h->prepared_compute) {
+    // (either way: a BF16 prepare writes the bf16 quads only — since round 5 no fp32 copy — and an F32 prepare no bf16 quads)
+    set_error("%s: the condition was bound under another bsg_diffnet_set_compute mode (%d) than the current one (%d); call bsg_diffnet_prepare again", who,
+              h->prepared_compute, h->compute);
     return BSG_ESTATE;
   }
   return BSG_OK;
+}
+
+// Does the launch this shape takes read the ROW layout of the conditioner term?  (The 16-row stack launch and the part forms read the quads,
+// the bf16 launches the bf16 quads; everything else — 32-row launch, F(4,3), per-layer and channel-split kernels — the rows.)
+static bool cond_rows_needed(bsg_diffnet* h, int B, int T, hipStream_t st) {
+  if (h->compute == BSG_COMPUTE_BF16) return false;
+  const int srows = h->no_split ? 0 : stack_rows(h, B, T, st);
+  return !(srows && h->stack_is_h2 && h->cond_q_valid && (h->stack_parts || h->stack_q));
+}
+static int cond_layout_for(bsg_diffnet* h, int B, int T, hipStream_t st) {
+  return cond_rows_needed(h, B, T, st) ? ensure_cond_rows(h, st) : BSG_OK;
 }
 
 // eps = DiffNet(x, t); t either per-row on the device or uniform
@@ -1971,16 +2054,20 @@ static int forward_impl(bsg_diffnet* h, const float* x, const long long* t_dev, 
 
 extern "C" int bsg_diffnet_forward(bsg_diffnet* h, const float* x, const int64_t* t, float* eps, int32_t B, int32_t T,
                                    void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   TRY(check_bound(h, B, T, "diffnet_forward"));
   BSG_REQUIRE(x && t && eps, "diffnet_forward: null argument");
+  TRY(cond_layout_for(h, B, T, (hipStream_t)stream));
   return forward_impl(h, x, (const long long*)t, 0, eps, B, T, (hipStream_t)stream);
 }
 
 extern "C" int bsg_diffnet_residual_layer(bsg_diffnet* h, int32_t layer, const float* x_in, const int64_t* t, float* x_out,
                                           float* skip, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   TRY(check_bound(h, B, T, "diffnet_residual_layer"));
   BSG_REQUIRE(x_in && t && x_out && skip && x_in != x_out, "diffnet_residual_layer: null or aliased argument");
   BSG_REQUIRE(layer >= 0 && layer < h->L, "diffnet_residual_layer: layer %d out of range", layer);
+  if (h->compute == BSG_COMPUTE_F32) TRY(ensure_cond_rows(h, (hipStream_t)stream));
   return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream);
 }
 
@@ -2167,6 +2254,7 @@ static int dual_join(bsg_diffnet* h, int n_sub, hipStream_t st, int rc) {
 extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, const float* noise, uint64_t seed,
                                int32_t t_start, int32_t n_steps, int32_t B, int32_t T, int32_t row0, int32_t B_total,
                                void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   TRY(check_bound(h, B, T, "ddpm_sample"));
   TRY(check_schedule(s, "ddpm_sample", false));
   BSG_REQUIRE(x, "ddpm_sample: null x");
@@ -2177,6 +2265,7 @@ extern "C" int bsg_ddpm_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * h->M * T;
   BSG_REQUIRE(n % 4 == 0, "ddpm_sample: B*M*T must be a multiple of 4");
+  TRY(cond_layout_for(h, B, T, st));
   const long long n4 = n / 4;
   const unsigned long long quad0 = (unsigned long long)row0 * h->M * T / 4;
   const bool fused = fused_tail_ok(h);
@@ -2227,9 +2316,11 @@ extern "C" int bsg_diffnet_set_compute(bsg_diffnet* h, int32_t mode) {
 
 extern "C" int bsg_diffnet_debug_stamps(bsg_diffnet* h, int32_t layer, const float* x_in, const int64_t* t, float* x_out,
                                        float* skip, int32_t B, int32_t T, uint64_t* stamps, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   TRY(check_bound(h, B, T, "diffnet_debug_stamps"));
   BSG_REQUIRE(x_in && t && x_out && skip && stamps && x_in != x_out, "diffnet_debug_stamps: null or aliased argument");
   BSG_REQUIRE(layer >= 0 && layer < h->L, "diffnet_debug_stamps: layer %d out of range", layer);
+  if (h->compute == BSG_COMPUTE_F32) TRY(ensure_cond_rows(h, (hipStream_t)stream));
   return launch_layer(h, layer, x_in, (const long long*)t, 0, x_out, skip, B, T, (hipStream_t)stream, (unsigned long long*)stamps);
 }
 
@@ -2298,6 +2389,14 @@ extern "C" int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable) {
   return BSG_OK;
 }
 
+// middle tier of the range guard (ABI v7): 0 takes the 16-row stack launch (its conv image holds 16 x: |x| < 3750) off this handle; shapes
+// that ran it take the 32-row launch (residual_stack_h2_kernel: |x + d| < 60000, about 8 % slower) — still the 16-bit matrix pipe
+extern "C" int bsg_diffnet_set_h2q(bsg_diffnet* h, int32_t enable) {
+  BSG_REQUIRE(h, "diffnet_set_h2q: null handle");
+  h->q_off = enable == 0;
+  return BSG_OK;
+}
+
 // test hook (ABI v6): the launch epoch of the handle's stack / part launches (device memory) := epoch, so that the wrap at 2^25 — two
 // hours of single-utterance serving away — can be driven by a test
 extern "C" int bsg_diffnet_debug_set_epoch(bsg_diffnet* h, uint32_t epoch, void* stream) {
@@ -2343,8 +2442,10 @@ extern "C" int bsg_diffnet_status_async(bsg_diffnet* h, int32_t* host_counts, vo
 }
 
 extern "C" int bsg_diffnet_debug_stack_stamps(bsg_diffnet* h, int32_t t_uniform, int32_t B, int32_t T, uint64_t* stamps, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   TRY(check_bound(h, B, T, "diffnet_debug_stack_stamps"));
   BSG_REQUIRE(stamps, "diffnet_debug_stack_stamps: null stamps");
+  TRY(cond_layout_for(h, B, T, (hipStream_t)stream));
   if (h->compute == BSG_COMPUTE_BF16) {
     const int hrows = stack_rows_bf16(h, B, T, (hipStream_t)stream);
     BSG_REQUIRE(hrows >= B, "diffnet_debug_stack_stamps: (B=%d,T=%d) does not run as one bf16 stack launch", B, T);
@@ -2437,6 +2538,7 @@ extern "C" int bsg_philox_normal(float* x, int64_t n, uint64_t seed, uint32_t st
 
 extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, int32_t K_step, int32_t interval, int32_t B,
                                int32_t T, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   TRY(check_bound(h, B, T, "plms_sample"));
   TRY(check_schedule(s, "plms_sample", true));
   BSG_REQUIRE(x && interval > 0 && K_step > 0 && K_step <= s->num_timesteps && K_step <= h->cfg.max_steps,
@@ -2444,6 +2546,7 @@ extern "C" int bsg_plms_sample(bsg_diffnet* h, const bsg_schedule* s, float* x, 
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)B * h->M * T;
   BSG_REQUIRE(h->xpred, "plms_sample: history buffers missing (bsg_diffnet_prepare allocates them)");
+  TRY(cond_layout_for(h, B, T, st));
   const dim3 grid(cdiv((long long)n, 256)), block(256);
   const bool fused = fused_tail_ok(h);
   // history ring: hist[0] = newest
@@ -2530,4 +2633,9 @@ extern "C" int bsg_plms_step(const float* x, float* x_out, const float* e0, cons
                      n_hist >= 2 ? e2 : nullptr, n_hist >= 3 ? e3 : nullptr, c, (long long)n);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+
+// ---- per-handle range guard of the split-fp16 GEMMs (ABI v7): one implementation for the five handle kinds
+namespace bsg {
+Guard* guard_of_diffnet(void* h) { return &static_cast<bsg_diffnet*>(h)->guard; }
 }

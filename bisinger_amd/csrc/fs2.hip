@@ -1051,6 +1051,7 @@ struct FftLayerW {
 
 struct bsg_fs2midi {
   bsg_fs2midi_cfg cfg;
+  Guard guard;   // this handle's range-event word and split-fp16 GEMM switch
   std::vector<float*> owned;
   // weights
   float *Etok, *dec_alpha, *dec_lnw, *dec_lnb, *mel_w, *mel_b, *Espk, *dur_lin_w, *dur_lin_b;
@@ -1095,6 +1096,7 @@ static int fs2_conv(bsg_fs2midi* h, float** dst, const void* src, int M, int Cin
 
 extern "C" void bsg_fs2midi_destroy(bsg_fs2midi* h) {
   if (!h) return;
+  guard_free(&h->guard);
   for (float* p : h->owned) (void)hipFree(p);
   float* ws[] = {h->w_x, h->w_a, h->w_b, h->w_qkv, h->w_ffn, h->w_keep, h->w_scores, h->w_c};
   for (float* p : ws)
@@ -1218,7 +1220,8 @@ extern "C" int bsg_fs2midi_create(bsg_fs2midi** out, const bsg_fs2midi_cfg* cfg,
   for (int i = 0; i < n_weights; ++i) BSG_REQUIRE(dev_weights[i] != nullptr, "fs2midi_create: weight %d is null", i);
   bsg_fs2midi* h = new bsg_fs2midi();
   h->cfg = *cfg;
-  int rc = fs2_create_impl(h, dev_weights, dec_pos_table, rel_pos_table, (hipStream_t)stream);
+  int rc = guard_init(&h->guard, (hipStream_t)stream);
+  if (rc == BSG_OK) rc = fs2_create_impl(h, dev_weights, dec_pos_table, rel_pos_table, (hipStream_t)stream);
   if (rc != BSG_OK) {
     bsg_fs2midi_destroy(h);
     return rc;
@@ -1556,6 +1559,7 @@ static int encode_impl(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_
 extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
                                   const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t Tt,
                                   float* enc_out, float* dur_xs, int64_t* dur, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && txt && pitch_midi && midi_dur && is_slur && lang && spk_id && enc_out, "fs2midi_encode: null argument");
   BSG_REQUIRE(B > 0 && Tt > 0 && Tt <= h->cfg.n_rel, "fs2midi_encode: B=%d T_txt=%d (rel-pos table has %d rows)", B, Tt, h->cfg.n_rel);
   BSG_REQUIRE((dur_xs == nullptr) == (dur == nullptr), "fs2midi_encode: dur_xs and dur go together");
@@ -1565,6 +1569,7 @@ extern "C" int bsg_fs2midi_encode(bsg_fs2midi* h, const int64_t* txt, const int6
 extern "C" int bsg_fs2midi_encode_rows(bsg_fs2midi* h, const int64_t* txt, const int64_t* pitch_midi, const float* midi_dur,
                                        const int64_t* is_slur, const int64_t* lang, const int64_t* spk_id, int32_t B, int32_t Tt,
                                        int32_t row0, int32_t n_rows, float* enc_out, float* dur_xs, int64_t* dur, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && txt && pitch_midi && midi_dur && is_slur && lang && spk_id && enc_out, "fs2midi_encode_rows: null argument");
   BSG_REQUIRE(B > 0 && Tt > 0 && Tt <= h->cfg.n_rel, "fs2midi_encode_rows: B=%d T_txt=%d (rel-pos table has %d rows)", B, Tt, h->cfg.n_rel);
   BSG_REQUIRE(row0 >= 0 && n_rows > 0 && row0 + n_rows <= B, "fs2midi_encode_rows: rows [%d, %d) of a batch of %d", row0, row0 + n_rows, B);
@@ -1591,6 +1596,7 @@ extern "C" int bsg_length_regulator(const int64_t* dur, const int64_t* txt, int6
 extern "C" int bsg_fs2midi_decode(bsg_fs2midi* h, const float* enc_out, const int64_t* mel2ph, const int64_t* spk_id,
                                   const int64_t* speechsing, int32_t B, int32_t Tt, int32_t T, float* decoder_inp,
                                   float* mel_out, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && enc_out && mel2ph && spk_id && speechsing && decoder_inp, "fs2midi_decode: null argument");
   BSG_REQUIRE(B > 0 && Tt > 0 && T > 0 && T < h->cfg.n_pos, "fs2midi_decode: B=%d T_txt=%d T=%d (position table has %d rows)", B, Tt, T, h->cfg.n_pos);
   hipStream_t st = (hipStream_t)stream;
@@ -1691,6 +1697,8 @@ extern "C" int bsg_fftden_create(bsg_fftden** out, int32_t in_dims, int32_t n_la
   bsg_fs2midi* c = h->core;
   auto fail = [&](int rc) { bsg_fftden_destroy(h); return rc; };
   int rc, i = 0;
+  if ((rc = guard_init(&c->guard, st)) != BSG_OK) return fail(rc);
+  GuardScope guard_scope(&c->guard);
   // FFT.state_dict(): pos_embed_alpha, embed_positions._float_tensor, layers.*, layer_norm.{w,b}, input_projection.{w,b},
   // mlp.0.{w,b}, mlp.2.{w,b}, get_mel_out.{w,b}, get_decode_inp.{w,b}
   if ((rc = fs2_copy(c, &h->alpha, w[i++], 1, st)) != BSG_OK) return fail(rc);
@@ -1723,6 +1731,7 @@ extern "C" int bsg_fftden_create(bsg_fftden** out, int32_t in_dims, int32_t n_la
 }
 
 extern "C" int bsg_fftden_prepare(bsg_fftden* h, const float* cond, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h && h->core ? &h->core->guard : nullptr);
   BSG_REQUIRE(h && cond && B > 0 && T > 0 && T < h->n_pos, "fftden_prepare: bad argument (T=%d)", T);
   hipStream_t st = (hipStream_t)stream;
   const size_t rows = (size_t)B * T;
@@ -1751,6 +1760,7 @@ extern "C" int bsg_fftden_prepare(bsg_fftden* h, const float* cond, int32_t B, i
 }
 
 extern "C" int bsg_fftden_forward(bsg_fftden* h, const float* x, const int64_t* t, float* eps, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h && h->core ? &h->core->guard : nullptr);
   BSG_REQUIRE(h && x && t && eps, "fftden_forward: null argument");
   BSG_REQUIRE(h->cap > 0 && h->B == B && h->T == T, "fftden_forward: (B=%d,T=%d) does not match bsg_fftden_prepare (B=%d,T=%d)", B, T, h->B, h->T);
   hipStream_t st = (hipStream_t)stream;
@@ -1787,4 +1797,9 @@ extern "C" int bsg_fftden_forward(bsg_fftden* h, const float* x, const int64_t* 
   hipLaunchKernelGGL(transpose_brc_kernel, dim3(cdiv(h->M, 32), cdiv(T, 32), B), dim3(256), 0, st, (const float*)h->mel, eps, T, h->M);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+
+namespace bsg {
+Guard* guard_of_fs2midi(void* h) { return &static_cast<bsg_fs2midi*>(h)->guard; }
+Guard* guard_of_fftden(void* h) { return &static_cast<bsg_fftden*>(h)->core->guard; }
 }

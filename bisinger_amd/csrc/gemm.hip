@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
     __syncthreads();
   }
-  if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(&g_gemm_range_events, 1u);
+  if (g.range_events && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicAdd(g.range_events, 1u);
 
   float* __restrict__ C = g.C + (long long)zo * g.sC + (long long)zi * g.sC2;
   const float* __restrict__ R = g.R ? g.R + (long long)zo * g.sR : nullptr;
@@ -588,9 +588,40 @@ int launch_fast(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-static int g_split = -1;   // -1: not read yet (environment); set by bsg_gemm_set_split
+static int g_split = -1;   // -1: not read yet (environment); set by bsg_gemm_set_split (test hook: AND-ed into every handle's switch)
+static thread_local Guard* tl_guard = nullptr;   // the handle whose compute entry this thread is inside (GuardScope)
+
+GuardScope::GuardScope(Guard* g) : prev(tl_guard) { tl_guard = g; }
+GuardScope::~GuardScope() { tl_guard = prev; }
+
+int guard_init(Guard* g, hipStream_t st) {
+  BSG_HIP(hipMalloc((void**)&g->counter, 4 * sizeof(unsigned)));
+  BSG_HIP(hipMemsetAsync(g->counter, 0, 4 * sizeof(unsigned), st));
+  g->split = 1;
+  return BSG_OK;
+}
+void guard_free(Guard* g) {
+  if (g->counter) (void)hipFree(g->counter);
+  g->counter = nullptr;
+}
+int guard_events(Guard* g, int32_t* events, int reset, hipStream_t st) {
+  unsigned v = 0;
+  BSG_HIP(hipMemcpyAsync(&v, g->counter, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  BSG_HIP(hipStreamSynchronize(st));
+  if (v && reset) {
+    BSG_HIP(hipMemsetAsync(g->counter, 0, sizeof(unsigned), st));
+    BSG_HIP(hipStreamSynchronize(st));
+  }
+  *events = (int32_t)v;
+  return BSG_OK;
+}
+int guard_events_async(Guard* g, int32_t* host_word, hipStream_t st) {
+  BSG_HIP(hipMemcpyAsync(host_word, g->counter, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  return BSG_OK;
+}
 
 unsigned* gemm_range_counter() {
+  if (tl_guard && tl_guard->counter) return tl_guard->counter;   // inside a handle's call: that handle's own word
   // the symbol lives once per device: cache its address per device id (the Python wrappers switch devices per call)
   static unsigned* p[64] = {};
   int dev = 0;
@@ -601,10 +632,12 @@ unsigned* gemm_range_counter() {
 
 bool gemm_split_enabled() {
   if (g_split < 0) { const char* e = getenv("BSG_GEMM_SPLIT"); g_split = e ? atoi(e) : 1; }
-  return g_split != 0;
+  return g_split != 0 && (!tl_guard || tl_guard->split != 0);
 }
 
-int launch_gemm(const GemmArgs& g, hipStream_t st) {
+int launch_gemm(const GemmArgs& g_in, hipStream_t st) {
+  GemmArgs g = g_in;
+  g.range_events = gemm_range_counter();
   BSG_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0 && g.taps > 0, "gemm: empty problem M=%d N=%d K=%d batch=%d", g.M, g.N, g.K, g.batch);
   BSG_REQUIRE(g.batch <= 65535, "gemm: batch %d > 65535", g.batch);
   // the fast kernel moves 16-byte pieces: every operand row and every batch / tap offset must keep 16-byte alignment
@@ -616,8 +649,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     const long long wg128 = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
     const bool small = wg128 < 2 * 256;
     // BSG_GEMM_SPLIT=0 / bsg_gemm_set_split(0): multiply on the fp32 matrix pipe (gemm_fast_kernel) instead of the split-fp16 form
-    if (g_split < 0) { const char* e = getenv("BSG_GEMM_SPLIT"); g_split = e ? atoi(e) : 1; }
-    if (g_split) {
+    if (gemm_split_enabled()) {
       const long long wgs = (long long)cdiv(g.N, FBN) * cdiv(g.M, 128) * g.batch;
       const bool sm = wgs < 3 * 256;
       if (g.trans_b) return sm ? launch_split<64, true>(g, st) : launch_split<128, true>(g, st);
@@ -674,5 +706,52 @@ extern "C" int bsg_gemm_range_events(int32_t* events, int32_t reset, void* strea
 extern "C" int bsg_gemm_range_events_async(int32_t* host_word, void* stream) {
   BSG_REQUIRE(host_word, "gemm_range_events_async: null argument");
   BSG_HIP(hipMemcpyFromSymbolAsync(host_word, HIP_SYMBOL(bsg::g_gemm_range_events), sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return BSG_OK;
+}
+
+// ---- per-handle range guard (ABI v7): every handle kind owns a Guard; these three entries reach it through (kind, handle) --------------
+namespace bsg {
+Guard* guard_of_diffnet(void* h);
+Guard* guard_of_fs2midi(void* h);
+Guard* guard_of_hifigan(void* h);
+Guard* guard_of_pitchext(void* h);
+Guard* guard_of_fftden(void* h);
+static Guard* guard_of(int kind, void* h) {
+  if (!h) return nullptr;
+  switch (kind) {
+    case BSG_HANDLE_DIFFNET: return guard_of_diffnet(h);
+    case BSG_HANDLE_FS2MIDI: return guard_of_fs2midi(h);
+    case BSG_HANDLE_HIFIGAN: return guard_of_hifigan(h);
+    case BSG_HANDLE_PITCHEXT: return guard_of_pitchext(h);
+    case BSG_HANDLE_FFTDEN: return guard_of_fftden(h);
+  }
+  return nullptr;
+}
+}  // namespace bsg
+
+extern "C" int bsg_handle_range_events(int32_t kind, void* handle, int32_t* events, int32_t reset, void* stream) {
+  bsg::Guard* g = bsg::guard_of(kind, handle);
+  BSG_REQUIRE(g && g->counter && events, "handle_range_events: bad handle (kind %d) or null argument", kind);
+  return bsg::guard_events(g, events, reset, (hipStream_t)stream);
+}
+
+extern "C" int bsg_handle_range_events_async(int32_t kind, void* handle, int32_t* host_word, void* stream) {
+  bsg::Guard* g = bsg::guard_of(kind, handle);
+  BSG_REQUIRE(g && g->counter && host_word, "handle_range_events_async: bad handle (kind %d) or null argument", kind);
+  return bsg::guard_events_async(g, host_word, (hipStream_t)stream);
+}
+
+extern "C" int bsg_handle_set_gemm_split(int32_t kind, void* handle, int32_t enable) {
+  bsg::Guard* g = bsg::guard_of(kind, handle);
+  BSG_REQUIRE(g, "handle_set_gemm_split: bad handle (kind %d)", kind);
+  g->split = enable ? 1 : 0;
+  return BSG_OK;
+}
+
+extern "C" int bsg_handle_get_gemm_split(int32_t kind, void* handle, int32_t* enabled) {
+  bsg::Guard* g = bsg::guard_of(kind, handle);
+  BSG_REQUIRE(g && enabled, "handle_get_gemm_split: bad handle (kind %d) or null argument", kind);
+  bsg::GuardScope scope(g);
+  *enabled = bsg::gemm_split_enabled() ? 1 : 0;   // the handle's switch AND the process-wide one (BSG_GEMM_SPLIT / bsg_gemm_set_split)
   return BSG_OK;
 }

@@ -568,8 +568,8 @@ int h2w_split_transposed(const float* src, unsigned short* hi, unsigned short* l
 
 int launch_gemm_h2w(const H2wArgs& g0, hipStream_t st) {
   H2wArgs g = g0;
-  BSG_REQUIRE(g.act && g.wpack && (g.C || g.out || g.Ch) && g.batch > 0, "gemm_h2w: null operand");
-  BSG_REQUIRE(g.C || !g.Ch || (!g.act_is_a && !g.up_u && !g.R && !g.rowscale && g.act_fn == ACT_NONE), "gemm_h2w: a bf16-quad output without the fp32 one needs the direct-store epilogue");
+  BSG_REQUIRE(g.act && g.wpack && (g.C || g.out || g.Ch || g.Cq) && g.batch > 0, "gemm_h2w: null operand");
+  BSG_REQUIRE(g.C || !(g.Ch || g.Cq) || (!g.act_is_a && !g.up_u && !g.R && !g.rowscale && g.act_fn == ACT_NONE), "gemm_h2w: a quad-order output without the fp32 row-order one needs the direct-store epilogue");
   BSG_REQUIRE(h2w_supports(g.rows, g.Wn, g.K, g.taps, g.lda), "gemm_h2w: unsupported shape rows=%d Wn=%d K=%d taps=%d lda=%d", g.rows, g.Wn, g.K,
               g.taps, g.lda);
   BSG_REQUIRE(!g.out || g.act_is_a, "gemm_h2w: plane output needs the [token][feature] form");

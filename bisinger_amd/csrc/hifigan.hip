@@ -1660,6 +1660,7 @@ struct ConvW {
 
 struct bsg_hifigan {
   bsg_hifigan_cfg cfg;
+  Guard guard;   // this handle's range-event word and split-fp16 switch
   std::vector<float*> owned;
   std::vector<float*> create_tmp;   // reorder temporaries of the weight packing: freed behind create's stream synchronize
   ConvW pre, post;
@@ -1682,6 +1683,7 @@ struct bsg_hifigan {
 
 extern "C" void bsg_hifigan_destroy(bsg_hifigan* h) {
   if (!h) return;
+  guard_free(&h->guard);
   for (float* p : h->owned) (void)hipFree(p);
   for (float* p : h->buf)
     if (p) (void)hipFree(p);
@@ -1866,6 +1868,7 @@ extern "C" int bsg_hifigan_create(bsg_hifigan** out, const bsg_hifigan_cfg* cfg,
   const void* const* w = dev_weights;
   int rc = BSG_OK;
   auto fail = [&](int code) { bsg_hifigan_destroy(h); return code; };
+  if ((rc = guard_init(&h->guard, st)) != BSG_OK) return fail(rc);
   const int C0 = cfg->upsample_initial_channel;
   {
     float* cnt = nullptr;
@@ -2137,12 +2140,14 @@ static int hifigan_run(bsg_hifigan* h, const float* mel, float* wav, int32_t B, 
 }
 
 extern "C" int bsg_hifigan_forward(bsg_hifigan* h, const float* mel, float* wav, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && !h->cfg.use_nsf, "hifigan_forward: this generator was created with the NSF source; call bsg_hifigan_forward_nsf");
   return hifigan_run(h, mel, wav, B, T, stream, nullptr, 0);
 }
 
 extern "C" int bsg_hifigan_forward_nsf(bsg_hifigan* h, const float* mel, const float* f0, const float* rand_ini, const float* noise,
                                        float* wav, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && h->cfg.use_nsf, "hifigan_forward_nsf: generator created without the NSF source");
   BSG_REQUIRE(mel && f0 && rand_ini && noise && wav && B > 0 && T > 0, "hifigan_forward_nsf: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -2163,4 +2168,8 @@ extern "C" int bsg_hifigan_forward_nsf(bsg_hifigan* h, const float* mel, const f
   }
   TRY(nsf_launch_source(f0, rand_ini, noise, h->src_w, h->src_b, h->sw_tmp, h->har, B, T, hop, NH, (float)h->cfg.sample_rate, st));
   return hifigan_run(h, mel, wav, B, T, stream, h->har, L);
+}
+
+namespace bsg {
+Guard* guard_of_hifigan(void* h) { return &static_cast<bsg_hifigan*>(h)->guard; }
 }

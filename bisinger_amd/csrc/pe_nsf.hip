@@ -302,6 +302,7 @@ using namespace bsg;
 
 struct bsg_pitchext {
   bsg_pitchext_cfg cfg;
+  Guard guard;   // this handle's range-event word and split-fp16 GEMM switch
   std::vector<float*> owned;
   float *pre_w[3], *pre_b[3], *pre_scale[3], *pre_shift[3], *pre_out_w, *pre_out_b;
   std::vector<float*> enc_w, enc_b, enc_gw, enc_gb;
@@ -334,6 +335,7 @@ static int pe_conv(bsg_pitchext* h, float** dst, const void* src, int M, int Cin
 
 extern "C" void bsg_pitchext_destroy(bsg_pitchext* h) {
   if (!h) return;
+  guard_free(&h->guard);
   for (float* p : h->owned) (void)hipFree(p);
   float* ws[] = {h->a, h->b, h->c, h->keep, h->pred};
   for (float* p : ws)
@@ -397,7 +399,8 @@ extern "C" int bsg_pitchext_create(bsg_pitchext** out, const bsg_pitchext_cfg* c
   for (int i = 0; i < n_weights; ++i) BSG_REQUIRE(dev_weights[i] != nullptr, "pitchext_create: weight %d is null", i);
   bsg_pitchext* h = new bsg_pitchext();
   h->cfg = *cfg;
-  int rc = pe_create_impl(h, dev_weights, pos_table, (hipStream_t)stream);
+  int rc = guard_init(&h->guard, (hipStream_t)stream);
+  if (rc == BSG_OK) rc = pe_create_impl(h, dev_weights, pos_table, (hipStream_t)stream);
   if (rc != BSG_OK) { bsg_pitchext_destroy(h); return rc; }
   *out = h;
   return BSG_OK;
@@ -421,6 +424,7 @@ static int pe_conv_gemm(const float* X, const float* Wt, const float* bias, floa
 }
 
 extern "C" int bsg_pitchext_forward(bsg_pitchext* h, const float* mel, float* pitch_pred, float* f0, int32_t B, int32_t T, void* stream) {
+  GuardScope guard_scope(h ? &h->guard : nullptr);
   BSG_REQUIRE(h && mel && f0 && B > 0 && T > 0 && T < h->cfg.n_pos, "pitchext_forward: bad argument (T=%d, table %d rows)", T, h ? h->cfg.n_pos : 0);
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)B * T;
@@ -483,4 +487,8 @@ extern "C" int bsg_pitchext_forward(bsg_pitchext* h, const float* mel, float* pi
   hipLaunchKernelGGL(f0_denorm_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, (const float*)pred, h->keep, f0, rows, h->cfg.use_uv);
   BSG_LAUNCH_CHECK();
   return BSG_OK;
+}
+
+namespace bsg {
+Guard* guard_of_pitchext(void* h) { return &static_cast<bsg_pitchext*>(h)->guard; }
 }

@@ -54,7 +54,9 @@ class ResidualBlock(nn.Module):
         self.output_projection = _conv1d(residual_channels, 2 * residual_channels, 1)
 
 
-class DiffNet(nn.Module):
+class DiffNet(nn.Module, _lib.GemmGuarded):
+    GUARD_KIND = 'diffnet'
+
     def __init__(self, in_dims=80):
         super().__init__()
         self.in_dims = in_dims
@@ -108,6 +110,7 @@ class DiffNet(nn.Module):
                                               _lib.ptr(table), _lib.stream_ptr()), 'bsg_diffnet_create')
         self._h, self._h_key, self._bound = h, key, None
         self._apply_compute()
+        self._apply_guard_state()
         if getattr(self, 'split_disabled', False):
             _lib.check(lib.bsg_diffnet_set_split(h, 0), 'bsg_diffnet_set_split')
         return h
@@ -135,6 +138,11 @@ class DiffNet(nn.Module):
         _lib.check(_lib.load().bsg_diffnet_set_h2(self.handle(), int(bool(enable))), 'bsg_diffnet_set_h2')
         self._h2_range_off = False
 
+    def set_q_launch(self, enable):
+        """False: not the 16-row stack launch (|x| < 3750) but the 32-row one (|x + d| < 60000) — what BSG_H2_Q=0 does for the whole process."""
+        _lib.check(_lib.load().bsg_diffnet_set_h2q(self.handle(), int(bool(enable))), 'bsg_diffnet_set_h2q')
+        self._h2q_range_off = False
+
     def release(self):
         if self._h is not None:
             _lib.load().bsg_diffnet_destroy(self._h)
@@ -149,15 +157,17 @@ class DiffNet(nn.Module):
     def prepare(self, cond):
         """Bind ``cond`` [B,H,T]: hoists every layer's conditioner projection out of the step loop."""
         h = self.handle()
-        off = getattr(self, '_h2_range_off', False)
-        if off is not False and off is not cond:        # a range event of the split-fp16 launch was a property of the condition bound then
-            if _lib._in_retry or getattr(self, '_h2_strikes', 0) >= self.H2_STRIKES_MAX:
-                # the repeated pass of an outer guarded call (GaussianDiffusion.forward recomputes cond: a NEW tensor with the same values),
-                # or a handle whose inputs keep leaving the range: stay on the fp32 matrix pipe
-                self._h2_range_off = cond
-            else:
-                _lib.check(_lib.load().bsg_diffnet_set_h2(h, 1), 'bsg_diffnet_set_h2')
-                self._h2_range_off = False
+        # a range event of a split-fp16 launch was a property of the condition bound then: with another condition the handle tries the faster
+        # launch again — unless this is the repeated pass of an outer guarded call (GaussianDiffusion.forward recomputes cond: a NEW tensor with
+        # the same values), or the handle's inputs keep leaving the range (H2_STRIKES_MAX)
+        for attr, strikes, setter in (('_h2_range_off', '_h2_strikes', 'bsg_diffnet_set_h2'), ('_h2q_range_off', '_h2q_strikes', 'bsg_diffnet_set_h2q')):
+            off = getattr(self, attr, False)
+            if off is not False and off is not cond:
+                if _lib.in_retry() or getattr(self, strikes, 0) >= self.H2_STRIKES_MAX:
+                    setattr(self, attr, cond)
+                else:
+                    _lib.check(getattr(_lib.load(), setter)(h, 1), setter)
+                    setattr(self, attr, False)
         cond = cond.contiguous().float()
         B, H, T = cond.shape
         assert H == self.encoder_hidden
@@ -243,7 +253,7 @@ class DiffNet(nn.Module):
             # no wait: look at what the PREVIOUS call on this handle left (BsgError, after switching the fallback on), run, and enqueue
             # the non-blocking copy of the health words behind this call's work
             _lib.check_deferred(self)
-            _lib.range_guarded(run, 'DiffNet', device=self)
+            _lib.range_guarded(run, 'DiffNet', device=self, owners=(self,))
             self._deferred_enqueue()
             return
 
@@ -252,9 +262,18 @@ class DiffNet(nn.Module):
                 self.prepare(self._bound[0])
             if restore is not None:
                 restore()
-        _lib.range_guarded(lambda: self._guarded_handoffs(run, B, T, restore), 'DiffNet', on_retry=again, device=self)
+        _lib.range_guarded(lambda: self._guarded_handoffs(run, B, T, restore), 'DiffNet', on_retry=again, device=self, owners=(self,))
 
     def _guarded_handoffs(self, run, B, T, restore):
+        """run(), then look at the handle's health words and heal — tier by tier, one repeat per tier, whatever the order in which the
+        events show up (a repeat on another launch form can raise the OTHER kind of event: ADVICE r05):
+          range event (status word 1), by the launch that raised it:
+            16-row stack launch (its conv image holds 16 x: |x| >= 3750)  -> bsg_diffnet_set_h2q(h, 0): the 32-row launch (|x + d| < 60000, ~8 % slower)
+            any other split-fp16 launch (|x + d| >= 60000)               -> bsg_diffnet_set_h2(h, 0): the fp32 matrix pipe (~2x slower)
+            both while this condition is bound (the event is a property of the input); H2_STRIKES_MAX events keep the handle there
+          hand-off give-up (status word 0):
+            inside a part launch  -> part forms off (one workgroup per tile), CLEAN_CALLS_TO_REENABLE calls
+            otherwise             -> every hand-off launch off (per-layer launches on the fp32 matrix pipe)"""
         import warnings
         run()
         if getattr(self, 'split_disabled', False):
@@ -270,63 +289,64 @@ class DiffNet(nn.Module):
                     _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
                     self.parts_disabled, self._clean_calls_parts = False, 0
             return
-        if not self.uses_handoffs(B, T):
-            return
-        give, rng = self.take_health()
-        if not give and not rng:
-            if getattr(self, 'parts_disabled', False):      # part forms come back after as many clean calls as hand-off launches do
-                self._clean_calls_parts = getattr(self, '_clean_calls_parts', 0) + 1
-                if self._clean_calls_parts >= self.CLEAN_CALLS_TO_REENABLE:
-                    _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
-                    self.parts_disabled, self._clean_calls_parts = False, 0
-            return
-        if rng and not give:
-            warnings.warn(f'bisinger_amd: {rng} waves saw an activation beyond the fp16 range of the split-fp16 launch (|x + d| >= 60000); '
-                          f'this DiffNet handle runs the kernels of the fp32 matrix pipe while this condition is bound and the '
-                          f'evaluation is repeated')
-            _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
-            self._h2_range_off = self._bound[0] if self._bound is not None else True
-            self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
-            if _lib.gemm_range_peek(self):
-                # a split-fp16 GEMM counted an operand too.  Cause and effect cannot be told apart here (a NaN condition makes the launch
-                # trip; a launch that tripped feeds NaN to the GEMMs behind it): the GEMM guard around this call repeats everything
-                # with the GEMMs on the fp32 matrix pipe — and this handle off the 16-bit pipe — in ONE more pass
-                return
-            if restore is not None:
-                restore()
-            run()
-            if not self.uses_handoffs(B, T):
-                return
-            give, rng = self.take_health()
-            if not give:
-                return
-        if self.last_path() in self.PART_PATHS and not getattr(self, 'parts_disabled', False):
-            # first tier: the give-up came out of a PART launch (several workgroups per tile on CUs of one XCD: partners not on this XCD, or not
-            # resident).  The one-workgroup-per-tile stack launch does not depend on that placement: part forms off, repeat; only if that
-            # launch gives up too does the handle go to launches without hand-offs (below)
-            warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up inside a part launch ({self.last_path()}); part forms are off '
-                          f'for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (one workgroup per tile) and the evaluation is repeated')
-            _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 0), 'bsg_diffnet_set_parts')
-            self.parts_disabled, self._clean_calls_parts = True, 0
-            if restore is not None:
-                restore()
-            run()
+        lib = _lib.load()
+        for attempt in range(5):      # at most: h2q off, h2 off | parts off, split off — each tier once
             if not self.uses_handoffs(B, T):
                 return
             give, rng = self.take_health()
             if not give and not rng:
+                if attempt == 0 and getattr(self, 'parts_disabled', False):      # part forms come back after as many clean calls as hand-off launches do
+                    self._clean_calls_parts = getattr(self, '_clean_calls_parts', 0) + 1
+                    if self._clean_calls_parts >= self.CLEAN_CALLS_TO_REENABLE:
+                        _lib.check(lib.bsg_diffnet_set_parts(self._h, 1), 'bsg_diffnet_set_parts')
+                        self.parts_disabled, self._clean_calls_parts = False, 0
                 return
-        warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up (a partner workgroup was not resident); channel-split and '
-                      f'stack launches are off for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (per-layer launches '
-                      f'on the fp32 matrix pipe) and the evaluation is repeated')
-        _lib.check(_lib.load().bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
-        self.split_disabled, self._clean_calls = True, 0
-        if restore is not None:
-            restore()
-        run()
-        give, rng = self.take_health()
-        if give or rng:
-            raise _lib.BsgError(f'{give + rng} inter-workgroup hand-offs gave up with split launches off: the result is invalid')
+            path = self.last_path()
+            if not give:
+                bound = self._bound[0] if self._bound is not None else True
+                if path.startswith('stack_h2q') and not getattr(self, '_h2q_range_off', False):
+                    warnings.warn(f'bisinger_amd: {rng} waves saw an activation beyond the range of the 16-row split-fp16 stack launch (|x| >= 3750: its '
+                                  f'conv image holds 16 x in fp16 planes); this DiffNet handle takes the 32-row launch (|x + d| < 60000, about 8 % slower) '
+                                  f'while this condition is bound and the evaluation is repeated')
+                    _lib.check(lib.bsg_diffnet_set_h2q(self._h, 0), 'bsg_diffnet_set_h2q')
+                    self._h2q_range_off = bound
+                    self._h2q_strikes = getattr(self, '_h2q_strikes', 0) + 1
+                else:
+                    warnings.warn(f'bisinger_amd: {rng} waves saw an activation beyond the fp16 range of the split-fp16 launch {path} (|x + d| >= 60000); '
+                                  f'this DiffNet handle runs the kernels of the fp32 matrix pipe while this condition is bound and the '
+                                  f'evaluation is repeated')
+                    _lib.check(lib.bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
+                    self._h2_range_off = bound
+                    self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
+                # A split-fp16 GEMM of this handle may have counted an operand too.  Behind a launch that tripped that is the rule, not a second
+                # fault: the launch's invalid output (inf / NaN) is the operand of the skip projection.  The word is cleared and only the launch
+                # goes one tier down; if a GEMM was the CAUSE (a condition or an x beyond |v| < 4062: its product is inf / NaN, never finite
+                # garbage — 16 v overflows the fp16 hi term), the repeat trips again, down to the fp32-pipe kernels, whose non-finite output
+                # makes the projections count once more — and the GEMM guard around this call then repeats everything, prepare() included,
+                # with the handle's GEMMs on the fp32 matrix pipe
+                self.gemm_range_take()
+            elif path in self.PART_PATHS and not getattr(self, 'parts_disabled', False):
+                # first tier: the give-up came out of a PART launch (several workgroups per tile on CUs of one XCD: partners not on this XCD,
+                # or not resident).  The one-workgroup-per-tile stack launch does not depend on that placement
+                warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up inside a part launch ({path}); part forms are off '
+                              f'for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (one workgroup per tile) and the evaluation is repeated')
+                _lib.check(lib.bsg_diffnet_set_parts(self._h, 0), 'bsg_diffnet_set_parts')
+                self.parts_disabled, self._clean_calls_parts = True, 0
+            else:
+                warnings.warn(f'bisinger_amd: {give} inter-workgroup hand-offs gave up (a partner workgroup was not resident); channel-split and '
+                              f'stack launches are off for this DiffNet handle for the next {self.CLEAN_CALLS_TO_REENABLE} calls (per-layer launches '
+                              f'on the fp32 matrix pipe) and the evaluation is repeated')
+                _lib.check(lib.bsg_diffnet_set_split(self._h, 0), 'bsg_diffnet_set_split')
+                self.split_disabled, self._clean_calls = True, 0
+            if restore is not None:
+                restore()
+            run()
+            if getattr(self, 'split_disabled', False):
+                give, rng = self.take_health()
+                if give or rng:
+                    raise _lib.BsgError(f'{give + rng} inter-workgroup hand-offs gave up with split launches off: the result is invalid')
+                return
+        raise _lib.BsgError('DiffNet: the evaluation stayed invalid through every fallback tier')
 
     # ------------------------------------------------------------------ guard_mode = 'deferred'
     def _deferred_enqueue(self):
@@ -373,11 +393,19 @@ class DiffNet(nn.Module):
         rec.drop_pending()      # reads enqueued before this point repeat the same (cumulative) counts: dropped — repeat everything issued since the last clean check
         what = []
         if rng:
-            _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
-            self._h2_range_off = self._bound[0] if self._bound is not None else True
-            self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
-            what.append(f'{rng} waves saw a value beyond the fp16 range of the split-fp16 launch (this handle now runs the fp32 matrix pipe '
-                        f'while this condition is bound)')
+            bound = self._bound[0] if self._bound is not None else True
+            if self.last_path().startswith('stack_h2q') and not getattr(self, '_h2q_range_off', False):
+                _lib.check(_lib.load().bsg_diffnet_set_h2q(self._h, 0), 'bsg_diffnet_set_h2q')
+                self._h2q_range_off = bound
+                self._h2q_strikes = getattr(self, '_h2q_strikes', 0) + 1
+                what.append(f'{rng} waves saw a value beyond the range of the 16-row split-fp16 stack launch (|x| >= 3750; this handle now takes the '
+                            f'32-row launch while this condition is bound)')
+            else:
+                _lib.check(_lib.load().bsg_diffnet_set_h2(self._h, 0), 'bsg_diffnet_set_h2')
+                self._h2_range_off = bound
+                self._h2_strikes = getattr(self, '_h2_strikes', 0) + 1
+                what.append(f'{rng} waves saw a value beyond the fp16 range of the split-fp16 launch (this handle now runs the fp32 matrix pipe '
+                            f'while this condition is bound)')
         if give and not give_split and self.last_path() in self.PART_PATHS and not getattr(self, 'parts_disabled', False):
             # first tier (as in the same-call mode): the give-up came out of a part launch; the one-workgroup-per-tile launch stays
             _lib.check(_lib.load().bsg_diffnet_set_parts(self._h, 0), 'bsg_diffnet_set_parts')

@@ -164,7 +164,8 @@ class GaussianDiffusion(nn.Module):
             def again():
                 x.copy_(keep)
                 self.denoise_fn.prepare(cond)
-            _lib.range_guarded(loop, 'FFT denoiser sampler loop', on_retry=None if capturing else again, device=x)
+            _lib.range_guarded(loop, 'FFT denoiser sampler loop', on_retry=None if capturing else again, device=x,
+                               owners=(self.denoise_fn,) if isinstance(self.denoise_fn, _lib.GemmGuarded) else ())
             return x
         n = t if n_steps is None else n_steps
         if noise is not None:
@@ -228,9 +229,11 @@ class GaussianDiffusion(nn.Module):
         if not infer:
             raise NotImplementedError('training (p_losses) is outside the accelerated hot path (SURVEY.md §8)')
         # one range guard around the whole call (FS2, the conditioner projections, the sampler): an operand beyond the fp16 range of the
-        # split-fp16 GEMMs repeats all of it on the fp32 matrix pipe (_lib.range_guarded; the nested guards leave the check to this one)
+        # split-fp16 GEMMs repeats all of it with THAT handle (FS2's or the denoiser's) on the fp32 matrix pipe (_lib.range_guarded; the nested
+        # guards register their handles with this one and leave the check to it)
         return _lib.range_guarded(lambda: self._forward_infer(txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows,
-                                                              **kwargs), 'GaussianDiffusion.forward', device=self)
+                                                              **kwargs), 'GaussianDiffusion.forward', device=self,
+                                  owners=tuple(m for m in (self.fs2, self.denoise_fn) if isinstance(m, _lib.GemmGuarded)))
 
     def _forward_infer(self, txt_tokens, mel2ph, spk_embed, ref_mels, f0, uv, energy, noise, seed, rows, **kwargs):
         B_total = txt_tokens.shape[0]

@@ -181,7 +181,9 @@ class DurationPredictor(_Holder):
         self.linear = nn.Linear(n_chans, 1)
 
 
-class FastSpeech2MIDI(nn.Module):
+class FastSpeech2MIDI(nn.Module, _lib.GemmGuarded):
+    GUARD_KIND = 'fs2midi'
+
     def __init__(self, dictionary, out_dims=None):
         super().__init__()
         hp = hparams
@@ -249,6 +251,7 @@ class FastSpeech2MIDI(nn.Module):
                                               _lib.ptr(dec_table), _lib.ptr(rel_table), _lib.stream_ptr()),
                        'bsg_fs2midi_create')
         self._h, self._h_key = h, key
+        self._apply_guard_state()
         return h
 
     def release(self):
@@ -351,7 +354,7 @@ class FastSpeech2MIDI(nn.Module):
         given nothing else of the other rows is computed (``encode(rows=...)``).  With predicted durations the frame count T is the
         maximum over the whole batch (tts_modules.py:182), so the token-level front then runs on every row and is sliced afterwards."""
         return _lib.range_guarded(lambda: self._forward(txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs),
-                                  'FastSpeech2MIDI.forward', device=self)
+                                  'FastSpeech2MIDI.forward', device=self, owners=(self,))
 
     def _forward(self, txt_tokens, mel2ph, spk_embed, skip_decoder, rows, **kwargs):
         ret = {}

@@ -92,7 +92,9 @@ class ResBlock2(nn.Module):
             c.fold()
 
 
-class HifiGanGenerator(nn.Module):
+class HifiGanGenerator(nn.Module, _lib.GemmGuarded):
+    GUARD_KIND = 'hifigan'
+
     def __init__(self, h, c_out=1):
         super().__init__()
         self.h = h
@@ -182,6 +184,7 @@ class HifiGanGenerator(nn.Module):
             _lib.check(lib.bsg_hifigan_create(byref(hd), byref(cfg), cast(arr, POINTER(c_void_p)), len(ws), _lib.stream_ptr()),
                        'bsg_hifigan_create')
         self._h, self._h_key = hd, key
+        self._apply_guard_state()
         return hd
 
     def release(self):
@@ -202,7 +205,7 @@ class HifiGanGenerator(nn.Module):
         (numpy RandomState(seed) for the 9 initial phases, the library's Philox stream 0x4E5346 for the noise)."""
         # range guard of the split-fp16 ResBlock pairs (an activation beyond the fp16 range is counted by the kernels, never clipped):
         # read once per outermost call; on an event the call is repeated on the fp32 matrix pipe (_lib.range_guarded)
-        return _lib.range_guarded(lambda: self._forward(x, f0, rand_ini, noise, seed), 'HifiGanGenerator.forward', device=self)
+        return _lib.range_guarded(lambda: self._forward(x, f0, rand_ini, noise, seed), 'HifiGanGenerator.forward', device=self, owners=(self,))
 
     def _forward(self, x, f0, rand_ini, noise, seed):
         hd = self.handle()

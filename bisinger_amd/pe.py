@@ -69,7 +69,9 @@ class PitchPredictor(_Holder):
         self.pos_embed_alpha = nn.Parameter(torch.Tensor([1]))
 
 
-class PitchExtractor(nn.Module):
+class PitchExtractor(nn.Module, _lib.GemmGuarded):
+    GUARD_KIND = 'pitchext'
+
     def __init__(self, n_mel_bins=80, conv_layers=2):
         super().__init__()
         self.hidden_size = 256
@@ -113,6 +115,7 @@ class PitchExtractor(nn.Module):
             _lib.check(lib.bsg_pitchext_create(byref(h), byref(cfg), cast(arr, POINTER(c_void_p)), len(ws), _lib.ptr(table),
                                                _lib.stream_ptr()), 'bsg_pitchext_create')
         self._h, self._h_key = h, key
+        self._apply_guard_state()
         return h
 
     def release(self):
@@ -129,7 +132,7 @@ class PitchExtractor(nn.Module):
     @torch.no_grad()
     def forward(self, mel_input=None):
         """mel [B,T,80] -> {'pitch_pred': [B,T,2], 'f0_denorm_pred': [B,T]}   (pe.py:136-149)."""
-        return _lib.range_guarded(lambda: self._forward(mel_input), 'PitchExtractor.forward', device=self)
+        return _lib.range_guarded(lambda: self._forward(mel_input), 'PitchExtractor.forward', device=self, owners=(self,))
 
     def _forward(self, mel_input):
         h = self.handle()

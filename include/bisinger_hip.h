@@ -162,7 +162,8 @@ int bsg_diffnet_status(bsg_diffnet* h, int32_t* handoff_timeouts);
 /* Asynchronous form (ABI v5: THREE words): enqueues copies of the handle's health words into host_counts[0..2] (pinned host memory,
  * caller-owned) on `stream` and returns; the values are valid once the stream has passed that point (e.g. an event recorded after the
  * call): [0] hand-off give-ups of the stack / part launches, [1] values beyond the fp16 range seen by the split-fp16 stack / part / tail
- * launches (|x + d| >= 60000: the result is invalid, repeat with bsg_diffnet_set_h2(h, 0)), [2] give-ups of the channel-split launches.
+ * launches (16-row stack launch: |x| >= 3750; 32-row launch, part forms and tails: |x + d| >= 60000: the result is invalid, repeat with
+ * bsg_diffnet_set_h2q(h, 0) after a 16-row launch, with bsg_diffnet_set_h2(h, 0) otherwise), [2] give-ups of the channel-split launches.
  * Nothing is reset (bsg_diffnet_health_take does that).  Lets a caller fail loudly — or repeat — one call later without adding a
  * synchronisation to the path: what a replayed capture of the sampler loop (round 4: the stack / part launches keep their launch epoch in
  * device memory and can be captured) and the `deferred` guard mode of the Python drop-ins use. */
@@ -388,9 +389,32 @@ int bsg_gemm_f32(const float* A, const float* Bm, float* C, const float* bias_m,
  * later GEMM to the fp32 matrix pipe — what the Python drop-ins do before they repeat the call (bisinger_amd/diffnet.py guarded). */
 int bsg_gemm_set_split(int32_t enable);
 int bsg_diffnet_set_h2(bsg_diffnet* h, int32_t enable);   /* 0: this handle's residual stack on the fp32 matrix pipe only (as BSG_H2=0) */
+/* ABI v7, the tier in between: 0 = not the 16-row stack launch (residual_stack_q_kernel: its conv image holds 16 x, so its range guard
+ * trips at |x| >= 3750) but the 32-row one (residual_stack_h2_kernel: |x + d| < 60000, about 8 % slower), as BSG_H2_Q=0 does for the
+ * process.  Recovery order of a range event (status word 1) in the 16-row launch: bsg_diffnet_set_h2q(h, 0), repeat; only if that launch
+ * trips too bsg_diffnet_set_h2(h, 0) (the fp32 matrix pipe, about 2x slower). */
+int bsg_diffnet_set_h2q(bsg_diffnet* h, int32_t enable);
 int bsg_gemm_range_events(int32_t* events, int32_t reset, void* stream);
 /* ABI v5, non-blocking: enqueues a copy of the counter into *host_word (pinned host memory) on `stream`; nothing is reset. */
 int bsg_gemm_range_events_async(int32_t* host_word, void* stream);
+
+/* ABI v7: the range guard is PER HANDLE.  Every bsg_diffnet / bsg_fs2midi / bsg_hifigan / bsg_pitchext / bsg_fftden owns the device word
+ * its split-fp16 kernels count out-of-range operands into, and its own switch between the split-fp16 products and the fp32 matrix pipe:
+ * an out-of-range input to one model demotes THAT handle only ("distinct handles are independent", top of this file); inside a handle's
+ * compute entries the state is looked up thread-locally, so two host threads on two handles do not see each other.  The two process-wide
+ * functions above remain as the guard of the handle-less entries (bsg_gemm_f32, bsg_gemm_presplit_f32) and as a test hook:
+ * bsg_gemm_set_split(0) (like BSG_GEMM_SPLIT=0 in the environment) is AND-ed into every handle's switch.
+ *   kind: which handle type `handle` points to.
+ *   bsg_handle_range_events        waits for `stream`; *events = waves of this handle's kernels that staged an operand beyond the fp16 range
+ *                                  (|16 v| >= 65000, i.e. |v| >= 4062) since the last reset; reset != 0 zeroes the word when it is non-zero
+ *   bsg_handle_range_events_async  no wait: enqueues the copy of the word into *host_word (pinned host memory) on `stream`
+ *   bsg_handle_set_gemm_split      0: this handle's GEMMs / fused attention / ResBlock convolutions on the fp32 matrix pipe; 1: split-fp16 again
+ *   bsg_handle_get_gemm_split      the EFFECTIVE switch (handle AND process-wide) */
+enum { BSG_HANDLE_DIFFNET = 0, BSG_HANDLE_FS2MIDI = 1, BSG_HANDLE_HIFIGAN = 2, BSG_HANDLE_PITCHEXT = 3, BSG_HANDLE_FFTDEN = 4 };
+int bsg_handle_range_events(int32_t kind, void* handle, int32_t* events, int32_t reset, void* stream);
+int bsg_handle_range_events_async(int32_t kind, void* handle, int32_t* host_word, void* stream);
+int bsg_handle_set_gemm_split(int32_t kind, void* handle, int32_t enable);
+int bsg_handle_get_gemm_split(int32_t kind, void* handle, int32_t* enabled);
 
 /* Round 4: the same products with PRE-SPLIT operands (csrc/gemm_h2w.hip gemm_h2w_kernel) — weights split once into hi / lo fp16 MFMA
  * fragments at create, activations written as hi / lo fp16 planes by their producers; FS2's Linear / Conv1d-FFN layers

@@ -260,9 +260,9 @@ def test_deferred_guard_mode_raises_one_call_late():
     finally:
         hparams.pop('guard_mode', None)
         torch.cuda.synchronize()
-        _lib.gemm_range_take()
+        net.gemm_range_take()
         net.take_health()
-        _lib.check(_lib.load().bsg_gemm_set_split(1), 'bsg_gemm_set_split')
+        net.set_gemm_split(True)
 
 
 WRAP_CHILD = r'''
