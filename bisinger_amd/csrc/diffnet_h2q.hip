@@ -222,6 +222,17 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
   // requested straight into the accumulators a phase before they are used
 #define BSG_CQ_LD(R, V, S) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(R, V, S, BSG_CQ_AUX))
   auto cond_request = [&](int l) {
+    if (DIAG == 4) {
+      // timing experiment (wrong results): the term costs NOTHING — a per-lane pseudo-value of its magnitude instead of the 128 KB per tile
+      // and layer from HBM: what is left is the layer without its only HBM stream
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int ct = 0; ct < NQ; ++ct)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[k][ct][i] = (float)((lane * 37 + l * 13 + 29 * k + 11 * ct + 5 * i) & 31) * 0.0625f - 1.0f;
+      return;
+    }
     if (p.condterm_q) {
       // channel-quad order [2C/4][T][4]: the 4 registers of an accumulator tile are ONE 16-byte load, 256 B contiguous per 16 lanes: 8 NCT
       // requests per lane instead of 32 NCT (as dwords every 128-byte line of the term was looked up by two requests of 64 B, and the
@@ -406,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
       };
       auto mid = [&]() {
         if (l == 0) return;   // layer 0 staged its halo rows from HBM
+        if (DIAG == 6) return;   // timing experiment (wrong results): no hand-off — no flag poll, no halo copy (the halo rows keep layer 0's), no barriers (D), (A)
         if (wave == 0) {
           // lane 0 polls the left neighbour's flag, lane 1 the right one's — both loads in flight together (one L2 round trip, not two)
           const unsigned want = p.fbase + (unsigned)l;
@@ -464,8 +476,17 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     for (int ct = 0; ct < NQ; ++ct) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        const f32x2 z01 = gate2_scaled(f32x2{y[rt][ct][0], y[rt][ct][1]}, f32x2{y[2 + rt][ct][0], y[2 + rt][ct][1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
-        const f32x2 z23 = gate2_scaled(f32x2{y[rt][ct][2], y[rt][ct][3]}, f32x2{y[2 + rt][ct][2], y[2 + rt][ct][3]}, gcg, gcf, glim, ZSCALE);
+        f32x2 z01, z23;
+        if (DIAG == 5) {
+          // timing experiment (wrong results): sigmoid x tanh costs NOTHING — a clamped product of the two halves (2 instructions per value
+          // instead of 2 exponentials, a reciprocal and ~12 others), values of the gate's magnitude
+          auto cheap = [&](float a, float c) { return __builtin_amdgcn_fmed3f(a * inv1 * (c * inv1) * 0.25f, -1.0f, 1.0f) * ZSCALE; };
+          z01 = f32x2{cheap(y[rt][ct][0], y[2 + rt][ct][0]), cheap(y[rt][ct][1], y[2 + rt][ct][1])};
+          z23 = f32x2{cheap(y[rt][ct][2], y[2 + rt][ct][2]), cheap(y[rt][ct][3], y[2 + rt][ct][3])};
+        } else {
+          z01 = gate2_scaled(f32x2{y[rt][ct][0], y[rt][ct][1]}, f32x2{y[2 + rt][ct][0], y[2 + rt][ct][1]}, gcg, gcf, glim, ZSCALE);   // 2^10 z from the raw (scaled) accumulators
+          z23 = gate2_scaled(f32x2{y[rt][ct][2], y[rt][ct][3]}, f32x2{y[2 + rt][ct][2], y[2 + rt][ct][3]}, gcg, gcf, glim, ZSCALE);
+        }
         const HiLo s0 = split2(z01[0], z01[1]), s1_ = split2(z23[0], z23[1]);
         char* dst = zs + (n16 + fo(ct)) * ROWB + (cw + 16 * rt) * 2;
         *reinterpret_cast<u32x2*>(dst) = u32x2{s0.hi, s1_.hi};
@@ -535,6 +556,10 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
     if (p.stamp_mode == 3 || p.stamp_mode >= 5) STK_STAMP(2);
     __syncthreads();   // (C1) the core rows are complete (every wave wrote its 32 channels of every frame)
     STK_STAMP(6);
+    if (DIAG == 6) {   // (no publish either: no edge stores, no drain, no flag, no barrier (C))
+      STK_STAMP(7);
+      continue;
+    }
     {
       // publish the first and the last 8 frames of both planes: [plane][side][8 frames][256 ch] fp16 = 16 KB, write-through
       unsigned short* hx_t = reinterpret_cast<unsigned short*>(p.hx) + ((long long)((l + 1) & 1) * n_tiles + tile_id) * (4 * 8 * C);
@@ -631,7 +656,8 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
   const dim3 grid(8 * cdiv(p.n_tiles, 8)), block(512);
   const TailArgs a = tail ? *tail : TailArgs{};
   const size_t lds = h2_lds(NCT);
-  static int diag = -1;   // BSG_H2Q_DIAG=1 / 2 / 3: timing experiments on the launches of 64-frame tiles (1: no weight reloads, 2: no operand reads either — wrong results; 3: a stamp per pass)
+  static int diag = -1;   // BSG_H2Q_DIAG=1 / 2 / 3 / 4 / 5 / 6: timing experiments on the launches of 64-frame tiles (1: no weight reloads, 2: no operand reads either; 3: a stamp per pass;
+                          // round 6, the buckets outside the GEMM phases: 4: no conditioner-term loads, 5: a two-instruction gate, 6: no hand-off and no publish — all but 3: wrong results)
   if (diag < 0) { const char* e = getenv("BSG_H2Q_DIAG"); diag = e ? atoi(e) : 0; }
   if constexpr (NCT == 2) {
     if (diag) {
@@ -643,6 +669,9 @@ static int h2q_launch(const StackArgs& p, const TailArgs* tail, hipStream_t st) 
       };
       if (diag == 1) go(residual_stack_q_kernel<true, true, 2, 1, NS>, residual_stack_q_kernel<true, false, 2, 1, NS>);
       else if (diag == 2) go(residual_stack_q_kernel<true, true, 2, 2, NS>, residual_stack_q_kernel<true, false, 2, 2, NS>);
+      else if (diag == 4) go(residual_stack_q_kernel<true, true, 2, 4, NS>, residual_stack_q_kernel<true, false, 2, 4, NS>);
+      else if (diag == 5) go(residual_stack_q_kernel<true, true, 2, 5, NS>, residual_stack_q_kernel<true, false, 2, 5, NS>);
+      else if (diag == 6) go(residual_stack_q_kernel<true, true, 2, 6, NS>, residual_stack_q_kernel<true, false, 2, 6, NS>);
       else go(residual_stack_q_kernel<true, true, 2, 3, NS>, residual_stack_q_kernel<true, false, 2, 3, NS>);
       BSG_LAUNCH_CHECK();
       return BSG_OK;

@@ -263,3 +263,44 @@ print(json.dumps(out))
         print(f'bf16 stack vs per-layer {k}: max-abs {dev:.2e}, rms {rms:.2e}')
         assert dev <= 2e-2 and rms <= 2e-3
 
+
+
+def test_bf16_trajectory_vs_emulating_oracle():
+    """the WHOLE 100-step DDPM trajectory of the bf16-operand configuration (stack launch + bf16 step tail) at B = 2,
+    T = 256 against an INDEPENDENT oracle that emulates the same roundings — operands of both GEMMs, the skip sum rounded once per
+    evaluation (the stack launch keeps it in fp32 registers), skip / output projection and, from the second evaluation on, the input
+    projection with bf16 operands — not against the HIP fp32 path (that comparison is tests/test_gpu_bf16.py::test_bf16_sampler_... and
+    test_gpu_fullsize.py, self-comparisons).  Same statistical bounds as test_config2_bf16_full_size_vs_emulating_oracle: bf16 roundings
+    sit at decision boundaries, a 1e-7 summation-order difference flips an operand by one bf16 ulp now and then and 100 steps carry every
+    flip forward, so the agreement with the emulation is statistical — closer (rms) to the emulation than the emulation is to fp32, a
+    max-abs of the order of the roundings' own; a wrong tile, tap, channel order or tail weight shows as O(1)."""
+    from oracle import diffusion as odf
+    m = _sampler_model()
+    sd = cpu_sd(m)
+    B, T = 2, 256
+    rs = np.random.RandomState(77)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32))
+    noise = T_(synth.synth_noise(100, B, 80, T, seed=6))
+    x0 = noise[0][:, None].contiguous()
+    m.denoise_fn.set_compute('bf16')
+    try:
+        got = m.sample(cond.cuda(), x0.clone().cuda(), noise=noise[1:].cuda(), n_steps=100).cpu()
+        path = m.denoise_fn.last_path()
+    finally:
+        m.denoise_fn.set_compute('fp32')
+    assert path == 'stack_bf16' and bool(torch.isfinite(got).all())
+    sch = odf.make_schedule(100, 'linear', 0.06)
+    calls = []
+
+    def denoise_emu(x, t):
+        calls.append(1)
+        return odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.', operand_bf16=True, skip_rounding='final', tail_bf16=True, in_bf16=len(calls) > 1)
+    emu = odf.ddpm_sample(sch, denoise_emu, x0, noise[1:][:, :, None], 100)
+    f32 = odf.ddpm_sample(sch, lambda x, t: odn.diffnet_forward(sd, x, t, cond, 'denoise_fn.'), x0, noise[1:][:, :, None], 100)
+    e, q = maxabs(got, emu), maxabs(emu, f32)
+    rms = float((got - emu).pow(2).mean().sqrt())
+    rms_q = float((emu - f32).pow(2).mean().sqrt())
+    rms_x = float(f32.pow(2).mean().sqrt())
+    print(f'bf16 trajectory B={B} T={T}, 100 steps (x rms {rms_x:.3f}): HIP-bf16 vs bf16-emulating oracle max-abs {e:.3e}, rms {rms:.2e}; the roundings '
+          f'themselves cost max-abs {q:.3e}, rms {rms_q:.2e} vs the fp32 oracle')
+    assert rms <= rms_q and e <= 2.0 * q and e <= 0.1 * max(rms_x, 0.1)
