@@ -2348,7 +2348,7 @@ extern "C" int bsg_diffnet_health_take(bsg_diffnet* h, int32_t* counts, void* st
   if (h->flags) BSG_HIP(hipMemcpyAsync(&v[0], h->flags + h->flags_cap, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
   if (h->split_flags) BSG_HIP(hipMemcpyAsync(&v[2], h->split_flags + 16 * h->split_cap, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   BSG_HIP(hipStreamSynchronize(st));
-  if (v[0] | v[1]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap, 0, 2 * sizeof(unsigned), st));
+  if (v[0] | v[1]) BSG_HIP(hipMemsetAsync(h->flags + h->flags_cap, 0, 3 * sizeof(unsigned), st));   // (word 2: the flag base of the part launch that gave up)
   if (v[2]) BSG_HIP(hipMemsetAsync(h->split_flags + 16 * h->split_cap, 0, sizeof(unsigned), st));
   counts[0] = (int32_t)(v[0] + v[2]);
   counts[1] = (int32_t)v[1];

@@ -1218,24 +1218,33 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
   unsigned* fz = p.pflags + P * n_tiles;     // z flags     [n_tiles][P]
   unsigned* xcc_tab = p.pflags + 2 * P * n_tiles;   // [n_tiles][P]: launch epoch + the XCC id the part runs on
   const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+  // A give-up of THIS launch is recorded twice: counted in status word 0 (cumulative until the host takes it) and, as the launch's own flag
+  // base, in status word 2.  Only the second makes the other waits of the launch return at once: word 0 may still hold a give-up of an
+  // EARLIER launch that the host has not taken yet (guard_mode 'deferred', captured replays, ABI users who only poll bsg_diffnet_status) —
+  // a later launch must then wait for its partners as usual, not skip every hand-off and produce garbage too
+  auto give_up = [&]() {
+    atomicAdd(p.status, 1u);
+    __hip_atomic_store(p.status + 2, p.fbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto launch_gave_up = [&]() { return __hip_atomic_load(p.status + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.fbase; };
   auto wait_flags = [&](const unsigned* fl, unsigned want) {   // a whole wave: every lane with a flag polls its own; bounded
     bool pend = fl != nullptr;
     if (p.inject == 1) {
-      if (pend) atomicAdd(p.status, 1u);
+      if (pend) give_up();
       return;
     }
-    // a launch that has already counted a give-up (status != 0: the host repeats the call anyway) waits for nothing any more — in particular
-    // not for flags that partners on ANOTHER XCD store plainly and that never become visible here (checked first, below)
-    if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    // a launch that has already counted a give-up (the host repeats the call anyway) waits for nothing any more — in particular not for
+    // flags that partners on ANOTHER XCD store plainly and that never become visible here (checked first, below)
+    if (launch_gave_up()) return;
     unsigned spins = 0;
     while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
       if (pend) pend = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;
       if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
       __builtin_amdgcn_s_sleep(2);
       ++spins;
-      const bool quit = spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u);
+      const bool quit = spins > (1u << 22) || ((spins & 1023u) == 0u && launch_gave_up());
       if (quit) {
-        if (pend) atomicAdd(p.status, 1u);
+        if (pend) give_up();
         break;
       }
     }
@@ -1534,9 +1543,9 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
               }
               if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
               __builtin_amdgcn_s_sleep(2);
-              if (++spins > (1u << 22) || ((spins & 1023u) == 0u && __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) break;
+              if (++spins > (1u << 22) || ((spins & 1023u) == 0u && launch_gave_up())) break;
             }
-            if (xw != nullptr && p.inject != 1 && (pend || theirs != p.fbase + my_xcc)) atomicAdd(p.status, 1u);
+            if (xw != nullptr && p.inject != 1 && (pend || theirs != p.fbase + my_xcc)) give_up();
           }
           wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
         }

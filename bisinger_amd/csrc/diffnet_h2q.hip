@@ -319,7 +319,9 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const float v0 = xr16[ct][rt][0], v1 = xr16[ct][rt][1], v2 = xr16[ct][rt][2], v3 = xr16[ct][rt][3];
-        worst = max(max(worst, max(absbits(v0), absbits(v1))), max(absbits(v2), absbits(v3)));
+        // (columns beyond T hold other rows' values — they are not clamped, only masked below: they must not raise a range event either)
+        const unsigned w4 = max(max(absbits(v0), absbits(v1)), max(absbits(v2), absbits(v3)));
+        worst = max(worst, all_cols || col_ok(ct) ? w4 : 0u);
         const HiLo s0 = split2(v0, v1);
         const HiLo s1_ = split2(v2, v3);
         u32x2 wh = u32x2{s0.hi, s1_.hi}, wl = u32x2{s0.lo, s1_.lo};
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void residual_stack_q_kernel(StackArgs p, T
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) worst = max(worst, absbits(sk[ct][rt][i]));   // |s| <= |skip sum|
+          for (int i = 0; i < 4; ++i) worst = max(worst, all_cols || col_ok(ct) ? absbits(sk[ct][rt][i]) : 0u);   // |s| <= |skip sum|; real frames only
       range_check(worst);
 #pragma unroll
       for (int ct = 0; ct < NQ; ++ct)
