@@ -118,8 +118,27 @@ for cfg in ('f32', 'bf16', 'voc', 'voc1', 'rank', 'b1'):
         once = [k for k in out if 'conv_post_kernel' in k]
         fw = min((out[k]['FETCH_SIZE']['n'] for k in once), default=0) or int(os.environ.get('PN', 5))
         tot = sum(e['hbm_bytes_per_launch'] * out[k]['FETCH_SIZE']['n'] for k, e in per_kernel.items() if 'hbm_bytes_per_launch' in e and k in out)
+        # attribution: bytes of one forward per kernel, and per generator stage.  The stage of a ResBlock kernel is its
+        # channel count (template argument C: 64 -> stage 0 at 8 000 positions, 32 -> stage 1 at 64 000, 16 -> stage 2 at 128 000, 8 -> stage 3
+        # at 256 000); the up-sampling GEMM / transposed convolutions and conv_pre / conv_post are listed by name
+        import re
+        by_kernel, by_stage = {}, collections.defaultdict(float)
+        for k, e in per_kernel.items():
+            if 'hbm_bytes_per_launch' not in e or k not in out:
+                continue
+            b = e['hbm_bytes_per_launch'] * out[k]['FETCH_SIZE']['n'] / fw
+            by_kernel[k] = {'launches_per_forward': out[k]['FETCH_SIZE']['n'] / fw, 'hbm_bytes_per_forward': round(b), 'avg_us': e.get('avg_us')}
+            m = re.match(r'resblock_\w+_kernel<(\d+), *(\d+)', k)
+            if m:
+                by_stage[f'ResBlocks C={m.group(2)}'] += b
+            elif 'upsample' in k or 'gemm_h2w' in k or 'h2w_split' in k or 'conv1d_kernel' in k:
+                by_stage['up-sampling (transposed convolutions as GEMM / polyphase kernels, incl. conv_pre on the GEMM)'] += b
+            else:
+                by_stage['other (conv_post, padding, NSF ...)'] += b
         json.dump({'B': 1, 'T': 1000, 'forwards': fw, 'hbm_bytes_per_forward': tot / fw, 'build_sha256': BUILD,
                    'algorithmic_bytes_per_forward': 80 * 1000 * 4 + 256000 * 4,
+                   'by_stage_bytes_per_forward': {k: round(v) for k, v in sorted(by_stage.items(), key=lambda kv: -kv[1])},
+                   'by_kernel': dict(sorted(by_kernel.items(), key=lambda kv: -kv[1]['hbm_bytes_per_forward'])),
                    'source': 'bench_voc1_pmc_summary.json of the same passes (tools/run_profiles.sh): 2 x FETCH_SIZE + WRITE_SIZE over every launch'},
                   open(f'{dst}/traffic_voc.json', 'w'), indent=1)
     json.dump(summ, open(f'{dst}/bench_{cfg}_pmc_summary.json', 'w'), indent=1)
