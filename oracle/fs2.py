@@ -110,21 +110,27 @@ def fft_blocks(sd, p, x, pad_mask, n_layers, num_heads, kernel_size, use_pos_emb
     return x.transpose(0, 1)
 
 
-def esm(sd, p, Eo, LP, nhead, dtype):
+def esm(sd, p, Eo, LP, nhead, dtype, rows=None):
     """ESM.forward :848-860.  nn.MultiheadAttention is sequence-first but is fed [B,T,C]:
-    L = B, N = T_txt — the softmax runs over the *batch* axis."""
+    L = B, N = T_txt — the softmax runs over the *batch* axis.
+    ``rows`` (slice): the result for these batch rows only, computed the way a rank of a sharded run computes it
+    (bsg_fs2midi_encode_rows): K and V — projections of LN(LP), the only thing other rows contribute — for every row, the
+    queries, the residual and the FFN for the rows asked for.  Row for row the same sums as the whole-batch call."""
     g = lambda k: sd[p + k].to(dtype)
     L, N, C = Eo.shape
     hd = C // nhead
     LPn = F.layer_norm(LP, (C,), g('ln1.weight'), g('ln1.bias'), 1e-5)
     w, b = g('mh.in_proj_weight'), g('mh.in_proj_bias')
+    if rows is not None:
+        Eo, LP = Eo[rows], LP[rows]
+    Lq = Eo.shape[0]
     q = F.linear(Eo, w[:C], b[:C])
     k = F.linear(LPn, w[C:2 * C], b[C:2 * C])
     v = F.linear(LPn, w[2 * C:], b[2 * C:])
-    sh = lambda a: a.contiguous().view(L, N * nhead, hd).transpose(0, 1)       # [N*H, L, hd]
+    sh = lambda a: a.contiguous().view(a.shape[0], N * nhead, hd).transpose(0, 1)       # [N*H, L, hd]
     q, k, v = sh(q) * math.sqrt(1.0 / float(hd)), sh(k), sh(v)
     a = F.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
-    o = torch.bmm(a, v).transpose(0, 1).contiguous().view(L, N, C)
+    o = torch.bmm(a, v).transpose(0, 1).contiguous().view(Lq, N, C)
     Mo = F.linear(o, g('mh.out_proj.weight'), g('mh.out_proj.bias')) + LP
     h = F.layer_norm(Mo, (C,), g('ln2.weight'), g('ln2.bias'), 1e-5)
     h = F.linear(F.relu(F.linear(h, g('ffn.0.weight'), g('ffn.0.bias'))), g('ffn.2.weight'), g('ffn.2.bias'))
@@ -164,9 +170,13 @@ def length_regulator(dur, dur_padding):
 
 
 # ----------------------------------------------------------------------------- model
-def fs2_forward(sd, inp, prefix='fs2.', hp=None, skip_decoder=False, dtype=torch.float32, rows=None):
+def fs2_forward(sd, inp, prefix='fs2.', hp=None, skip_decoder=False, dtype=torch.float32, rows=None, local_front=False):
     """FastSpeech2MIDI.forward(infer=True) with use_spk_id, no pitch/energy embed
-    (diffsinger_midi/fs2.py:94-197).  ``inp``: dict of tensors (see bisinger_amd/synth.py)."""
+    (diffsinger_midi/fs2.py:94-197).  ``inp``: dict of tensors (see bisinger_amd/synth.py).
+    ``rows``: the outputs for these batch rows (a rank of a sharded run).  By default the token-level front
+    is the reference's — evaluated on the whole batch — and sliced; ``local_front=True`` (needs ``mel2ph``) restates what
+    bsg_fs2midi_encode_rows does instead: only the ESM's K / V see every row, everything else runs on ``rows``
+    (tests/test_dist_cpu.py holds the two against each other)."""
     hp = {**DEFAULT_HP, **(hp or {})}
     H = hp['hidden_size']
     g = lambda k: sd[prefix + k].to(dtype)
@@ -178,7 +188,14 @@ def fs2_forward(sd, inp, prefix='fs2.', hp=None, skip_decoder=False, dtype=torch
     lang = F.embedding(inp['lang'], g('lang_embed.weight'))
     # FastspeechMIDIEncoder.forward_embedding :19-39
     x = math.sqrt(H) * F.embedding(txt, g('encoder.embed_tokens.weight'))
-    dyn = esm(sd, prefix + 'esm.', x, lang, hp['esm_heads'], dtype)
+    if local_front:
+        assert rows is not None and inp.get('mel2ph') is not None, 'local_front: a row slice and a given mel2ph'
+        dyn = esm(sd, prefix + 'esm.', x, lang, hp['esm_heads'], dtype, rows=rows)
+        x, midi, mdur, slur, txt = x[rows], midi[rows], mdur[rows], slur[rows], txt[rows]
+        inp = dict(inp, spk_embed=inp['spk_embed'][rows], speechsing=inp['speechsing'][rows], mel2ph=inp['mel2ph'][rows])
+        rows = None
+    else:
+        dyn = esm(sd, prefix + 'esm.', x, lang, hp['esm_heads'], dtype)
     x = x + midi + mdur + slur + dyn
     T_txt = x.shape[1]
     pe = rel_pos_table(max(hp['rel_pos_max_len'], T_txt), H).to(dtype)

@@ -45,3 +45,23 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith('.py'):
                 txt = open(os.path.join(dp, fn)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), fn
+
+
+def test_create_refuses_channel_counts_other_than_256_with_a_message():
+    """hparams['residual_channels'] / ['hidden_size'] other than 256 (no shipped config has one): BSG_EINVAL and a message naming the value at
+    create, before any device call — checked here without a GPU ("Differences from the reference's surface")."""
+    import ctypes
+    from ctypes import POINTER, byref, c_void_p, cast
+    lib = _lib.load()
+    dummy = (c_void_p * 200)(*([1] * 200))
+    h = c_void_p()
+    cfg = _lib.DiffnetCfg(80, 384, 384, 20, 4, 1000)
+    rc = lib.bsg_diffnet_create(byref(h), byref(cfg), cast(dummy, POINTER(c_void_p)), 170, c_void_p(1), None)
+    assert rc != 0 and h.value is None
+    msg = lib.bsg_last_error().decode()
+    assert '384' in msg and '256' in msg, msg
+    fcfg = _lib.Fs2Cfg(192, 65, 4, 4, 2, 9, 9, 80, 2, 3, 22, 8, 2002, 5000)
+    rc = lib.bsg_fs2midi_create(byref(h), byref(fcfg), cast(dummy, POINTER(c_void_p)), 143, c_void_p(1), c_void_p(1), None)
+    assert rc != 0 and h.value is None
+    msg = lib.bsg_last_error().decode()
+    assert '192' in msg and '256' in msg, msg

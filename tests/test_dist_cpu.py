@@ -64,6 +64,32 @@ def test_sharded_equals_unsharded_world2(tmp_path, B):
     assert np.abs(r['naive'] - r['ref']).max() > 1e-3
 
 
+def test_rank_local_front_equals_the_whole_batch_front():
+    """What bsg_fs2midi_encode_rows computes (restated in oracle.fs2.fs2_forward(local_front=True)): the ESM's K / V — projections of
+    LN(lang_embed[lang]), common_layers.py:850-853 — from EVERY row of the batch, everything else of the token-level front on the rank's
+    rows.  Against the reference's way (the front on the whole batch, sliced): the same rows to fp32 rounding — and a front that saw the
+    rank's rows ALONE is off by far more than the parity bar."""
+    from bisinger_amd import synth
+    from oracle import fs2 as ofs2
+    torch.manual_seed(0)
+    import json
+    spec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'state_dict_spec.json')))
+    from collections import OrderedDict
+    sdspec = OrderedDict((k, tuple(v)) for k, v in spec['GaussianDiffusion'] if k.startswith('fs2.'))
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(sdspec, 0).items()}
+    B, Tt, T = 6, 20, 60
+    inp = {k: torch.from_numpy(v) for k, v in synth.synth_inputs(B, Tt, T, seed=2, ragged=True).items()}
+    inp['lang'] = torch.from_numpy(np.random.RandomState(1).randint(0, 2, (B, Tt)).astype(np.int64))
+    for rows in (slice(0, 2), slice(2, 5), slice(5, 6)):
+        ref = ofs2.fs2_forward(sd, inp, 'fs2.', rows=rows)
+        loc = ofs2.fs2_forward(sd, inp, 'fs2.', rows=rows, local_front=True)
+        alone = ofs2.fs2_forward(sd, {k: v[rows] for k, v in inp.items()}, 'fs2.')
+        for k in ('decoder_inp', 'mel_out'):
+            assert float((ref[k] - loc[k]).abs().max()) <= 2e-5, k
+        assert torch.equal(ref['mel2ph'], loc['mel2ph'])
+        assert float((ref['decoder_inp'] - alone['decoder_inp']).abs().max()) > 1e-3
+
+
 def test_shard_rows_partition():
     for B in (1, 7, 16, 64):
         for w in (1, 2, 3, 8):
