@@ -834,7 +834,8 @@ def main():
                 # configs[1] (B = 16) and must not be divided into them
                 rec['strong_denominator'] = {'B': B_CFG3_TOTAL, 'value': c3['value_b64_one_gpu'], 'ms_per_step': c3['ms_per_step_b64_one_gpu'],
                                              'unit': 'mel-frames/s', 'note': 'configs[3] on ONE GPU: all 64 utterances, same pass as the N > 1 runs'}
-        if world == 1 and not bf16:
+        if world == 1 and not bf16 and not args.no_secondary and args.batch is None:
+            # (with the secondaries: the probe runs per-layer launches of the fp32 matrix pipe, which do not belong into a profile of the headline)
             rec['range_headroom'] = range_headroom(model, wl, device)
         if world == 1 and args.cpu_steps > 0:
             base, parity = cpu_baseline_and_parity(model, wl.inp_np, device, args.cpu_steps)

@@ -8,7 +8,7 @@
 # Summaries: tools/summarize_profiles.py -> profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${PROF_OUT:-prof}; mkdir -p $O
-for cfg in f32 bf16 voc voc1 rank b1; do
+for cfg in ${CFGS:-f32 bf16 voc voc1 rank b1}; do
   export PB=16 PW=1 PN=5
   case $cfg in
     f32) CMD="python3 $R/bench.py --dtype f32 --no-secondary --cpu-steps 0";;
