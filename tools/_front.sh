@@ -3,7 +3,7 @@
 # the host's pass time has beyond the GPU span.  PB / PW as tools/prof_rank.py.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/front; rm -rf $O
-PB=${PB:-64} PW=${PW:-8} PN=3 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/tools/prof_rank.py > $O.log 2>&1
+PB=${PB:-64} PW=${PW:-8} PN=${PN:-3} timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/tools/prof_rank.py > $O.log 2>&1
 grep "rank pass" $O.log
 python3 - <<'PY'
 import csv,glob,os
