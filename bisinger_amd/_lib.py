@@ -439,16 +439,16 @@ def range_guarded(run, what, on_retry=None, device=None, owners=()):
     try:
         if guard_mode() == 'deferred':
             check_deferred(device)
-            # a detection moved some handles to the fp32 pipe for THIS call; it puts them back (also when run() raises — a nested handle's
-            # check_deferred, say: the switch back would otherwise be lost and the handle stay on the fp32 pipe for good)
-            restore = [o for o in _deferred_objs if getattr(o, '_restore_split_after', False)]
-            for o in restore:
-                o._restore_split_after = False
+            # a detection moved a handle to the fp32 pipe for the NEXT call in which it takes part; that call puts it back — also when run()
+            # raises (a nested handle's check_deferred, say): the switch back would otherwise be lost and the handle stay on the fp32 pipe
+            # for good.  Only the handles of THIS call: another model's call in between must not consume the switch
             try:
                 out = run()
             finally:
-                for o in restore:
-                    o.set_gemm_split(True)
+                for o in st.owners:
+                    if getattr(o, '_restore_split_after', False):
+                        o._restore_split_after = False
+                        o.set_gemm_split(True)
             _deferred_enqueue(st.owners)
             return out
         out = run()
