@@ -208,6 +208,43 @@ def gemm_range_peek(device=None):
     return n.value
 
 
+class HandleOwner:
+    """Mixin of every module that owns a library handle: the handle is re-created when a parameter or buffer was moved, replaced or
+    modified (load_ckpt, .to(), an in-place edit) — told from (data_ptr, _version) of every state_dict entry.  Walking the module tree for
+    that (state_dict()) costs 250-300 us per look, and a pass looks several times: ~1 ms of host time per pass, most of the gaps between
+    the front's kernels (tools/_front.sh).  The SLOTS — (dict of the owning module, name) of every parameter and persistent buffer — are
+    found once (the module tree of these drop-ins is fixed after construction); a look reads each slot's current tensor: a replaced
+    tensor (a buffer after .to(), an assigned Parameter) is seen like a modified one.  50 us."""
+
+    def _slots(self):
+        slots = self.__dict__.get('_handle_slots')
+        if slots is None:
+            slots = []
+            for mod in self.modules():
+                slots.extend((mod._parameters, n) for n, v in mod._parameters.items() if v is not None)
+                slots.extend((mod._buffers, n) for n, v in mod._buffers.items() if v is not None and n not in mod._non_persistent_buffers_set)
+            self.__dict__['_handle_slots'] = slots
+        return slots
+
+    def _weights(self):
+        """The tensors in state_dict() order: the order of the ABI's weight pointer arrays."""
+        return list(self.state_dict(keep_vars=True).values())
+
+    def _key(self):
+        for attempt in (0, 1):
+            k = []
+            try:
+                for d, n in self._slots():
+                    t = d[n]
+                    k.append(t.data_ptr())
+                    k.append(t._version)
+                return tuple(k)
+            except (KeyError, AttributeError):      # a parameter was removed or set to None (weight norm folded ...): find the slots again
+                self.__dict__.pop('_handle_slots', None)
+                if attempt:
+                    raise
+
+
 class GemmGuarded:
     """Mixin of every module that owns a library handle (``self._h``; ``GUARD_KIND`` names its type): the range guard of the handle's
     split-fp16 GEMMs / fused attention / ResBlock convolutions is the HANDLE's — its own device word, its own switch to the fp32 matrix

@@ -16,7 +16,7 @@ from .fs2 import FFTBlocks
 from .hparams import hparams
 
 
-class FFT(FFTBlocks, _lib.GemmGuarded):
+class FFT(FFTBlocks, _lib.HandleOwner, _lib.GemmGuarded):
     GUARD_KIND = 'fftden'
 
     def __init__(self, hidden_size=None, num_layers=None, kernel_size=None, num_heads=None):
@@ -36,12 +36,6 @@ class FFT(FFTBlocks, _lib.GemmGuarded):
         self.get_mel_out = nn.Linear(hidden_size, 80, bias=True)
         self.get_decode_inp = nn.Linear(hidden_size + dim + dim, hidden_size)
         self._h = self._h_key = self._bound = None
-
-    def _weights(self):
-        return list(self.state_dict(keep_vars=True).values())
-
-    def _key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
 
     def handle(self):
         key = self._key()

@@ -54,7 +54,7 @@ class ResidualBlock(nn.Module):
         self.output_projection = _conv1d(residual_channels, 2 * residual_channels, 1)
 
 
-class DiffNet(nn.Module, _lib.GemmGuarded):
+class DiffNet(nn.Module, _lib.HandleOwner, _lib.GemmGuarded):
     GUARD_KIND = 'diffnet'
 
     def __init__(self, in_dims=80):
@@ -81,12 +81,6 @@ class DiffNet(nn.Module, _lib.GemmGuarded):
         self._bound = None
 
     # ------------------------------------------------------------------ handle management
-    def _weights(self):
-        return list(self.state_dict(keep_vars=True).values())
-
-    def _key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
-
     def handle(self):
         """(Re)create the library handle when the parameters moved or changed (load_ckpt, .to())."""
         key = self._key()
@@ -210,7 +204,7 @@ class DiffNet(nn.Module, _lib.GemmGuarded):
         from ctypes import c_int32
         u = c_int32()
         with _lib.on_device(self):
-            _lib.check(_lib.load().bsg_diffnet_uses_handoffs(self.handle(), B, T, byref(u)), 'bsg_diffnet_uses_handoffs')
+            _lib.check(_lib.load().bsg_diffnet_uses_handoffs(self._h if self._h is not None else self.handle(), B, T, byref(u)), 'bsg_diffnet_uses_handoffs')
         return bool(u.value)
 
     def take_handoff_timeouts(self):
@@ -438,7 +432,7 @@ class DiffNet(nn.Module, _lib.GemmGuarded):
 
     def last_path(self):
         """Form of the last residual-layer launch: 'stack', 'layer', 'split2', 'split4', 'wide', 'bf16' or 'none'."""
-        return _lib.load().bsg_diffnet_last_path(self.handle()).decode()
+        return _lib.load().bsg_diffnet_last_path(self._h if self._h is not None else self.handle()).decode()      # (a query of the handle that exists: no look at the weights)
 
     def handoff_timeouts(self):
         """Hand-off health: spins that gave up and were not yet taken (0 unless a workgroup was not resident). Synchronises."""

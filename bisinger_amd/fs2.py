@@ -181,7 +181,7 @@ class DurationPredictor(_Holder):
         self.linear = nn.Linear(n_chans, 1)
 
 
-class FastSpeech2MIDI(nn.Module, _lib.GemmGuarded):
+class FastSpeech2MIDI(nn.Module, _lib.HandleOwner, _lib.GemmGuarded):
     GUARD_KIND = 'fs2midi'
 
     def __init__(self, dictionary, out_dims=None):
@@ -215,12 +215,6 @@ class FastSpeech2MIDI(nn.Module, _lib.GemmGuarded):
         self._h_key = None
 
     # ------------------------------------------------------------------ handle management
-    def _weights(self):
-        return list(self.state_dict(keep_vars=True).values())
-
-    def _key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
-
     def handle(self):
         key = self._key()
         if self._h is not None and key == self._h_key:
@@ -310,7 +304,7 @@ class FastSpeech2MIDI(nn.Module, _lib.GemmGuarded):
         """-> (token rows the last encode ran its encoder on, rows of the last FFT stack): test introspection."""
         from ctypes import c_int32
         a, b = c_int32(), c_int32()
-        _lib.check(_lib.load().bsg_fs2midi_last_rows(self.handle(), byref(a), byref(b)), 'bsg_fs2midi_last_rows')
+        _lib.check(_lib.load().bsg_fs2midi_last_rows(self._h if self._h is not None else self.handle(), byref(a), byref(b)), 'bsg_fs2midi_last_rows')
         return a.value, b.value
 
     @torch.no_grad()

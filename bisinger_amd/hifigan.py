@@ -92,7 +92,7 @@ class ResBlock2(nn.Module):
             c.fold()
 
 
-class HifiGanGenerator(nn.Module, _lib.GemmGuarded):
+class HifiGanGenerator(nn.Module, _lib.HandleOwner, _lib.GemmGuarded):
     GUARD_KIND = 'hifigan'
 
     def __init__(self, h, c_out=1):
@@ -139,14 +139,9 @@ class HifiGanGenerator(nn.Module, _lib.GemmGuarded):
             l.remove_weight_norm()
         self.conv_pre.fold()
         self.conv_post.fold()
+        self.__dict__.pop('_handle_slots', None)      # the parameters changed NAMES (weight_g / weight_v -> weight): look the slots up again
 
     # ------------------------------------------------------------------ handle
-    def _weights(self):
-        return list(self.state_dict(keep_vars=True).values())
-
-    def _key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
-
     def handle(self):
         key = self._key()
         if self._h is not None and key == self._h_key:

@@ -69,7 +69,7 @@ class PitchPredictor(_Holder):
         self.pos_embed_alpha = nn.Parameter(torch.Tensor([1]))
 
 
-class PitchExtractor(nn.Module, _lib.GemmGuarded):
+class PitchExtractor(nn.Module, _lib.HandleOwner, _lib.GemmGuarded):
     GUARD_KIND = 'pitchext'
 
     def __init__(self, n_mel_bins=80, conv_layers=2):
@@ -86,12 +86,6 @@ class PitchExtractor(nn.Module, _lib.GemmGuarded):
         self.pitch_predictor = PitchPredictor(self.hidden_size, n_chans=ph, n_layers=5, dropout_rate=0.5, odim=2,
                                               kernel_size=self.predictor_kernel)
         self._h = self._h_key = None
-
-    def _weights(self):
-        return list(self.state_dict(keep_vars=True).values())
-
-    def _key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self._weights())
 
     def handle(self):
         key = self._key()
