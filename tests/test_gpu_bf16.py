@@ -304,3 +304,37 @@ def test_bf16_trajectory_vs_emulating_oracle():
     print(f'bf16 trajectory B={B} T={T}, 100 steps (x rms {rms_x:.3f}): HIP-bf16 vs bf16-emulating oracle max-abs {e:.3e}, rms {rms:.2e}; the roundings '
           f'themselves cost max-abs {q:.3e}, rms {rms_q:.2e} vs the fp32 oracle')
     assert rms <= rms_q and e <= 2.0 * q and e <= 0.1 * max(rms_x, 0.1)
+
+
+def test_set_compute_between_prepare_and_forward_is_refused_both_ways():
+    """a BF16 prepare writes the bf16 quads of the conditioner term only — no fp32 copy since round 5 — so a direct ABI
+    user who calls bsg_diffnet_set_compute(F32) behind it and then evaluates would read a stale / uninitialised fp32 term.  check_bound now
+    refuses a compute mode other than the prepared one in BOTH directions (BSG_ESTATE + a message); a new prepare makes the handle usable again
+    (the Python wrapper does that by itself: DiffNet.set_compute drops the binding)."""
+    from ctypes import c_void_p
+    from bisinger_amd import _lib
+    m = _sampler_model()
+    net = m.denoise_fn
+    lib = _lib.load()
+    B, T = 2, 96
+    rs = np.random.RandomState(8)
+    cond = T_(rs.standard_normal((B, 256, T)).astype(np.float32)).cuda()
+    x = T_(rs.standard_normal((B, 80, T)).astype(np.float32)).cuda()
+    t = torch.tensor([3, 70], device='cuda')
+    eps = torch.empty_like(x)
+    h = net.handle()
+    fwd = lambda: lib.bsg_diffnet_forward(h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(eps), B, T, _lib.stream_ptr())
+    prep = lambda: lib.bsg_diffnet_prepare(h, _lib.ptr(cond), B, T, _lib.stream_ptr())
+    try:
+        for first, second in ((1, 0), (0, 1)):          # BSG_COMPUTE_BF16 = 1, BSG_COMPUTE_F32 = 0
+            assert lib.bsg_diffnet_set_compute(h, first) == 0 and prep() == 0 and fwd() == 0
+            assert lib.bsg_diffnet_set_compute(h, second) == 0
+            rc = fwd()
+            assert rc != 0 and 'bsg_diffnet_prepare again' in lib.bsg_last_error().decode(), lib.bsg_last_error()
+            assert prep() == 0 and fwd() == 0                  # bound again under the new mode: valid
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(eps).all())
+    finally:
+        lib.bsg_diffnet_set_compute(h, 0)
+        net._bound = None
+        net.compute_dtype = 'fp32'

@@ -196,3 +196,75 @@ def test_default_launches_hold_on_reference_init_weights(kind):
             devs[(out_gain, parts)] = dev
     print(devs)
     assert max(devs.values()) <= 1e-4      # (north_star: 1e-3)
+
+
+def test_every_handle_kind_guards_itself_and_only_itself(hifigan_sd, sd_spec):
+    """The per-handle range guard on the three other handle kinds — HiFi-GAN generator, PitchExtractor, FFT candidate denoiser — beside a
+    DiffNet that must not notice: each gets an input that leaves the fp16 range of its split-fp16 products (|v| >= 4062), warns naming
+    ITSELF, returns what the same model gives with its products on the fp32 matrix pipe from the start, counts one strike, and is back on
+    the split form afterwards; the bystander's strike count, switch and launch form never change."""
+    import yaml
+    from collections import OrderedDict
+    from bisinger_amd.candidate_decoder import FFT
+    from bisinger_amd.diffnet import DiffNet
+    from bisinger_amd.hifigan import HifiGanGenerator
+    from bisinger_amd.pe import PitchExtractor
+    from tests.util import ROOT
+    hp = use_config()
+    hp.update(pitch_type='frame', use_uv=True, pitch_norm='log')
+    rs = np.random.RandomState(12)
+    by = load_formula_weights(DiffNet(80), 0, synth.DIFFNET_GAIN, prefix='denoise_fn.').cuda()
+    bx = T_(rs.standard_normal((2, 1, 80, 96)).astype(np.float32)).cuda()
+    bt = torch.full((2,), 11, device='cuda', dtype=torch.long)
+    bc = T_(rs.standard_normal((2, 256, 96)).astype(np.float32)).cuda()
+    ref_by = by(bx, bt, bc).clone()
+    path_by = by.last_path()
+
+    def bystander_untouched():
+        assert by.gemm_range_strikes == 0 and by.gemm_split_enabled()
+        assert torch.equal(by(bx, bt, bc), ref_by) and by.last_path() == path_by
+
+    def voc():
+        g = HifiGanGenerator(yaml.safe_load(open(f'{ROOT}/bisinger_amd/configs/hifigan.yaml')))
+        g.load_state_dict(hifigan_sd, strict=True)
+        return g.cuda()
+
+    def pe():
+        m = PitchExtractor()
+        spec = OrderedDict((k, tuple(s)) for k, s in sd_spec['PitchExtractor'])
+        w = synth.synth_state_dict(spec, seed=11)
+        for k in spec:
+            if k.endswith('running_var'):
+                w[k] = (0.5 + np.abs(w[k]) * 5).astype(np.float32)
+        m.load_state_dict({k: T_(v) for k, v in w.items()}, strict=False)
+        return m.cuda()
+
+    def fft():
+        m = FFT(256, 4, 9, 2)
+        spec = OrderedDict((k, tuple(s)) for k, s in sd_spec['FFT'])
+        m.load_state_dict({k: T_(v) for k, v in synth.synth_state_dict(spec, seed=17).items()}, strict=False)
+        return m.cuda()
+
+    mel_v = T_((rs.standard_normal((1, 80, 40)) * 1.5 - 3.0).astype(np.float32)).cuda() * 4e3      # conv_pre's operand: |v| ~ 2e4
+    mel_p = T_((rs.standard_normal((2, 50, 80)) * 1.5 - 3.0).astype(np.float32)).cuda() * 4e3
+    fx = T_(rs.standard_normal((2, 1, 80, 40)).astype(np.float32)).cuda()
+    ftt = torch.full((2,), 7, device='cuda', dtype=torch.long)
+    fc = T_(rs.standard_normal((2, 256, 40)).astype(np.float32)).cuda() * 2e4                        # the hoisted condition part's operand
+    cases = [('HifiGanGenerator', voc, lambda m: m(mel_v)), ('PitchExtractor', pe, lambda m: m(mel_p)['pitch_pred']),
+             ('FFT', fft, lambda m: m(fx, ftt, fc))]
+    for name, make, call in cases:
+        m = make()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            got = call(m).clone()
+        msgs = [str(v.message) for v in w]
+        assert any(name in s and 'fp16 range of the split-fp16 GEMMs' in s for s in msgs), (name, msgs)
+        assert m.gemm_range_strikes == 1 and m.gemm_split_enabled(), name
+        ref = make()
+        ref.set_gemm_split(False)                       # the fp32 matrix pipe from the first call on
+        with warnings.catch_warnings(record=True) as w2:
+            warnings.simplefilter('always')
+            want = call(ref)
+        assert not w2 and ref.gemm_range_strikes == 0, (name, [str(v.message) for v in w2])
+        assert torch.isfinite(got).all() and maxabs(got, want) <= 1e-5 * max(1.0, float(want.abs().max())), (name, maxabs(got, want))
+        bystander_untouched()
