@@ -1144,6 +1144,7 @@ struct bsg_diffnet {
   unsigned split_epoch = 0;
   bool split_off = false;              // bsg_diffnet_set_split(h, 0): regular launches only (the self-heal path after a give-up)
   int inject_giveup = 0;               // bsg_diffnet_debug_inject_giveup: split launches left that give up without waiting
+  int inject_nowait = 0;               // the same entry with a NEGATIVE count: part launches left that skip their waits silently (timing experiment)
   int inject_xcc = 0;                  // bsg_diffnet_debug_inject_xcc: part launches left in which odd parts report another XCD
   bool parts_off = false;              // bsg_diffnet_set_parts(h, 0): no part forms (several workgroups per tile on CUs of ONE XCD); the one-workgroup-per-tile launches stay
   // residency of the split kernels on this handle's device (workgroups per CU; -1 = not queried yet): pair / 4-way form with the
@@ -1888,6 +1889,7 @@ static int launch_stack(bsg_diffnet* h, const long long* t_dev, int t_uniform, i
     TRY(next_stack_epoch(h, p));
     if (h->inject_giveup > 0) { p.inject = 1; --h->inject_giveup; }
     else if (h->inject_xcc > 0 && h2 && h->stack_parts) { p.inject = 2; --h->inject_xcc; }
+    else if (h->inject_nowait > 0 && h2 && h->stack_parts) { p.inject = 3; --h->inject_nowait; }
     p.stamps = stamps && r0 == 0 ? stamps : nullptr;
     p.clk = h->prof_on && r0 == 0 ? h->clk : nullptr;
     if (stamps) { const char* e = getenv("BSG_STAMP_MODE"); p.stamp_mode = e ? atoi(e) : 0; }
@@ -2426,8 +2428,11 @@ extern "C" int bsg_diffnet_set_parts(bsg_diffnet* h, int32_t enable) {
 }
 
 extern "C" int bsg_diffnet_debug_inject_giveup(bsg_diffnet* h, int32_t n_launches) {
-  BSG_REQUIRE(h && n_launches >= 0, "diffnet_debug_inject_giveup: bad argument");
-  h->inject_giveup = n_launches;
+  BSG_REQUIRE(h, "diffnet_debug_inject_giveup: bad argument");
+  // n < 0 (timing experiment, tools/part_nowait.py): the next -n PART launches skip every hand-off wait without counting anything — wrong
+  // results, the same instructions otherwise: what the waits themselves cost
+  h->inject_giveup = n_launches > 0 ? n_launches : 0;
+  h->inject_nowait = n_launches < 0 ? -n_launches : 0;
   return BSG_OK;
 }
 

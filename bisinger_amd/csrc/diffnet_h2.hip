@@ -1233,6 +1233,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
       if (pend) give_up();
       return;
     }
+    if (p.inject == 3) return;   // timing experiment (tools/part_nowait.py; wrong results): no wait at all, nothing counted
     // a launch that has already counted a give-up (the host repeats the call anyway) waits for nothing any more — in particular not for
     // flags that partners on ANOTHER XCD store plainly and that never become visible here (checked first, below)
     if (launch_gave_up()) return;
@@ -1534,7 +1535,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
             // visible here and the mismatch was noticed after a full bounded spin, seconds).  The host then takes the part forms off
             // this handle and repeats the call on the one-workgroup-per-tile launch (DiffNet.guarded)
             const unsigned* xw = lane < P - 1 ? xcc_tab + P * tile_id + (lane < q ? lane : lane + 1) : nullptr;
-            bool pend = xw != nullptr && p.inject != 1;
+            bool pend = xw != nullptr && p.inject != 1 && p.inject != 3;
             unsigned theirs = 0, spins = 0;
             while (__builtin_amdgcn_ballot_w64(pend) != 0ull) {
               if (pend) {
@@ -1545,7 +1546,7 @@ __global__ __launch_bounds__(64 * W, 1) void residual_part_h2_kernel(StackArgs p
               __builtin_amdgcn_s_sleep(2);
               if (++spins > (1u << 22) || ((spins & 1023u) == 0u && launch_gave_up())) break;
             }
-            if (xw != nullptr && p.inject != 1 && (pend || theirs != p.fbase + my_xcc)) give_up();
+            if (xw != nullptr && p.inject != 1 && p.inject != 3 && (pend || theirs != p.fbase + my_xcc)) give_up();
           }
           wait_flags(lane < P - 1 ? fz + P * tile_id + (lane < q ? lane : lane + 1) : nullptr, p.fbase + (unsigned)(l + 1));
         }
