@@ -133,6 +133,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libbisinger_hip.so needs libamdhip64, and the process must hold ONE HIP runtime — the one torch ships and initialises.
+    # Loaded before torch, the library binds /opt/rocm's copy, torch then loads its own, and every hipMalloc of this library fails with
+    # "no ROCm-capable device is detected" (seen with `python __graft_entry__.py smoke`: build() loaded the library before anything had
+    # imported torch)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise BsgError(f'{LIB_PATH} not found: the HIP extension is not built. '
                        f'Run `python -m bisinger_amd.build`. There is no CPU fallback.')
