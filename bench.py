@@ -305,9 +305,13 @@ def roofline(bf16, layer_ms, n_layer, steps, b_per_gpu, path=None, clock=None):
         # split-fp16 stack launch (diffnet_h2.hip): every fp32 product as 3 fp16 MFMA products (hi hi, hi lo, lo hi), fp32 accumulate, so
         # the matrix pipe in use is the 16-bit one.  One launch = all 20 layers of up to 256 64-frame tiles; avg_ms = one layer over all rows
         executed = 3.0 * achieved
-        kname = 'residual_stack_q_kernel' if (path or '').startswith('stack_h2q') else 'residual_stack_h2_kernel'
-        shape = 'v_mfma_f32_16x16x32_f16' if kname == 'residual_stack_q_kernel' else 'v_mfma_f32_32x32x16_f16'
-        return dict(common, kernel=f'{kname} (20 fused DiffNet residual blocks + the step tail per launch; fp32 operands split exactly into hi + lo '
+        part = {'stack_h2_pair64': 'residual_part_h2_kernel<2, 8, 4> (a 64-frame tile on 2 CUs of one XCD, each half of the channels)',
+                'stack_h2_quad64': 'residual_part_h2_kernel<4, 4, 4> (a 64-frame tile on 4 CUs of one XCD, each a quarter of the channels)',
+                'stack_h2_quad': 'residual_part_h2_kernel<4, 4, 2> (a 32-frame tile on 4 CUs of one XCD, each a quarter of the channels)'}.get(path or '')
+        kname = part or ('residual_stack_q_kernel' if (path or '').startswith('stack_h2q') else 'residual_stack_h2_kernel')
+        shape = 'v_mfma_f32_16x16x32_f16' if part or kname == 'residual_stack_q_kernel' else 'v_mfma_f32_32x32x16_f16'
+        what = '20 fused DiffNet residual blocks per launch, the step tail in a launch of its own' if part else '20 fused DiffNet residual blocks + the step tail per launch'
+        return dict(common, kernel=f'{kname} ({what}; fp32 operands split exactly into hi + lo '
                                    f'fp16 terms, 3 fp16 MFMAs ({shape}) per fp32 product, fp32 accumulate; x and the skip sum on chip; figures per layer)',
                     frac_executed_at_sustained_clock=(executed / (PEAK_BF16_MFMA_TFLOPS * clock[0] / 2400.0)) if clock and clock[0] else None,
                     bound='mfma', achieved=achieved, peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s', frac=achieved / PEAK_BF16_MFMA_TFLOPS,
