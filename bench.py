@@ -380,6 +380,8 @@ class Workload:
                          rows=self.rows if self.world > 1 else None, **self.kw)
         if self.emulate:
             return out['mel_out']
+        if getattr(self, 'gather_on_host', False):      # --rehearse-one-gpu: gloo through host memory
+            return bdist.all_gather_rows(out['mel_out'].cpu(), self.B_total, self.world, self.rank)
         return bdist.all_gather_rows(out['mel_out'], self.B_total, self.world, self.rank)
 
 
@@ -656,7 +658,7 @@ def self_launch(args, argv):
     fresh child per GPU with the torchrun environment, forwards rank 0's record and returns the worst exit code."""
     import torch
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus and not args.selftest_procs:
+    if n_dev < args.gpus and not args.selftest_procs and not args.rehearse_one_gpu:
         sys.exit(f'bench.py --gpus {args.gpus}: this node exposes {n_dev} GPUs')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -708,6 +710,10 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2] / configs[4] secondaries (N = 1)')
     ap.add_argument('--no-weak', action='store_true', help='skip the weak-scaling figure (N > 1)')
     ap.add_argument('--force-dist', action='store_true', help='initialise RCCL and run the all-gather even with one rank (self-test)')
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='rehearsal of the N > 1 code path on a box with ONE GPU (tests/test_gpu_dist.py): every rank computes on cuda:0, the '
+                         'barrier / all-gather / max-over-ranks go over gloo through host memory.  Exercises the sharded workload, the timing '
+                         'protocol and the record; its numbers mean nothing (the ranks share one chip)')
     ap.add_argument('--selftest-procs', action='store_true',
                     help='process-management self-test (tests/test_dist_cpu.py): the N workers only rendezvous over gloo on the CPU, '
                          'all-gather their ranks and rank 0 prints a record; measures nothing')
@@ -736,11 +742,16 @@ def main():
         return
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X: the product path has no CPU fallback (GPUs visible: 0)')
+    rehearse = bool(args.rehearse_one_gpu) and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
-    if world > 1:
+    if rehearse:
+        bdist.init_distributed('gloo')
+    elif world > 1:
         bdist.init_distributed('nccl')
     elif args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -759,7 +770,7 @@ def main():
 
     def max_over_ranks(dt):
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt], device='cpu' if rehearse else device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return dt
@@ -767,6 +778,7 @@ def main():
     strong = world > 1 and args.batch is None
     B_total = B_CFG3_TOTAL if strong else (args.batch or B_CFG1) * world
     wl = Workload(model, device, B_total, rank, world)
+    wl.gather_on_host = rehearse
     if args.force_dist and world == 1:
         _step = wl.step
 
@@ -785,6 +797,7 @@ def main():
     weak = None
     if world > 1 and strong and not args.no_weak:
         wl2 = Workload(model, device, B_CFG1 * world, rank, world)
+        wl2.gather_on_host = rehearse
         k2 = max(2, min(args.steps, 5))
         dt2, _, _, mel2 = timed(wl2, k2, 1, fence, profile=False)
         dt2 = max_over_ranks(dt2)
@@ -825,6 +838,8 @@ def main():
         if use_dist:
             rec['ranks_seen_by_rccl'] = dist.get_world_size()
             rec['collective_backend'] = dist.get_backend()
+        if rehearse:
+            rec['rehearsal'] = 'every rank on cuda:0, collectives over gloo through host memory: the numbers of this line mean nothing'
         if weak:
             rec['weak_scaling'] = weak
         if world == 1 and not args.no_secondary and not bf16 and args.batch is None:

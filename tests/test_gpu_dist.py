@@ -107,3 +107,20 @@ def test_two_ranks_run_the_hip_path_and_gather():
     rec = json.loads([l for l in outs[0][0].splitlines() if l.startswith('{')][-1])
     assert rec['shape'] == [6, 120, 80] and rec['finite'] and rec['pending_timeouts'] == 0
     assert rec['max_abs'] <= 1e-3, rec
+
+
+def test_bench_n_gt_1_code_path_rehearsed_on_one_gpu():
+    """The driver runs `bench.py --gpus N` (N = 2, 4, 8) on an 8-GPU node that has never been available to this build: the N > 1 branch — rows of
+    configs[3] per rank with the rank-local token front, barrier + max-over-ranks timing, the gathered mels, the weak-scaling figure, the
+    record with the part kernel named in `roofline` — is rehearsed here with TWO rank processes on the one GPU of the box
+    (--rehearse-one-gpu: collectives over gloo through host memory).  Checks the record's shape, not its numbers."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--rehearse-one-gpu'],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stderr or '')[-3000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong' and rec['config']['global_batch'] == 64 and rec['config']['utterances_per_gpu'] == 32
+    assert rec['metric'] == 'mel_frames_per_sec' and rec['value'] > 0 and rec['steps'] == 1 and rec['handoff_timeouts'] == 0
+    assert rec['roofline']['frac'] > 0 and 'kernel' in rec['roofline']
+    assert rec['weak_scaling']['global_batch'] == 32 and rec['weak_scaling']['finite']
+    assert rec['collective_backend'] == 'gloo' and 'rehearsal' in rec
