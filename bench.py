@@ -102,7 +102,9 @@ def build_vocoder(device):
     spec = OrderedDict((k, tuple(v.shape)) for k, v in voc.state_dict().items())
     voc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, 7).items()})
     voc = voc.to(device)
-    voc.remove_weight_norm()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # (it prints 'Removing weight norm...' as the reference's does: stdout carries the ONE record)
+        voc.remove_weight_norm()
     return voc, cfg
 
 
