@@ -268,3 +268,39 @@ def test_every_handle_kind_guards_itself_and_only_itself(hifigan_sd, sd_spec):
         assert not w2 and ref.gemm_range_strikes == 0, (name, [str(v.message) for v in w2])
         assert torch.isfinite(got).all() and maxabs(got, want) <= 1e-5 * max(1.0, float(want.abs().max())), (name, maxabs(got, want))
         bystander_untouched()
+
+
+def test_two_host_threads_on_two_models_do_not_share_guard_state():
+    """include/bisinger_hip.h: 'distinct handles are independent'; the guard state a compute entry sees is thread-local (bsg::GuardScope in the
+    library, _lib._tls in the wrappers).  Two host threads, each with its own model on its own stream, run concurrently (ctypes releases the
+    GIL inside the library): thread A's input leaves the fp16 range of its FS2 GEMMs in every call — warned, repeated on the fp32 matrix pipe,
+    three strikes — while thread B's calls stay bit-identical to its reference, strike-free and on the split-fp16 GEMMs throughout."""
+    import threading
+    A, Bm = _diffusion(0), _diffusion(1)
+    d, kw = _inputs(2, 12, 64, 4)
+    noise = T_(synth.synth_noise(100, 2, 80, 64, seed=5)).cuda()
+    call = lambda m: m(d['txt_tokens'], mel2ph=d['mel2ph'], spk_embed=d['spk_embed'], ref_mels=None, infer=True, noise=noise, **kw)['mel_out'].clone()
+    ref_b = call(Bm)
+    with torch.no_grad():
+        A.fs2.encoder_embed_tokens.weight.mul_(3e4)
+    torch.cuda.synchronize()
+    res, errs = {'a': [], 'b': []}, []
+
+    def worker(tag, m, n):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for _ in range(n):
+                    res[tag].append(call(m))
+                s.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append((tag, repr(e)))
+
+    ta, tb = threading.Thread(target=worker, args=('a', A, 4)), threading.Thread(target=worker, args=('b', Bm, 8))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    assert len(res['a']) == 4 and all(bool(torch.isfinite(o).all()) for o in res['a'])
+    assert A.fs2.gemm_range_strikes == 3 and not A.fs2.gemm_split_enabled()
+    assert all(torch.equal(o, ref_b) for o in res['b'])
+    assert Bm.fs2.gemm_range_strikes == 0 and Bm.denoise_fn.gemm_range_strikes == 0 and Bm.fs2.gemm_split_enabled() and Bm.denoise_fn.gemm_split_enabled()
